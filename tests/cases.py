@@ -1,0 +1,32 @@
+"""Shared seeded test cases (TEST INFRASTRUCTURE): configs + synthetic tensors used by the golden
+generator (dev container, Tier A), the oracle tests (CPU, anywhere) and the GPU parity tests."""
+from v_express_amd import synth
+
+SMALL = dict(block_out_channels=(64, 128, 256, 256))          # head dims 8/16/32, 57.7 M params
+FULL = dict(block_out_channels=(320, 640, 1280, 1280))        # the SD-1.5 widths (head dims 40/80/160)
+SMALL_VAE = dict(block_out_channels=(32, 64, 128, 128))
+
+W_REF, W_AUD, GUIDANCE = 0.95, 3.0, 3.5                        # inference.py:66,69-70 defaults
+
+# name -> (unet cfg kwargs, F, latent h, latent w, timestep)
+FORWARD_CASES = {
+    "small_f4_8x8": (SMALL, 4, 8, 8, 959),
+    "small_f8_16x8": (SMALL, 8, 16, 8, 39),
+    "full_f4_8x8": (FULL, 4, 8, 8, 959),
+}
+
+# name -> (F, context_frames, context_overlap, steps)   (SMALL unet + SMALL_VAE, 8x8 latents)
+PIPELINE_CASES = {
+    "aligned_F10_c4o2": (10, 4, 2, 3),
+    "reflected_F11_c4o2": (11, 4, 2, 3),       # last window [8,9,10,9]: SURVEY.md Appendix D #10
+    "single_F8_c8o2": (8, 8, 2, 3),
+}
+
+
+def unet_cfg(kw):
+    return synth.UNetConfig(**kw)
+
+
+def oracle_cfg(kw):
+    import oracle
+    return oracle.UNetConfig(**kw)

@@ -1,0 +1,272 @@
+"""Seeded synthetic weights and inputs with the reference's state_dict key schema.
+
+No checkpoints exist offline, so parity tests and the benchmark use random-init
+weights.  Keys and shapes follow the reference modules exactly (SURVEY.md Appendix C;
+modules/unet_3d.py, unet_3d_blocks.py, attention.py:321-376, motion_module.py:119-144,207-234,
+transformer_3d.py:58-95, resnet.py:157-215, unet_2d_condition.py / unet_2d_blocks.py) so a real
+checkpoint loads through the same `load_state_dict` path.  tests/test_oracle_vs_reference.py checks the
+schema against the reference's own `state_dict()`.
+
+Draws: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) like torch's default Linear/Conv init; norm affine
+parameters are perturbed (gamma ~ 1 + 0.1 N, beta ~ 0.1 N) and the tensors the reference
+zero-initialises (attn2.to_out, motion proj_out — attention.py:361, motion_module.py:72-75) are
+re-drawn N(0, 0.02^2) so that every path is numerically live.
+"""
+import math
+from dataclasses import dataclass
+from typing import Tuple
+
+import torch
+
+
+@dataclass
+class UNetConfig:
+    """Architecture of both UNets (SD-1.5 config + inference_v2.yaml:1-23)."""
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    heads: int = 8
+    cross_attention_dim: int = 768
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    temporal_max_len: int = 32
+    attn_levels: Tuple[bool, ...] = (True, True, True, False)
+
+    @property
+    def time_embed_dim(self):
+        return self.block_out_channels[0] * 4
+
+
+@dataclass
+class VaeConfig:
+    latent_channels: int = 4
+    out_channels: int = 3
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_num_groups: int = 32
+    scaling_factor: float = 0.18215
+
+
+class _Gen:
+    def __init__(self, seed, device="cpu", dtype=torch.float32):
+        self.g = torch.Generator(device="cpu")
+        self.g.manual_seed(seed)
+        self.device = device
+        self.dtype = dtype
+        self.sd = {}
+
+    def _out(self, t):
+        return t.to(device=self.device, dtype=self.dtype)
+
+    def uniform(self, shape, bound):
+        return self._out((torch.rand(shape, generator=self.g) * 2 - 1) * bound)
+
+    def normal(self, shape, std, mean=0.0):
+        return self._out(torch.randn(shape, generator=self.g) * std + mean)
+
+    def linear(self, p, cin, cout, bias=True, small=False):
+        b = 1.0 / math.sqrt(cin)
+        self.sd[p + ".weight"] = self.normal((cout, cin), 0.02) if small else self.uniform((cout, cin), b)
+        if bias:
+            self.sd[p + ".bias"] = self.normal((cout,), 0.02) if small else self.uniform((cout,), b)
+
+    def conv(self, p, cin, cout, k):
+        b = 1.0 / math.sqrt(cin * k * k)
+        self.sd[p + ".weight"] = self.uniform((cout, cin, k, k), b)
+        self.sd[p + ".bias"] = self.uniform((cout,), b)
+
+    def norm(self, p, c):
+        self.sd[p + ".weight"] = self.normal((c,), 0.1, 1.0)
+        self.sd[p + ".bias"] = self.normal((c,), 0.1)
+
+    def attn(self, p, c, ctx=None, out_small=False, qkv_bias=False):
+        ctx = ctx or c
+        self.linear(p + ".to_q", c, c, bias=qkv_bias)
+        self.linear(p + ".to_k", ctx, c, bias=qkv_bias)
+        self.linear(p + ".to_v", ctx, c, bias=qkv_bias)
+        self.linear(p + ".to_out.0", c, c, small=out_small)
+        if out_small:   # only the weight is zero-initialised in the reference; bias keeps default init
+            self.sd[p + ".to_out.0.bias"] = self.uniform((c,), 1.0 / math.sqrt(c))
+
+    def ff(self, p, c):
+        self.linear(p + ".net.0.proj", c, 8 * c)
+        self.linear(p + ".net.2", 4 * c, c)
+
+    def resnet(self, p, cin, cout, temb):
+        self.norm(p + ".norm1", cin)
+        self.conv(p + ".conv1", cin, cout, 3)
+        if temb:
+            self.linear(p + ".time_emb_proj", temb, cout)
+        self.norm(p + ".norm2", cout)
+        self.conv(p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            self.conv(p + ".conv_shortcut", cin, cout, 1)
+
+
+def pe_table(max_len, d_model):
+    """PositionalEncoding buffer (modules/motion_module.py:262-277): pe[0,:,0::2]=sin, 1::2=cos."""
+    position = torch.arange(max_len).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+    pe = torch.zeros(1, max_len, d_model)
+    pe[0, :, 0::2] = torch.sin(position * div_term)
+    pe[0, :, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def block_plan(cfg: UNetConfig):
+    """Channel walk shared by both UNets (modules/unet_3d.py:112-227)."""
+    ch = cfg.block_out_channels
+    n = len(ch)
+    plan = {"down": [], "up": []}
+    out_c = ch[0]
+    for i in range(n):
+        in_c, out_c = out_c, ch[i]
+        layers = [dict(cin=in_c if j == 0 else out_c, cout=out_c) for j in range(cfg.layers_per_block)]
+        plan["down"].append(dict(prefix=f"down_blocks.{i}", layers=layers, attn=cfg.attn_levels[i],
+                                 sampler=(i != n - 1), c=out_c))
+    plan["mid"] = dict(prefix="mid_block", c=ch[-1])
+    rev = list(reversed(ch))
+    rev_attn = list(reversed(cfg.attn_levels))
+    out_c = rev[0]
+    for i in range(n):
+        prev_out, out_c = out_c, rev[i]
+        in_c = rev[min(i + 1, n - 1)]
+        nl = cfg.layers_per_block + 1
+        layers = []
+        for j in range(nl):
+            skip = in_c if j == nl - 1 else out_c
+            rin = prev_out if j == 0 else out_c
+            layers.append(dict(cin=rin + skip, cout=out_c, c_hidden=rin, c_skip=skip))
+        plan["up"].append(dict(prefix=f"up_blocks.{i}", layers=layers, attn=rev_attn[i],
+                               sampler=(i != n - 1), c=out_c))
+    return plan
+
+
+def _spatial_block_3d(g: _Gen, p, c, cfg):
+    g.norm(p + ".norm", c)
+    g.conv(p + ".proj_in", c, c, 1)
+    g.conv(p + ".proj_out", c, c, 1)
+    t = p + ".transformer_blocks.0"
+    g.attn(t + ".attn1", c)
+    g.norm(t + ".norm1", c)
+    g.attn(t + ".attn1_5", c)
+    g.norm(t + ".norm1_5", c)
+    g.attn(t + ".attn2", c, ctx=cfg.cross_attention_dim, out_small=True)
+    g.norm(t + ".norm2", c)
+    g.ff(t + ".ff", c)
+    g.norm(t + ".norm3", c)
+
+
+def _motion_module(g: _Gen, p, c, cfg):
+    t = p + ".temporal_transformer"
+    g.norm(t + ".norm", c)
+    g.linear(t + ".proj_in", c, c)
+    b = t + ".transformer_blocks.0"
+    for i in range(2):
+        a = f"{b}.attention_blocks.{i}"
+        g.attn(a, c)
+        g.sd[a + ".pos_encoder.pe"] = g._out(pe_table(cfg.temporal_max_len, c))
+        g.norm(f"{b}.norms.{i}", c)
+    g.ff(b + ".ff", c)
+    g.norm(b + ".ff_norm", c)
+    g.linear(t + ".proj_out", c, c, small=True)
+
+
+def _spatial_block_2d(g: _Gen, p, c, cfg):
+    g.norm(p + ".norm", c)
+    g.conv(p + ".proj_in", c, c, 1)
+    g.conv(p + ".proj_out", c, c, 1)
+    t = p + ".transformer_blocks.0"
+    g.norm(t + ".norm1", c)
+    g.attn(t + ".attn1", c)
+    g.norm(t + ".norm2", c)
+    g.attn(t + ".attn2", c, ctx=cfg.cross_attention_dim)
+    g.norm(t + ".norm3", c)
+    g.ff(t + ".ff", c)
+
+
+def _unet_common(g: _Gen, cfg: UNetConfig, three_d: bool):
+    ch0 = cfg.block_out_channels[0]
+    temb = cfg.time_embed_dim
+    g.conv("conv_in", cfg.in_channels, ch0, 3)
+    g.linear("time_embedding.linear_1", ch0, temb)
+    g.linear("time_embedding.linear_2", temb, temb)
+    plan = block_plan(cfg)
+    spatial = _spatial_block_3d if three_d else _spatial_block_2d
+    for blk in plan["down"] + plan["up"]:
+        p = blk["prefix"]
+        for j, l in enumerate(blk["layers"]):
+            g.resnet(f"{p}.resnets.{j}", l["cin"], l["cout"], temb)
+            if blk["attn"]:
+                spatial(g, f"{p}.attentions.{j}", l["cout"], cfg)
+            if three_d:
+                _motion_module(g, f"{p}.motion_modules.{j}", l["cout"], cfg)
+        if blk["sampler"]:
+            name = "downsamplers" if p.startswith("down") else "upsamplers"
+            g.conv(f"{p}.{name}.0.conv", blk["c"], blk["c"], 3)
+    c = plan["mid"]["c"]
+    g.resnet("mid_block.resnets.0", c, c, temb)
+    spatial(g, "mid_block.attentions.0", c, cfg)
+    if three_d:
+        _motion_module(g, "mid_block.motion_modules.0", c, cfg)
+    g.resnet("mid_block.resnets.1", c, c, temb)
+    if three_d:
+        g.norm("conv_norm_out", ch0)
+    g.conv("conv_out", ch0, cfg.out_channels, 3)
+
+
+def unet3d_state_dict(cfg: UNetConfig = None, seed=42, device="cpu", dtype=torch.float32):
+    """Denoising UNet3DConditionModel weights (1386 tensors at the SD-1.5 config)."""
+    g = _Gen(seed, device, dtype)
+    _unet_common(g, cfg or UNetConfig(), True)
+    return g.sd
+
+
+def refnet_state_dict(cfg: UNetConfig = None, seed=43, device="cpu", dtype=torch.float32):
+    """ReferenceNet (UNet2DConditionModel, conv_norm_out=None: unet_2d_condition.py:650) weights."""
+    g = _Gen(seed, device, dtype)
+    _unet_common(g, cfg or UNetConfig(), False)
+    return g.sd
+
+
+def vae_decoder_state_dict(cfg: VaeConfig = None, seed=44, device="cpu", dtype=torch.float32):
+    """sd-vae-ft-mse decoder half of diffusers AutoencoderKL (post_quant_conv + decoder.*)."""
+    cfg = cfg or VaeConfig()
+    g = _Gen(seed, device, dtype)
+    ch = list(cfg.block_out_channels)
+    g.conv("post_quant_conv", cfg.latent_channels, cfg.latent_channels, 1)
+    g.conv("decoder.conv_in", cfg.latent_channels, ch[-1], 3)
+    for j in range(2):
+        g.resnet(f"decoder.mid_block.resnets.{j}", ch[-1], ch[-1], None)
+    a = "decoder.mid_block.attentions.0"
+    g.norm(a + ".group_norm", ch[-1])
+    g.attn(a, ch[-1], qkv_bias=True)
+    rev = list(reversed(ch))
+    prev = rev[0]
+    for i, c in enumerate(rev):
+        for j in range(cfg.layers_per_block + 1):
+            g.resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else c, c, None)
+        if i != len(rev) - 1:
+            g.conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", c, c, 3)
+        prev = c
+    g.norm("decoder.conv_norm_out", ch[0])
+    g.conv("decoder.conv_out", ch[0], cfg.out_channels, 3)
+    return g.sd
+
+
+def synthetic_inputs(cfg: UNetConfig, num_frames, latent_h, latent_w, seed=42, device="cpu", dtype=torch.float32):
+    """Synthetic clip inputs: start latents N(0,1) drawn in fp32 on CPU then cast;
+    reference latent N(0,1)*0.18215; kps features cat([0, N(0,0.1^2)]); audio cat([0, N(0,1)])."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    c0 = cfg.block_out_channels[0]
+    latents = torch.randn(1, cfg.in_channels, num_frames, latent_h, latent_w, generator=g)
+    ref_latents = torch.randn(1, cfg.in_channels, latent_h, latent_w, generator=g) * 0.18215
+    kps = torch.randn(1, c0, num_frames, latent_h, latent_w, generator=g) * 0.1
+    kps = torch.cat([torch.zeros_like(kps), kps], dim=0)
+    audio = torch.randn(1, num_frames, 5, cfg.cross_attention_dim, generator=g)
+    audio = torch.cat([torch.zeros_like(audio), audio], dim=0)
+    to = dict(device=device, dtype=dtype)
+    return dict(latents=latents.to(**to), ref_latents=ref_latents.to(**to), kps_features=kps.to(**to),
+                audio_embeddings=audio.to(**to))
