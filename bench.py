@@ -1,0 +1,243 @@
+"""Benchmark of the V-Express denoising hot path on MI355X — BASELINE.json metric:
+decoded frames/sec at 512x512, 25 DDIM steps.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
+
+One "step" = one full pass of the hot path over one synthetic clip: 25 DDIM steps of the sliding-window
+mean-overlap loop (CFG UNet3D forwards + fused CFG/overlap/DDIM update) followed by the sd-vae-ft-mse decode of
+every frame.  Inputs (latents, kps features, audio embeddings, reference banks) are resident in HBM when the
+timed region starts; the once-per-clip prologue (ReferenceNet + bank K/V precompute) is timed separately.
+
+Workload: N=1 is BASELINE.json configs[1] (16 frames = one 16-frame window).  N>1 is weak scaling: F = 12*N + 4
+frames = N windows of 16 with overlap 4, i.e. one window (both CFG halves) per GPU per DDIM step, latents
+exchanged by one RCCL all-gather per step; the decode is split over the ranks.  value = F*K / max-over-ranks time.
+
+Extra objects in the JSON line:
+  roofline      dominant kernel = the MFMA GEMM / implicit-conv kernel (bound "mfma"): algorithmic FLOPs of every
+                vx_gemm launch (2*M*N*K) / its HIP-event duration, measured on ONE extra instrumented DDIM step after
+                the timed region (events on the launch stream); `whole_path` = fps * algorithmic FLOP per frame
+                (66.4 TFLOP/frame at F=16) / peak.
+  cpu_baseline  the fp32 oracle (port of the reference path) on the host cores: one CFG UNet3D forward at 512^2 with a
+                4-frame window + one frame of VAE decode, extrapolated linearly (x4 frames, x25 steps, x16 frames).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+UNET_TFLOP_PER_FRAME_FWD = 1.277   # 40.86 TFLOP per CFG forward of 2x16 frames at 512^2
+VAE_TFLOP_PER_FRAME = 2.515
+
+
+def flop_per_frame(num_frames, windows, steps, scale):
+    unet = steps * 2 * UNET_TFLOP_PER_FRAME_FWD * (16 * windows / num_frames)
+    return (unet + VAE_TFLOP_PER_FRAME) * scale
+
+
+def cpu_baseline(size, seconds_budget):
+    """Port (`oracle/`) of the reference path timed on the host cores, bounded sample."""
+    import oracle
+    from oracle import unet as OU
+    from oracle import vae as OV
+    from v_express_amd import synth
+    torch.set_num_threads(os.cpu_count())
+    cfg, ocfg = synth.UNetConfig(), oracle.UNetConfig()
+    h = w = size // 8
+    f = 4
+    t0 = time.time()
+    sd3 = synth.unet3d_state_dict(cfg)
+    inp = synth.synthetic_inputs(cfg, f, h, w)
+    banks = {}
+    from v_express_amd.synth import block_plan
+    plan = block_plan(cfg)
+    g = torch.Generator().manual_seed(1)
+    hh = h
+    for blk in plan["down"]:
+        if blk["attn"]:
+            for j in range(len(blk["layers"])):
+                banks[f"{blk['prefix']}.attentions.{j}"] = torch.randn(1, hh * hh, blk["c"], generator=g)
+        if blk["sampler"]:
+            hh //= 2
+    banks["mid_block.attentions.0"] = torch.randn(1, hh * hh, plan["mid"]["c"], generator=g)
+    for blk in plan["up"]:
+        if blk["attn"]:
+            for j in range(len(blk["layers"])):
+                banks[f"{blk['prefix']}.attentions.{j}"] = torch.randn(1, hh * hh, blk["c"], generator=g)
+        if blk["sampler"]:
+            hh *= 2
+    rb = OU.reader_banks(banks)
+    x = inp["latents"].repeat(2, 1, 1, 1, 1)
+    ehs = inp["audio_embeddings"].reshape(-1, 5, 768)
+    gen_s = time.time() - t0
+    with torch.no_grad():
+        t0 = time.time()
+        OU.unet3d_forward(sd3, ocfg, x, 519, ehs, inp["kps_features"], rb, 0.95, 3.0)
+        unet_s = time.time() - t0
+        del sd3
+        vcfg = synth.VaeConfig()
+        sdv = synth.vae_decoder_state_dict(vcfg)
+        z = inp["latents"][0, :, :1].permute(1, 0, 2, 3).contiguous()
+        t0 = time.time()
+        OV.vae_decode(sdv, oracle.VaeConfig(), z)
+        vae_s = time.time() - t0
+    clip_s = unet_s * (16 / f) * 25 + vae_s * 16
+    return dict(value=16.0 / clip_s, unit="frames/s", cores=os.cpu_count(), kind="port",
+                sample=(f"oracle fp32: 1 CFG UNet3D forward {size}x{size} f={f} ({unet_s:.1f} s) + 1 frame VAE decode "
+                        f"({vae_s:.1f} s) on {torch.get_num_threads()} threads; extrapolated x(16/{f}) frames x25 "
+                        f"steps + x16 frames = {clip_s:.0f} s per 16-frame clip"),
+                unet_forward_s=unet_s, vae_frame_s=vae_s)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--ddim-steps", type=int, default=25)
+    ap.add_argument("--frames", type=int, default=0, help="override the clip length (default 12*gpus+4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    import v_express_amd as vx
+    from v_express_amd import ops, synth
+    from v_express_amd.context import uniform
+
+    cfg, vcfg = synth.UNetConfig(), synth.VaeConfig()
+    ctx, ovl = 16, 4
+    F = args.frames or (ctx - ovl) * world + ovl
+    h = w = args.size // 8
+    t_build = time.time()
+    unet = vx.UNet3DConditionModel(cfg).to(dev)
+    refnet = vx.UNet2DConditionModel(cfg).to(dev)
+    vae = vx.AutoencoderKLDecoder(vcfg).to(dev)
+    unet.load_state_dict(synth.unet3d_state_dict(cfg, seed=42, device=dev, dtype=torch.bfloat16, draw_on_device=True))
+    unet.release_raw_weights()
+    refnet.load_state_dict(synth.refnet_state_dict(cfg, seed=43, device=dev, dtype=torch.bfloat16, draw_on_device=True))
+    refnet.release_raw_weights()
+    vae.load_state_dict(synth.vae_decoder_state_dict(vcfg, seed=44, device=dev, dtype=torch.bfloat16,
+                                                     draw_on_device=True))
+    vae._prepared()
+    sched = vx.DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                             steps_offset=1, prediction_type="v_prediction", rescale_betas_zero_snr=True,
+                             timestep_spacing="trailing")
+    pipe = vx.VExpressPipeline(vae=vae, reference_net=refnet, denoising_unet=unet, scheduler=sched)
+    inp = synth.synthetic_inputs(cfg, F, h, w, seed=42, device=dev)
+    torch.cuda.synchronize()
+    t_build = time.time() - t_build
+
+    # ---- once-per-clip prologue (ReferenceNet -> banks -> K/V of every attn1_5), timed separately
+    writer = vx.ReferenceAttentionControl(refnet, do_classifier_free_guidance=True, mode="write", fusion_blocks="full")
+    reader = vx.ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", fusion_blocks="full",
+                                          reference_attention_weight=0.95, audio_attention_weight=3.0)
+    ehs0 = torch.zeros(1, 1, 768, device=dev)
+    refnet(inp["ref_latents"], timestep=0, encoder_hidden_states=ehs0, return_dict=False)   # warm
+    torch.cuda.synchronize()
+    t0 = time.time()
+    refnet(inp["ref_latents"], timestep=0, encoder_hidden_states=ehs0, return_dict=False)
+    reader.update(writer, True)
+    torch.cuda.synchronize()
+    prologue_s = time.time() - t0
+
+    sched.set_timesteps(args.ddim_steps)
+    timesteps = sched.timesteps.tolist()
+    windows = list(uniform(step=0, num_frames=F, context_size=ctx, context_stride=1, context_overlap=ovl,
+                           closed_loop=False))
+    c0 = cfg.block_out_channels[0]
+    kps_tokens = ops.ncfhw_to_nhwc(inp["kps_features"], c0).view(2, F, h * w, c0)
+    audio = inp["audio_embeddings"].to(torch.bfloat16).contiguous()
+
+    def one_clip():
+        lat = inp["latents"].clone()
+        pipe.denoise(lat, kps_tokens, audio, timesteps, windows, 3.5)
+        return pipe.decode_latents(lat)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        video = one_clip()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        video = one_clip()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert video.shape == (1, 3, F, args.size, args.size) and torch.isfinite(video).all()
+    fps = F * args.steps / elapsed
+    scale = (args.size / 512.0) ** 2
+    fpf = flop_per_frame(F, len(windows), args.ddim_steps, scale)
+
+    result = {
+        "metric": "decoded frames/sec at 512x512, 25 DDIM steps", "value": fps, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": (f"{args.size}x{args.size}, {F} frames ({len(windows)} window(s) of {ctx}, overlap {ovl}), "
+                                f"{args.ddim_steps} DDIM steps, CFG 3.5, random-init UNet3D + ReferenceNet banks + "
+                                "sd-vae-ft-mse decode"),
+                   "frames": F, "windows": len(windows), "parallelism": f"window x CFG-half units over {world} GPU(s)"},
+        "prologue_ms": 1e3 * prologue_s, "model_build_s": t_build,
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # one instrumented DDIM step (all of this rank's UNet calls) + the decode of its frames
+        with ops.GemmProfile() as prof:
+            lat = inp["latents"].clone()
+            pipe.denoise(lat, kps_tokens, audio, timesteps[:1], windows, 3.5)
+            pipe.vae.decode_video(lat[:, :, :min(F, 4)].contiguous(), chunk=4)
+        summ = prof.summary()
+        tot_s = sum(v["seconds"] for v in summ.values())
+        tot_f = sum(v["flops"] for v in summ.values())
+        dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
+        ach = dom[1]["flops"] / dom[1]["seconds"] / 1e12
+        result["roofline"] = {
+            "bound": "mfma", "kernel": dom[0], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+            "avg_launch_us": 1e6 * dom[1]["seconds"] / dom[1]["launches"], "launches": dom[1]["launches"],
+            "all_gemm_tflops": tot_f / tot_s / 1e12,
+            "per_kernel": {k: {"launches": v["launches"], "avg_us": 1e6 * v["seconds"] / v["launches"],
+                               "tflops": v["flops"] / v["seconds"] / 1e12} for k, v in summ.items()},
+            "whole_path": {"tflop_per_frame": fpf, "achieved": fps * fpf / world, "frac": fps * fpf / world / PEAK_BF16_TFLOPS,
+                           "note": "fps x algorithmic TFLOP/frame (SURVEY.md 8d) per GPU / 2.5 PFLOP/s"},
+        }
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.size, 30)
+        result["speedup_vs_cpu"] = fps / result["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

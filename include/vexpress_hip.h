@@ -1,0 +1,140 @@
+/* libvexpress_hip.so — C ABI of the MI355X (gfx950) V-Express denoising hot path.
+ *
+ * The reference (tencent-ailab/V-Express) has no FFI/plugin interface: its hot path is Python calling
+ * PyTorch aten ops.  Each entry point below replaces the aten call sites named in
+ * its comment (paths relative to the reference root).  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates all buffers, incl. workspaces);
+ *   - activations are bfloat16, channels-last tokens:  [(b f), H*W, C]  ==  NHWC per frame;
+ *   - norm affine parameters, biases and statistics are float32; weights are bfloat16 [N, K], K contiguous,
+ *     conv weights pre-laid-out as [Cout][ky][kx][Cin];
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*); no host threads, no
+ *     device-wide synchronisation, no global mutable state except the last-error string;
+ *   - return value: 0 = ok, <0 = error (VX_ERR_*), message via vx_last_error_string(); nothing throws or exits.
+ */
+#ifndef VEXPRESS_HIP_H
+#define VEXPRESS_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VX_ABI_VERSION 1
+
+const char* vx_last_error_string(void);
+int vx_abi_version(void);
+/* device properties snapshot: out[0]=CU count, out[1]=LDS bytes per block, out[2]=wavefront size, out[3]=clock kHz */
+int vx_device_info(int device, int* out4);
+
+/* ---- GEMM / implicit-GEMM convolution on MFMA -------------------------------------------------------------
+ * out[m, n] = epilogue( sum_k A[m, k] * W[n, k] ),  m = (frame, oy, ox), k = (ky, kx, ci).
+ * Replaces: F.conv2d via InflatedConv3d (modules/resnet.py:9-17: resnet conv1/conv2 :223,:244, conv_shortcut :247,
+ * Downsample3D :106-118, Upsample3D :59-88 with `upsample`=1 fusing the nearest-2x gather), Transformer3DModel
+ * proj_in/proj_out 1x1 (modules/transformer_3d.py:126,154), every F.linear of diffusers Attention/FeedForward reached
+ * from modules/mutual_self_attention.py:177-247 and modules/motion_module.py:158,177,243-256, TimestepEmbedding
+ * (modules/unet_3d.py:470) and ResnetBlock3D.time_emb_proj (modules/resnet.py:226), torch.cat skip concat
+ * (modules/unet_3d_blocks.py:694,831) as the dual-source A operand (a/a2).
+ */
+enum { VX_EPI_STORE = 0, VX_EPI_GEGLU = 1, VX_EPI_SPLIT = 2 };
+enum { VX_PART_ROWS = 0, VX_PART_VT = 1 };
+enum { VX_ACT_NONE = 0, VX_ACT_SILU = 1 };
+
+typedef struct {
+  /* A operand: up to two channel-concatenated NHWC sources (a2 may be NULL) */
+  const void* a;
+  const void* a2;
+  int32_t c1, c2;            /* channels taken from a / a2 (multiples of 8)                       */
+  int32_t lda1, lda2;        /* pixel (row) stride of a / a2 in elements                          */
+  int32_t nb, h_in, w_in;    /* frames, stored input height/width (before the optional upsample)   */
+  int32_t kh, kw, stride, pad;
+  int32_t upsample;          /* 1: input is nearest-2x upsampled on the fly                        */
+  int32_t h_out, w_out;
+  /* B operand */
+  const void* w;             /* bf16 [n, k], k = kh*kw*(c1+c2)                                    */
+  int32_t n, k, m;           /* m = nb*h_out*w_out                                                */
+  /* epilogue */
+  int32_t epi;               /* VX_EPI_*                                                          */
+  int32_t act;               /* VX_ACT_* (STORE only)                                             */
+  float alpha;               /* STORE: out = residual + alpha * act(acc + bias + rowbias)         */
+  const float* bias;         /* [n] or NULL                                                       */
+  const float* rowbias;      /* [m / rows_per_group][rowbias_ld] or NULL (time-embedding add)     */
+  int32_t rowbias_ld, rows_per_group;
+  const void* residual;      /* bf16 [m, ldr] or NULL (may alias out)                             */
+  int32_t ldr;
+  void* out;                 /* STORE/GEGLU destination                                           */
+  int32_t ldc;
+  int32_t out_f32;           /* STORE: 1 = write float32 instead of bf16                          */
+  /* SPLIT: columns [p*part_cols, (p+1)*part_cols) go to part p */
+  int32_t part_cols, n_parts;
+  void* part_out[3];
+  int32_t part_kind[3];      /* VX_PART_ROWS: [m, part_ld] ; VX_PART_VT: [m/seq_len, heads, head_dim, vt_pitch] */
+  int32_t part_ld[3];
+  int32_t seq_len, head_dim, vt_pitch;
+} vx_gemm_params;
+
+int vx_gemm(const vx_gemm_params* p, void* stream);
+
+/* ---- GroupNorm (+SiLU), per-frame statistics, NHWC, optional dual (concat) source --------------------------
+ * Replaces F.group_norm via InflatedGroupNorm (modules/resnet.py:20-28; :220-221,:235,:241), Transformer3DModel.norm
+ * (modules/transformer_3d.py:124), motion-module norm (modules/motion_module.py:156), conv_norm_out + SiLU
+ * (modules/unet_3d.py:571-572).  ws: float32 workspace of vx_groupnorm_ws_floats() elements. */
+int64_t vx_groupnorm_ws_floats(int frames, int slices, int groups);
+int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int frames, int hw, int groups, float eps,
+                 const float* gamma, const float* beta, int silu, void* out, float* ws, int slices, void* stream);
+
+/* ---- LayerNorm over the channel axis (+ optional additive table: motion-module positional encoding) -------
+ * Replaces F.layer_norm (modules/attention.py:329-376 norms via mutual_self_attention.py:176-247;
+ * modules/motion_module.py:228,234) and `x + pe[:, :f]` (modules/motion_module.py:262-277,365-366):
+ * out[r, :] = LN(x[r, :]) * gamma + beta + (add ? add[(r / add_rows_per_entry) % add_entries, :] : 0). */
+int vx_layernorm(const void* x, int ldx, int rows, int c, float eps, const float* gamma, const float* beta,
+                 const float* add, int add_rows_per_entry, int add_entries, void* out, int ldo, void* stream);
+
+/* ---- Fused (flash-style) attention, softmax(q k^T * scale) v, per (batch, head) ----------------------------
+ * Replaces F.scaled_dot_product_attention via diffusers AttnProcessor2_0 for attn1 / attn1_5
+ * (modules/mutual_self_attention.py:177-224) and the sd-vae-ft-mse mid-block attention.
+ * q: bf16 rows [batch*n_q] with row stride ldq, head h at column h*head_dim; k likewise (kv batch = batch / q_per_kv);
+ * vt: bf16 [kv_batches, heads, head_dim, vt_pitch] (keys contiguous); out: bf16 rows, stride ldo. */
+int vx_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_pitch, void* out, int ldo,
+                 int batch, int heads, int n_q, int n_kv, int head_dim, int q_per_kv, float scale, void* stream);
+
+/* ---- Temporal self-attention over the frame axis (one sequence per (batch row, pixel, head)) ---------------
+ * Replaces VersatileAttention.forward (modules/motion_module.py:351-388) incl. both einops transposes:
+ * tokens stay [(b f), hw, 3C] / [(b f), hw, C]; the kernel strides over f. */
+int vx_temporal_attention(const void* qkv, int ldqkv, void* out, int ldo, int b, int f, int hw, int heads,
+                          int head_dim, float scale, void* stream);
+
+/* ---- Cross-attention against a short key/value list (audio tokens: 5 keys) --------------------------------
+ * Replaces attn2 SDPA (modules/mutual_self_attention.py:227-244).  q: [batch*n_q, ldq]; kv: [batch, n_kv, ldkv] with
+ * K at column 0 and V at column v_off; n_kv <= 16. */
+int vx_small_kv_attention(const void* q, int ldq, const void* kv, int ldkv, int v_off, void* out, int ldo,
+                          int batch, int n_q, int n_kv, int heads, int head_dim, float scale, void* stream);
+
+/* ---- elementwise / layout ---------------------------------------------------------------------------------- */
+/* x[r, :] += alpha * bias[:]  (uncond half of reference attention == to_out bias) */
+int vx_add_row_bias(void* x, int ldx, int rows, int c, const float* bias, float alpha, void* stream);
+/* gather window frames of the fp32 latent clip [1,C,F,h,w] into NHWC bf16 [reps*f, h*w, c_pad] (channels >= C zero).
+ * Replaces latents[:, :, context].repeat(2,...) + rearrange (pipelines/v_express_pipeline.py:538-539, resnet.py:13). */
+int vx_gather_latents(const float* latents, int c, int total_frames, int hw, const int32_t* frame_ids, int f,
+                      int reps, int c_pad, void* out, void* stream);
+/* CFG combine of one window: pred[w_slot, c, li, hw] = u + s * (c - u) from the conv_out result
+ * [2f, hw, ld] float32 (rows: uncond frames then cond frames).  pipelines/v_express_pipeline.py:548-550. */
+int vx_cfg_combine(const float* unet_out, int ld, int c, int f, int hw, float guidance, float* pred_slot,
+                   void* stream);
+/* per-frame mean-overlap + DDIM v-prediction step (eta=0):  v = sum_t (pred[term_slot[t]] / count) ;
+ * latents[:, :, frame] = step(v).  terms: int32 [n_frames][max_terms][2] = (window slot, latent idx) or -1.
+ * pipelines/v_express_pipeline.py:552-572 + diffusers DDIMScheduler.step.  */
+int vx_overlap_ddim_step(float* latents, int c, int total_frames, int hw, const float* preds, int f_window,
+                         const int32_t* terms, int max_terms, const int32_t* frame_ids, const float* count,
+                         int n_frames, float sqrt_a, float sqrt_1ma, float sqrt_ap, float sqrt_1map, void* stream);
+/* NCHW-ish float32 [b, C, f, h, w] -> NHWC bf16 [(b f), h*w, c_pad]  (API-boundary layout change) */
+int vx_ncfhw_to_nhwc(const float* x, int b, int c, int f, int hw, int c_pad, void* out, void* stream);
+/* NHWC float32 [(b f), hw, ld] -> [b, C, f, h*w] float32 */
+int vx_nhwc_to_ncfhw(const float* x, int ld, int b, int c, int f, int hw, float* out, void* stream);
+/* VAE post-process: NHWC float32 [n, hw, ld] -> clamp(x/2+0.5, 0, 1) as [n, 3, hw] float32
+ * (pipelines/v_express_pipeline.py:160). */
+int vx_vae_postprocess(const float* x, int ld, int n, int c, int hw, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,333 @@
+"""Per-kernel parity on a real MI355X: every libvexpress_hip entry point, called through the C ABI (ctypes), against
+a float32 PyTorch restatement of the same op fed the same bf16-rounded inputs.
+
+Tolerance (written per test): outputs are bf16, so the only error vs an fp32 evaluation of the same bf16 inputs is
+accumulation order + one final rounding:  max|err| <= 2^-7 * max|ref| (+ tiny abs) and relative L2 <= 6e-3.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from v_express_amd import ops as o
+    return o
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=BF):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to("cuda").to(dtype)
+
+
+def check(got, ref, what, rel=6e-3, mx=2 ** -7):
+    got, ref = got.float(), ref.float()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite output ({(~torch.isfinite(got)).sum().item()} elements)"
+    err = (got - ref).abs()
+    scale = ref.abs().max().item() + 1e-12
+    rl2 = (err.pow(2).sum().sqrt() / (ref.pow(2).sum().sqrt() + 1e-12)).item()
+    i = err.argmax().item()
+    idx = tuple(int(v) for v in torch.unravel_index(torch.tensor(i), got.shape))
+    msg = (f"{what}: max|err|={err.max().item():.4g} at {idx} (got {got.flatten()[i].item():.5g}, ref "
+           f"{ref.flatten()[i].item():.5g}), max|ref|={scale:.4g}, relL2={rl2:.3g}; "
+           f"frac>tol={(err > mx * scale + 1e-5).float().mean().item():.4g}")
+    assert err.max().item() <= mx * scale + 1e-5 and rl2 <= rel, msg
+
+
+# ----------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("m,n,k", [(256, 320, 320), (200, 64, 72), (131, 1280, 640), (64, 8, 2880), (2, 1280, 320),
+                                   (300, 192, 64), (1000, 960, 320), (257, 128, 128), (512, 2560, 1280)])
+def test_gemm_plain(ops, m, n, k):
+    a, w = rnd(m, k), rnd(n, k, scale=k ** -0.5, seed=1)
+    bias = rnd(n, seed=2, dtype=torch.float32)
+    out = ops.gemm(a, w, bias)
+    check(out, a.float() @ w.float().t() + bias, f"gemm {m}x{n}x{k}")
+
+
+def test_gemm_epilogue_options(ops):
+    from v_express_amd import lib as L
+    m, n, k, grp = 384, 320, 256, 96
+    a, w = rnd(m, k), rnd(n, k, scale=k ** -0.5, seed=1)
+    bias = rnd(n, seed=2, dtype=torch.float32)
+    rowbias_full = rnd(m // grp, 3 * n, seed=3, dtype=torch.float32)
+    rowbias = rowbias_full[:, n:2 * n]                       # strided view, like the time-embedding slices
+    res = rnd(m, n, seed=4)
+    base = a.float() @ w.float().t() + bias + rowbias.repeat_interleave(grp, 0)
+    out = ops.gemm(a, w, bias, rowbias=rowbias, rows_per_group=grp, residual=res, alpha=0.95)
+    check(out, res.float() + 0.95 * base, "gemm bias+rowbias+alpha+residual")
+    out = ops.gemm(a, w, bias, act=L.VX_ACT_SILU, out_f32=True)
+    assert out.dtype == torch.float32
+    check(out, F.silu(a.float() @ w.float().t() + bias), "gemm silu f32-out", rel=1e-4, mx=1e-4)
+    # in-place residual (out aliases residual) and strided A / out views
+    big = rnd(m, 3 * k, seed=5)
+    h = res.clone()
+    ops.gemm(big[:, k:2 * k], w, bias, residual=h, out=h)
+    check(h, res.float() + big[:, k:2 * k].float() @ w.float().t() + bias, "gemm in-place residual, strided A")
+
+
+def _conv_ref(x_nhwc, w_oihw, bias, stride, pad, upsample):
+    x = x_nhwc.float().permute(0, 3, 1, 2)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(x, w_oihw.float(), bias, stride=stride, padding=pad)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("nb,h,w,cin,cout,kk,stride,pad,ups", [
+    (3, 16, 16, 64, 320, 3, 1, 1, 0), (2, 16, 12, 320, 64, 3, 2, 1, 0), (2, 8, 8, 128, 160, 3, 1, 1, 1),
+    (2, 8, 8, 8, 320, 3, 1, 1, 0), (1, 32, 32, 320, 8, 3, 1, 1, 0), (5, 8, 16, 192, 128, 1, 1, 0, 0),
+    (2, 7, 9, 64, 64, 3, 1, 1, 0)])
+def test_conv(ops, nb, h, w, cin, cout, kk, stride, pad, ups):
+    x = rnd(nb, h, w, cin)
+    wt = rnd(cout, cin, kk, kk, scale=(cin * kk * kk) ** -0.5, seed=1)
+    bias = rnd(cout, seed=2, dtype=torch.float32)
+    w2d = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    g = ops.ConvGeom(nb, h, w, kk, kk, stride, pad, ups)
+    out = ops.gemm(x.view(nb * h * w, cin), w2d, bias, geom=g)
+    ref = _conv_ref(x, wt, bias, stride, pad, ups)
+    assert (g.h_out, g.w_out) == tuple(ref.shape[1:3])
+    check(out.view(nb, g.h_out, g.w_out, cout), ref, f"conv k{kk} s{stride} ups{ups} {cin}->{cout}")
+
+
+def test_conv_dual_source_concat(ops):
+    nb, h, w, c1, c2, cout = 2, 8, 8, 128, 64, 160
+    x1, x2 = rnd(nb, h, w, c1), rnd(nb, h, w, c2, seed=7)
+    wt = rnd(cout, c1 + c2, 3, 3, scale=(9 * (c1 + c2)) ** -0.5, seed=1)
+    bias = rnd(cout, seed=2, dtype=torch.float32)
+    w2d = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    g = ops.ConvGeom(nb, h, w, 3, 3, 1, 1)
+    out = ops.gemm(x1.view(-1, c1), w2d, bias, geom=g, a2=x2.view(-1, c2))
+    check(out.view(nb, h, w, cout), _conv_ref(torch.cat([x1, x2], -1), wt, bias, 1, 1, 0), "conv3x3 concat sources")
+    w1 = rnd(cout, c1 + c2, scale=(c1 + c2) ** -0.5, seed=3)
+    out = ops.gemm(x1.view(-1, c1), w1, bias, a2=x2.view(-1, c2))
+    check(out, torch.cat([x1, x2], -1).view(-1, c1 + c2).float() @ w1.float().t() + bias, "1x1 concat shortcut")
+
+
+@pytest.mark.parametrize("m,c", [(300, 64), (256, 320), (130, 1280)])
+def test_geglu(ops, m, c):
+    from v_express_amd import weights as Wt
+    a = rnd(m, c)
+    w = rnd(8 * c, c, scale=c ** -0.5, seed=1)
+    b = rnd(8 * c, seed=2, dtype=torch.float32)
+    out = ops.geglu(a, Wt.geglu_interleave(w), Wt.geglu_interleave(b))
+    hg = a.float() @ w.float().t() + b
+    hval, gate = hg.chunk(2, dim=-1)
+    check(out, hval * F.gelu(gate), f"geglu c={c}")
+
+
+@pytest.mark.parametrize("seqs,n_tok,c,heads", [(3, 64, 64, 8), (2, 256, 320, 8), (4, 16, 128, 8), (6, 4, 64, 8),
+                                                (5, 1, 64, 8), (2, 128, 512, 1)])
+def test_gemm_split_qkv_vt(ops, seqs, n_tok, c, heads):
+    m, d = seqs * n_tok, c // heads
+    a = rnd(m, c)
+    w = rnd(3 * c, c, scale=c ** -0.5, seed=1)
+    bias = rnd(3 * c, seed=2, dtype=torch.float32)
+    q = torch.zeros(m, c, device="cuda", dtype=BF)
+    k = torch.zeros(m, c, device="cuda", dtype=BF)
+    vt = ops.alloc_vt(seqs, heads, d, n_tok, "cuda")
+    ops.gemm_split(a, w, bias, [("rows", q), ("rows", k), ("vt", vt)], part_cols=c, seq_len=n_tok, head_dim=d)
+    ref = a.float() @ w.float().t() + bias
+    check(q, ref[:, :c], "split Q")
+    check(k, ref[:, c:2 * c], "split K")
+    vref = ref[:, 2 * c:].view(seqs, n_tok, heads, d).permute(0, 2, 3, 1)
+    check(vt[..., :n_tok], vref, f"split V^T seq_len={n_tok}")
+    assert (vt[..., n_tok:] == 0).all()
+
+
+# ----------------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("frames,hw,c1,c2,groups,silu", [(4, 64, 320, 0, 32, True), (3, 256, 64, 0, 32, False),
+                                                         (2, 64, 1280, 640, 32, True), (2, 1024, 128, 0, 32, True),
+                                                         (5, 16, 2560, 0, 32, True), (3, 1, 1280, 1280, 32, True),
+                                                         (2, 4096, 320, 0, 32, False)])
+def test_groupnorm(ops, frames, hw, c1, c2, groups, silu):
+    x1 = rnd(frames, hw, c1, scale=2.0) + 0.7
+    x1 = x1.to(BF)
+    x2 = rnd(frames, hw, c2, seed=5) if c2 else None
+    c = c1 + c2
+    gamma, beta = rnd(c, seed=1, dtype=torch.float32) * 0.1 + 1, rnd(c, seed=2, dtype=torch.float32) * 0.1
+    out = ops.groupnorm(x1, gamma, beta, frames=frames, hw=hw, groups=groups, eps=1e-5, silu=silu, x2=x2)
+    x = x1 if x2 is None else torch.cat([x1, x2], -1)
+    ref = F.group_norm(x.float().permute(0, 2, 1), groups, gamma, beta, 1e-5).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    check(out, ref, f"groupnorm C={c} hw={hw}", rel=8e-3, mx=2 ** -6)
+
+
+@pytest.mark.parametrize("rows,c", [(100, 64), (257, 320), (64, 640), (33, 1280)])
+def test_layernorm(ops, rows, c):
+    x = (rnd(rows, c, scale=1.5) + 0.3).to(BF)
+    gamma, beta = rnd(c, seed=1, dtype=torch.float32) * 0.1 + 1, rnd(c, seed=2, dtype=torch.float32) * 0.1
+    out = ops.layernorm(x, gamma, beta)
+    check(out, F.layer_norm(x.float(), (c,), gamma, beta, 1e-5), f"layernorm c={c}")
+
+
+def test_layernorm_add_table_and_strided(ops):
+    b, f, hw, c = 2, 4, 8, 320
+    x = rnd(b * f * hw, 2 * c)[:, c:]
+    gamma, beta = rnd(c, seed=1, dtype=torch.float32) * 0.1 + 1, rnd(c, seed=2, dtype=torch.float32) * 0.1
+    pe = rnd(32, c, seed=3, dtype=torch.float32)
+    out = ops.layernorm(x, gamma, beta, add=pe, add_rows_per_entry=hw, add_entries=f)
+    ref = F.layer_norm(x.float(), (c,), gamma, beta, 1e-5).view(b, f, hw, c) + pe[:f].view(1, f, 1, c)
+    check(out, ref.reshape(-1, c), "layernorm + positional table")
+
+
+# ----------------------------------------------------------------------------------------------------- attention
+def _sdpa_ref(q, k, v):
+    return F.scaled_dot_product_attention(q.float(), k.float(), v.float())
+
+
+@pytest.mark.parametrize("batch,heads,n_q,n_kv,d", [(2, 8, 64, 64, 8), (2, 8, 256, 256, 40), (3, 8, 100, 100, 16),
+                                                    (2, 8, 64, 192, 80), (2, 8, 128, 128, 160), (1, 8, 1024, 1024, 40),
+                                                    (2, 8, 16, 16, 32), (3, 8, 4, 4, 160), (2, 8, 1, 1, 80),
+                                                    (1, 1, 320, 320, 512), (2, 4, 72, 200, 64)])
+def test_flash_attention(ops, batch, heads, n_q, n_kv, d):
+    c = heads * d
+    q = rnd(batch * n_q, c)
+    k = rnd(batch * n_kv, c, seed=1)
+    v = rnd(batch * n_kv, c, seed=2)
+    vt = ops.alloc_vt(batch, heads, d, n_kv, "cuda")
+    vt[..., :n_kv] = v.view(batch, n_kv, heads, d).permute(0, 2, 3, 1)
+    out = ops.attention(q, k, vt, batch=batch, heads=heads, n_q=n_q, n_kv=n_kv, head_dim=d)
+    ref = _sdpa_ref(q.view(batch, n_q, heads, d).transpose(1, 2), k.view(batch, n_kv, heads, d).transpose(1, 2),
+                    v.view(batch, n_kv, heads, d).transpose(1, 2)).transpose(1, 2).reshape(batch * n_q, c)
+    check(out, ref, f"attention d={d} nq={n_q} nkv={n_kv}", rel=1e-2, mx=2 ** -6)
+
+
+def test_flash_attention_shared_kv_and_strided_q(ops):
+    """reference attention: the f frames of a batch row share one bank (q_per_kv = f); Q is a column slice."""
+    f, heads, n, d = 4, 8, 64, 40
+    c = heads * d
+    qkv = rnd(f * n, 3 * c)
+    k, v = rnd(n, c, seed=1), rnd(n, c, seed=2)
+    vt = ops.alloc_vt(1, heads, d, n, "cuda")
+    vt[..., :n] = v.view(1, n, heads, d).permute(0, 2, 3, 1)
+    out = ops.attention(qkv[:, c:2 * c], k, vt, batch=f, heads=heads, n_q=n, n_kv=n, head_dim=d, q_per_kv=f)
+    q4 = qkv[:, c:2 * c].reshape(f, n, heads, d).transpose(1, 2)
+    k4 = k.view(1, n, heads, d).transpose(1, 2).expand(f, -1, -1, -1)
+    v4 = v.view(1, n, heads, d).transpose(1, 2).expand(f, -1, -1, -1)
+    check(out, _sdpa_ref(q4, k4, v4).transpose(1, 2).reshape(f * n, c), "attention shared K/V", rel=1e-2, mx=2 ** -6)
+
+
+def test_flash_attention_softmax_rescale_path(ops):
+    """A key spike late in the sequence forces the running-max rescale of the accumulator."""
+    heads, n, d = 8, 256, 40
+    c = heads * d
+    q, k, v = rnd(n, c), rnd(n, c, seed=1), rnd(n, c, seed=2)
+    k = k.float()
+    k[200] = q[5].float() * 6.0
+    k = k.to(BF)
+    vt = ops.alloc_vt(1, heads, d, n, "cuda")
+    vt[..., :n] = v.view(1, n, heads, d).permute(0, 2, 3, 1)
+    out = ops.attention(q, k, vt, batch=1, heads=heads, n_q=n, n_kv=n, head_dim=d)
+    ref = _sdpa_ref(q.view(1, n, heads, d).transpose(1, 2), k.view(1, n, heads, d).transpose(1, 2),
+                    v.view(1, n, heads, d).transpose(1, 2)).transpose(1, 2).reshape(n, c)
+    check(out, ref, "attention with late max spike", rel=1e-2, mx=2 ** -6)
+
+
+@pytest.mark.parametrize("b,f,hw,heads,d", [(2, 4, 16, 8, 8), (2, 16, 64, 8, 40), (1, 24, 16, 8, 80), (2, 8, 4, 8, 160),
+                                            (1, 1, 8, 8, 16), (2, 32, 5, 8, 32)])
+def test_temporal_attention(ops, b, f, hw, heads, d):
+    c = heads * d
+    qkv = rnd(b * f * hw, 3 * c)
+    out = ops.temporal_attention(qkv, b=b, f=f, hw=hw, heads=heads, head_dim=d)
+    t = qkv.view(b, f, hw, 3, heads, d).permute(3, 0, 2, 4, 1, 5)        # [3, b, hw, heads, f, d]
+    ref = _sdpa_ref(t[0], t[1], t[2]).permute(0, 3, 1, 2, 4).reshape(b * f * hw, c)
+    check(out, ref, f"temporal attention f={f} d={d}", rel=1e-2, mx=2 ** -6)
+
+
+@pytest.mark.parametrize("batch,n_q,n_kv,heads,d", [(4, 64, 5, 8, 40), (3, 100, 1, 8, 8), (2, 16, 5, 8, 160),
+                                                    (2, 7, 16, 8, 16)])
+def test_small_kv_attention(ops, batch, n_q, n_kv, heads, d):
+    c = heads * d
+    q = rnd(batch * n_q, c)
+    kv = rnd(batch * n_kv, 2 * c, seed=1)
+    out = ops.small_kv_attention(q, kv, batch=batch, n_q=n_q, n_kv=n_kv, heads=heads, head_dim=d)
+    k, v = kv[:, :c], kv[:, c:]
+    ref = _sdpa_ref(q.view(batch, n_q, heads, d).transpose(1, 2), k.reshape(batch, n_kv, heads, d).transpose(1, 2),
+                    v.reshape(batch, n_kv, heads, d).transpose(1, 2)).transpose(1, 2).reshape(batch * n_q, c)
+    check(out, ref, f"small-kv attention n_kv={n_kv} d={d}", rel=1e-2, mx=2 ** -6)
+
+
+# ----------------------------------------------------------------------------------------------------- elementwise
+def test_add_row_bias(ops):
+    x = rnd(50, 640)
+    bias = rnd(320, seed=1, dtype=torch.float32)
+    ref = x.float().clone()
+    ref[:, 320:] += 0.95 * bias
+    ops.add_row_bias(x[:, 320:], bias, 0.95)
+    check(x, ref, "add_row_bias on a strided view")
+
+
+def test_layout_and_loop_kernels(ops):
+    from oracle import loop as OL
+    F_, h, w, f = 11, 8, 8, 4
+    hw = h * w
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(1, 4, F_, h, w, generator=g).cuda()
+    ids = torch.tensor([8, 9, 10, 9], dtype=torch.int32, device="cuda")
+    x = ops.gather_latents(lat, ids, reps=2)
+    ref = lat[0][:, ids.long()].permute(1, 2, 3, 0).reshape(f, hw, 4)
+    assert x.shape == (2 * f, hw, 8)
+    check(x[:f, :, :4], ref, "gather_latents", rel=4e-3, mx=2 ** -8)
+    assert torch.equal(x[:f], x[f:]) and (x[..., 4:] == 0).all()
+    # NCFHW <-> NHWC
+    t = torch.randn(2, 320, 3, h, w, generator=g).cuda()
+    nh = ops.ncfhw_to_nhwc(t, 320)
+    check(nh, t.permute(0, 2, 3, 4, 1).reshape(6, hw, 320), "ncfhw_to_nhwc", rel=4e-3, mx=2 ** -8)
+    back = ops.nhwc_to_ncfhw(nh.float().view(-1, 320), 2, 320, 3, h, w)
+    assert torch.equal(back, nh.float().view(2, 3, h, w, 320).permute(0, 4, 1, 2, 3))
+    # CFG combine + overlap/DDIM step against the oracle's loop arithmetic
+    windows = OL.uniform_windows(F_, f, 2)
+    from v_express_amd.context import overlap_plan
+    plan = overlap_plan(windows, F_)
+    outs = [torch.randn(2 * f * hw, 8, generator=g).cuda() for _ in windows]
+    preds = torch.empty(len(windows), 4, f, hw, device="cuda")
+    for wi, o in enumerate(outs):
+        ops.cfg_combine(o, 4, f, hw, 3.5, preds[wi])
+    ddim = OL.DDIM()
+    ddim.set_timesteps(25)
+    t_step = 519
+
+    def fake_unet(inp, t, e, kfeat):       # returns the stored window outputs in call order
+        o = outs[fake_unet.i].cpu()
+        fake_unet.i += 1
+        return o.view(2, f, hw, 8)[..., :4].permute(0, 3, 1, 2).reshape(2, 4, f, h, w)
+    fake_unet.i = 0
+    ref_lat = OL.mean_overlap(fake_unet, lat.cpu(), [t_step], ddim, windows, 3.5,
+                              torch.zeros(2, 1, F_, h, w), torch.zeros(2, F_, 1, 8))
+    sf = plan["step_frames"]
+    terms = torch.full((len(sf), plan["max_terms"], 2), -1, dtype=torch.int32)
+    for i, fr in enumerate(sf):
+        for j, (wi, li) in enumerate(plan["terms"][fr]):
+            terms[i, j, 0], terms[i, j, 1] = wi, li
+    from v_express_amd.scheduler import DDIMScheduler
+    sch = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                        steps_offset=1, prediction_type="v_prediction", rescale_betas_zero_snr=True,
+                        timestep_spacing="trailing")
+    sch.set_timesteps(25)
+    lat2 = lat.clone()
+    ops.overlap_ddim_step(lat2, preds, terms.cuda(), torch.tensor(sf, dtype=torch.int32, device="cuda"),
+                          torch.tensor([float(plan["counts"][fr]) for fr in sf], device="cuda"),
+                          sch.step_coefficients(t_step))
+    check(lat2.cpu(), ref_lat, "cfg_combine + overlap_ddim_step (reflected window)", rel=1e-5, mx=1e-5)
+    # VAE post-process
+    img = torch.randn(2 * hw, 8, generator=g).cuda() * 2
+    pp = ops.vae_postprocess(img, 2, 3, h, w)
+    assert torch.allclose(pp, (img.view(2, h, w, 8)[..., :3].permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1))
+
+
+def test_errors_are_reported_not_fatal(ops):
+    from v_express_amd.lib import VxError
+    with pytest.raises(VxError):
+        ops.gemm(rnd(16, 12), rnd(8, 12))            # K not a multiple of 8
+    with pytest.raises(VxError):
+        ops.temporal_attention(rnd(33 * 4, 3 * 64), b=1, f=33, hw=4, heads=8, head_dim=8)

@@ -1,0 +1,164 @@
+"""Block-level forward functions over channels-last tokens, composed purely of libvexpress_hip ops.
+
+Every function cites the reference code it reproduces (paths relative to tencent-ailab/V-Express).
+Activations: bf16 `[frames, H*W, C]` (frames = b*f, batch-major like the reference's `(b f)` flattening).
+No einops / permutes ever run: the reference's `b c f h w <-> (b f) c h w <-> (b f) hw c <-> (b hw) f c`
+ping-pong (resnet.py:13-15,24-26; transformer_3d.py:115,165; motion_module.py:151,180,361-363,386)
+collapses to this one resident layout.
+"""
+import torch
+
+from . import lib as L
+from . import ops
+from .ops import ConvGeom
+
+
+def resnet_block(P, x, frames, H, W, *, groups, eps, temb=None, rows_per_group=0, skip=None):
+    """ResnetBlock3D.forward (modules/resnet.py:217-251) / diffusers ResnetBlock2D.
+    x: [frames, HW, C1]; skip: optional [frames, HW, C2] consumed as the channel concat
+    torch.cat([x, skip], dim=1) (modules/unet_3d_blocks.py:694,831) without materialising it;
+    temb: fp32 [b, Cout] view = time_emb_proj(silu(emb)) rows (resnet.py:225-233)."""
+    hw = H * W
+    c1 = x.shape[-1]
+    n = ops.groupnorm(x, P.norm1.g, P.norm1.b, frames=frames, hw=hw, groups=groups, eps=eps, silu=True, x2=skip)
+    g3 = ConvGeom(frames, H, W, 3, 3, 1, 1)
+    h = ops.gemm(n.view(frames * hw, -1), P.conv1.w, P.conv1.b, geom=g3, rowbias=temb, rows_per_group=rows_per_group)
+    cout = h.shape[-1]
+    n2 = ops.groupnorm(h.view(frames, hw, cout), P.norm2.g, P.norm2.b, frames=frames, hw=hw, groups=groups, eps=eps,
+                       silu=True)
+    if P.shortcut is not None:
+        sc = ops.gemm(x.view(frames * hw, c1), P.shortcut.w, P.shortcut.b,
+                      a2=None if skip is None else skip.view(frames * hw, -1))
+    else:
+        if skip is not None:
+            raise ValueError("concat input needs a conv_shortcut")
+        sc = x.view(frames * hw, c1)
+    out = ops.gemm(n2.view(frames * hw, cout), P.conv2.w, P.conv2.b, geom=g3, residual=sc)
+    return out.view(frames, hw, cout)
+
+
+def downsample(P, x, frames, H, W):
+    """Downsample3D: conv3x3 stride 2 pad 1 (modules/resnet.py:106-118)."""
+    g = ConvGeom(frames, H, W, 3, 3, 2, 1)
+    out = ops.gemm(x.view(frames * H * W, -1), P.w, P.b, geom=g)
+    return out.view(frames, g.h_out * g.w_out, -1), g.h_out, g.w_out
+
+
+def upsample(P, x, frames, H, W):
+    """Upsample3D: nearest x2 (fused into the conv's gather) + conv3x3 (modules/resnet.py:53-90)."""
+    g = ConvGeom(frames, H, W, 3, 3, 1, 1, upsample=1)
+    out = ops.gemm(x.view(frames * H * W, -1), P.w, P.b, geom=g)
+    return out.view(frames, g.h_out * g.w_out, -1), g.h_out, g.w_out
+
+
+def _self_attention(A, ln, h, *, seqs, n_tok, heads):
+    """diffusers Attention as self-attention: fused QKV GEMM whose epilogue also emits V^T, flash attention,
+    out-projection with the residual add fused (in place on h)."""
+    m, c = ln.shape
+    d = c // heads
+    q = torch.empty((m, c), device=ln.device, dtype=ops.BF16)
+    k = torch.empty((m, c), device=ln.device, dtype=ops.BF16)
+    vt = ops.alloc_vt(seqs, heads, d, n_tok, ln.device)
+    ops.gemm_split(ln, A.wqkv, A.bqkv, [("rows", q), ("rows", k), ("vt", vt)], part_cols=c, seq_len=n_tok,
+                   head_dim=d)
+    a = ops.attention(q, k, vt, batch=seqs, heads=heads, n_q=n_tok, n_kv=n_tok, head_dim=d)
+    ops.gemm(a, A.out.w, A.out.b, residual=h, out=h)
+
+
+def _feed_forward(P, h):
+    """h += FF(LN(h)): GEGLU fused in the first GEMM's epilogue, residual in the second's."""
+    ln = ops.layernorm(h, P.norm3.g if "norm3" in P else P.ff_norm.g, P.norm3.b if "norm3" in P else P.ff_norm.b)
+    g = ops.geglu(ln, P.ff.w1, P.ff.b1)
+    ops.gemm(g, P.ff.out.w, P.ff.out.b, residual=h, out=h)
+
+
+def spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_ref, w_aud):
+    """Transformer3DModel.forward (modules/transformer_3d.py:103-169) with the block forward patched by
+    ReferenceAttentionControl in *read* mode (modules/mutual_self_attention.py:176-267).
+    x: [b*f, HW, C]; ehs: bf16 [b*f*n_ctx, 768] audio tokens; bank: list over the b batch rows of
+    None (all-zero bank -> the attention output is exactly to_out.bias) or (k, vt)."""
+    frames, hw, c = b * f, H * W, x.shape[-1]
+    m = frames * hw
+    x2d = x.view(m, c)
+    n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
+    h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b)
+    # 1. self-attention (:177-184)
+    ln = ops.layernorm(h, P.norm1.g, P.norm1.b)
+    _self_attention(P.attn1, ln, h, seqs=frames, n_tok=hw, heads=heads)
+    # 1.5 reference attention (:186-224): K/V = bank of the batch row, shared by its f frames
+    d = c // heads
+    rows = f * hw
+    for bi in range(b):
+        hb = h[bi * rows:(bi + 1) * rows]
+        if bank[bi] is None:
+            ops.add_row_bias(hb, P.attn1_5.out.b, w_ref)
+        else:
+            kref, vtref = bank[bi]
+            ln = ops.layernorm(hb, P.norm1_5.g, P.norm1_5.b)
+            q = ops.gemm(ln, P.attn1_5.wq)
+            a = ops.attention(q, kref, vtref, batch=f, heads=heads, n_q=hw, n_kv=kref.shape[0], head_dim=d,
+                              q_per_kv=f)
+            ops.gemm(a, P.attn1_5.out.w, P.attn1_5.out.b, residual=hb, alpha=w_ref, out=hb)
+    # 2. audio cross-attention (:227-244)
+    n_ctx = ehs.shape[0] // frames
+    ln = ops.layernorm(h, P.norm2.g, P.norm2.b)
+    q = ops.gemm(ln, P.attn2.wq)
+    kv = ops.gemm(ehs, P.attn2.wkv)
+    a = ops.small_kv_attention(q, kv, batch=frames, n_q=hw, n_kv=n_ctx, heads=heads, head_dim=d)
+    ops.gemm(a, P.attn2.out.w, P.attn2.out.b, residual=h, alpha=w_aud, out=h)
+    # 3. feed-forward (:247)
+    _feed_forward(P, h)
+    out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x2d)
+    return out.view(frames, hw, c)
+
+
+def spatial_transformer_write(P, x, *, frames, H, W, heads, groups, ehs):
+    """Transformer2DModel.forward (modules/transformer_2d.py:216-399) with the BasicTransformerBlock forward
+    patched in *write* mode (modules/mutual_self_attention.py:145-174, FF tail :269-284).
+    Returns (output, bank) with bank = norm2(h + attn1(norm1 h)) as [frames*HW, C]."""
+    hw, c = H * W, x.shape[-1]
+    m = frames * hw
+    d = c // heads
+    n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
+    h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b)
+    ln = ops.layernorm(h, P.norm1.g, P.norm1.b)
+    _self_attention(P.attn1, ln, h, seqs=frames, n_tok=hw, heads=heads)
+    bank = ops.layernorm(h, P.norm2.g, P.norm2.b)
+    n_ctx = ehs.shape[0] // frames
+    q = ops.gemm(bank, P.attn2.wq)
+    kv = ops.gemm(ehs, P.attn2.wkv)
+    a = ops.small_kv_attention(q, kv, batch=frames, n_q=hw, n_kv=n_ctx, heads=heads, head_dim=d)
+    ops.gemm(a, P.attn2.out.w, P.attn2.out.b, residual=h, out=h)
+    _feed_forward(P, h)
+    out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x.view(m, c))
+    return out.view(frames, hw, c), bank
+
+
+def motion_module(P, x, *, b, f, H, W, heads, groups):
+    """VanillaTemporalModule -> TemporalTransformer3DModel.forward (modules/motion_module.py:146-182), one
+    TemporalTransformerBlock (:236-259): 2x [LN, +pe, QKV, attention over f, out-proj + residual], LN, GEGLU FF.
+    The additive sinusoid table goes through the LayerNorm kernel (pe enters Q, K and V: :365-366)."""
+    frames, hw, c = b * f, H * W, x.shape[-1]
+    m = frames * hw
+    d = c // heads
+    n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
+    h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b)
+    for A in P.attn:
+        ln = ops.layernorm(h, A.norm.g, A.norm.b, add=A.pe, add_rows_per_entry=hw, add_entries=f)
+        qkv = ops.gemm(ln, A.attn.wqkv, A.attn.bqkv)
+        a = ops.temporal_attention(qkv, b=b, f=f, hw=hw, heads=heads, head_dim=d)
+        ops.gemm(a, A.attn.out.w, A.attn.out.b, residual=h, out=h)
+    _feed_forward(P, h)
+    out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x.view(m, c))
+    return out.view(frames, hw, c)
+
+
+def bank_kv(A, bank_tokens, heads):
+    """Per-clip precompute of the reference-attention K / V^T from a writer bank (step-invariant):
+    k = bank Wk^T, v = bank Wv^T of the reader's attn1_5 (modules/mutual_self_attention.py:204-224)."""
+    n, c = bank_tokens.shape
+    d = c // heads
+    k = torch.empty((n, c), device=bank_tokens.device, dtype=ops.BF16)
+    vt = ops.alloc_vt(1, heads, d, n, bank_tokens.device)
+    ops.gemm_split(bank_tokens, A.wkv, None, [("rows", k), ("vt", vt)], part_cols=c, seq_len=n, head_dim=d)
+    return k, vt

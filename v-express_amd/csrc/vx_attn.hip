@@ -1,0 +1,535 @@
+// Attention kernels for gfx950 (see include/vexpress_hip.h): flash-style spatial attention on MFMA, temporal
+// (frame-axis) attention, and cross-attention against a short key list.
+//
+// MFMA mapping used by both MFMA kernels (v_mfma_f32_16x16x32_bf16, lane = (i = lane&15, g = lane>>4)):
+//   S^T[key, query] = K[key, :] . Q[query, :]      A = K fragment  (row = key i,  8 d-values at 32kk+8g)
+//                                                   B = Q fragment  (col = query i, same d-values)
+//                                                   C: reg r holds key 16kt+4g+r for query i
+//   => every lane owns ONE query column: the softmax statistics are per-lane scalars and the rescale of the
+//      output accumulator needs no cross-lane traffic; the row max/sum over keys is an in-lane reduction plus two
+//      xor-shuffles over g.
+//   O^T[dcol, query] = V^T[dcol, key] . P^T[key, query]   A = V^T fragment (row = dcol i, keys {4g..4g+3, 16+4g..})
+//                                                          B = P^T fragment = the C registers of two S^T tiles,
+//                                                              converted to bf16 in place (contraction order over
+//                                                              keys is arbitrary, so no lane exchange is needed)
+// V arrives pre-transposed ([.., head, dim, key], written by the QKV GEMM epilogue) so both LDS tiles are filled with
+// 16-B row copies and read conflict-free: K as [d/32 slabs][64 keys][64 B] with chunk ^= (-(key>>2))&3, V^T as
+// [dim rows][128 B] with chunk ^= (row>>1)&7.
+#include "vx_common.h"
+#include "../../include/vexpress_hip.h"
+
+namespace {
+
+struct AttnParams {
+  const bf16_t* q; int ldq;
+  const bf16_t* k; int ldk;
+  const bf16_t* vt; int vt_pitch;
+  bf16_t* out; int ldo;
+  int batch, heads, n_q, n_kv, d, q_per_kv;
+  float c;   // scale * log2(e)
+};
+
+__device__ __forceinline__ int k_lds_off(int slab, int key, int grp) {
+  return slab * 4096 + key * 64 + ((grp ^ ((0 - (key >> 2)) & 3)) << 4);
+}
+__device__ __forceinline__ int v_lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int KK, int DT, int QT, bool PREFETCH, int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
+  constexpr int NV = (DT + 1) / 2;   // V^T chunks per thread per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ks = smem;
+  char* vs = smem + KK * 4096;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const int kvb = b / p.q_per_kv;
+  const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+  const bf16_t* __restrict__ kbase = p.k + (size_t)kvb * p.n_kv * p.ldk + h * p.d;
+  const bf16_t* __restrict__ vbase = p.vt + (size_t)(kvb * p.heads + h) * p.d * p.vt_pitch;
+
+  // Q fragments (B operand), loaded once
+  uint4 qf[QT][KK];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    int qrow = q0 + 16 * qt + i;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      int dcol = 32 * kk + 8 * g;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qrow < p.n_q && dcol < p.d)
+        v = *reinterpret_cast<const uint4*>(p.q + (size_t)(b * p.n_q + qrow) * p.ldq + h * p.d + dcol);
+      qf[qt][kk] = v;
+    }
+  }
+
+  f32x4_t o[DT][QT];
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = -INFINITY;
+    l_run[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  uint4 rk[KK], rv[NV];
+  auto load_k = [&](int t, int s) -> uint4 {
+    int idx = tid + 256 * s;
+    int key = idx / (4 * KK), c = idx % (4 * KK);
+    int kg = t * 64 + key;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (kg < p.n_kv && c * 8 < p.d) v = *reinterpret_cast<const uint4*>(kbase + (size_t)kg * p.ldk + c * 8);
+    return v;
+  };
+  auto store_k = [&](int s, const uint4& v) {
+    int idx = tid + 256 * s;
+    int key = idx / (4 * KK), c = idx % (4 * KK);
+    *reinterpret_cast<uint4*>(ks + k_lds_off(c >> 2, key, c & 3)) = v;
+  };
+  auto load_v = [&](int t, int s) -> uint4 {
+    int idx = tid + 256 * s;
+    int row = idx >> 3, j = idx & 7;
+    int kg = t * 64 + j * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < p.d && kg < p.n_kv) v = *reinterpret_cast<const uint4*>(vbase + (size_t)row * p.vt_pitch + kg);
+    return v;
+  };
+  auto store_v = [&](int s, const uint4& v) {
+    int idx = tid + 256 * s;
+    int row = idx >> 3, j = idx & 7;
+    if (row < DT * 16) *reinterpret_cast<uint4*>(vs + v_lds_off(row, j)) = v;
+  };
+
+  const int n_tiles = (p.n_kv + 63) >> 6;
+  if constexpr (PREFETCH) {
+#pragma unroll
+    for (int s = 0; s < KK; ++s) rk[s] = load_k(0, s);
+#pragma unroll
+    for (int s = 0; s < NV; ++s) rv[s] = load_v(0, s);
+#pragma unroll
+    for (int s = 0; s < KK; ++s) store_k(s, rk[s]);
+#pragma unroll
+    for (int s = 0; s < NV; ++s) store_v(s, rv[s]);
+    __syncthreads();
+  }
+
+  for (int t = 0; t < n_tiles; ++t) {
+    if constexpr (PREFETCH) {
+      if (t + 1 < n_tiles) {
+#pragma unroll
+        for (int s = 0; s < KK; ++s) rk[s] = load_k(t + 1, s);
+#pragma unroll
+        for (int s = 0; s < NV; ++s) rv[s] = load_v(t + 1, s);
+      }
+    } else {
+      __syncthreads();
+#pragma unroll 4
+      for (int s = 0; s < KK; ++s) store_k(s, load_k(t, s));
+#pragma unroll 4
+      for (int s = 0; s < NV; ++s) store_v(s, load_v(t, s));
+      __syncthreads();
+    }
+
+    // ---- S^T = K Q^T
+    f32x4_t s_[4][QT];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) s_[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        uint4 kf = *reinterpret_cast<const uint4*>(ks + k_lds_off(kk, 16 * kt + i, g));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s_[kt][qt] = mfma16(kf, qf[qt][kk], s_[kt][qt]);
+      }
+    }
+    if ((t + 1) * 64 > p.n_kv) {   // ragged last tile: keys beyond n_kv never contribute
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (t * 64 + 16 * kt + 4 * g + r >= p.n_kv) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) s_[kt][qt][r] = -INFINITY;
+          }
+        }
+    }
+    // ---- online softmax (per-lane query column)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float mx = s_[0][qt][0];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s_[kt][qt][r]);
+      mx = wave_xor_max(mx, 16);
+      mx = wave_xor_max(mx, 32);
+      float mnew = fmaxf(m_run[qt], mx * p.c);
+      float alpha = __builtin_amdgcn_exp2f(m_run[qt] - mnew);
+      m_run[qt] = mnew;
+      float rs = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pv = __builtin_amdgcn_exp2f(fmaf(s_[kt][qt][r], p.c, -mnew));
+          rs += pv;
+          s_[kt][qt][r] = pv;
+        }
+      l_run[qt] = l_run[qt] * alpha + rs;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        o[dt][qt][0] *= alpha; o[dt][qt][1] *= alpha; o[dt][qt][2] *= alpha; o[dt][qt][3] *= alpha;
+      }
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int ks_ = 0; ks_ < 2; ++ks_) {
+      uint4 pb[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const f32x4_t& a = s_[2 * ks_][qt];
+        const f32x4_t& c2 = s_[2 * ks_ + 1][qt];
+        pb[qt] = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(c2[0], c2[1]),
+                            pack_bf16x2(c2[2], c2[3]));
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        int row = 16 * dt + i;
+        int j1 = 4 * ks_ + (g >> 1);
+        const uint2 v1 = *reinterpret_cast<const uint2*>(vs + v_lds_off(row, j1) + (g & 1) * 8);
+        const uint2 v2 = *reinterpret_cast<const uint2*>(vs + v_lds_off(row, j1 + 2) + (g & 1) * 8);
+        uint4 vf = make_uint4(v1.x, v1.y, v2.x, v2.y);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[dt][qt] = mfma16(vf, pb[qt], o[dt][qt]);
+      }
+    }
+    if constexpr (PREFETCH) {
+      __syncthreads();
+      if (t + 1 < n_tiles) {
+#pragma unroll
+        for (int s = 0; s < KK; ++s) store_k(s, rk[s]);
+#pragma unroll
+        for (int s = 0; s < NV; ++s) store_v(s, rv[s]);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- normalise and store: lane holds 4 consecutive d-columns of one query
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float l = l_run[qt];
+    l = wave_xor_sum(l, 16);
+    l = wave_xor_sum(l, 32);
+    float inv = 1.0f / l;
+    int qrow = q0 + 16 * qt + i;
+    if (qrow >= p.n_q) continue;
+    bf16_t* orow = p.out + (size_t)(b * p.n_q + qrow) * p.ldo + h * p.d;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      int dcol = 16 * dt + 4 * g;
+      if (dcol < p.d) {
+        uint2 w;
+        w.x = pack_bf16x2(o[dt][qt][0] * inv, o[dt][qt][1] * inv);
+        w.y = pack_bf16x2(o[dt][qt][2] * inv, o[dt][qt][3] * inv);
+        *reinterpret_cast<uint2*>(orow + dcol) = w;
+      }
+    }
+  }
+}
+
+template <int KK, int DT, int QT, bool PREFETCH, int MINW = 2>
+int launch_attn(const AttnParams& p, hipStream_t stream) {
+  constexpr int smem = KK * 4096 + DT * 2048;
+  auto kern = attn_kernel<KK, DT, QT, PREFETCH, MINW>;
+  static bool attr_set = false;
+  if (!attr_set && smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      vx_set_error("vx_attention: hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e));
+      return VX_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid(ceil_div(p.n_q, 64 * QT), p.batch * p.heads);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
+  return vx_check_launch("vx_attention");
+}
+
+// -------------------------------------------------------------------------------------------- temporal attention
+struct TemporalParams {
+  const bf16_t* qkv; int ldqkv;
+  bf16_t* out; int ldo;
+  int b, f, hw, heads, d;
+  float c;
+};
+
+template <int KK, int DT, int FT>
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const TemporalParams p) {
+  constexpr int VP = 32 * KK + 8;   // V tile pitch in elements (pad breaks the power-of-two stride)
+  __shared__ __attribute__((aligned(16))) bf16_t vsm[4][16 * FT][VP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const long total = (long)p.b * p.hw * p.heads;
+  long wg = (long)blockIdx.x * 4 + wave;
+  const bool live = wg < total;
+  if (!live) wg = total - 1;
+  const int h = (int)(wg % p.heads);
+  const int pix = (int)((wg / p.heads) % p.hw);
+  const int bb = (int)(wg / ((long)p.heads * p.hw));
+  const int C = p.heads * p.d;
+  auto row_ptr = [&](int fr) { return p.qkv + ((size_t)(bb * p.f + fr) * p.hw + pix) * p.ldqkv + h * p.d; };
+
+  uint4 qf[FT][KK], kf[FT][KK];
+#pragma unroll
+  for (int ft = 0; ft < FT; ++ft) {
+    int fr = 16 * ft + i;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      int dcol = 32 * kk + 8 * g;
+      uint4 qv = make_uint4(0, 0, 0, 0), kv = qv;
+      if (fr < p.f && dcol < p.d) {
+        const bf16_t* rp = row_ptr(fr);
+        qv = *reinterpret_cast<const uint4*>(rp + dcol);
+        kv = *reinterpret_cast<const uint4*>(rp + C + dcol);
+      }
+      qf[ft][kk] = qv;
+      kf[ft][kk] = kv;
+    }
+  }
+  // stage V rows (natural [frame][d]) into this wave's LDS tile; rows >= f and columns >= d are zero
+#pragma unroll
+  for (int s = 0; s < FT * KK; ++s) {
+    int idx = lane + 64 * s;
+    int fr = idx / (4 * KK), c = idx % (4 * KK);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (fr < p.f && c * 8 < p.d) v = *reinterpret_cast<const uint4*>(row_ptr(fr) + 2 * C + c * 8);
+    *reinterpret_cast<uint4*>(&vsm[wave][fr][c * 8]) = v;
+  }
+  __syncthreads();
+
+  f32x4_t s_[FT][FT];
+#pragma unroll
+  for (int kt = 0; kt < FT; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < FT; ++qt) {
+      f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) a = mfma16(kf[kt][kk], qf[qt][kk], a);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * kt + 4 * g + r >= p.f) a[r] = -INFINITY;
+      s_[kt][qt] = a;
+    }
+  float inv_l[FT];
+#pragma unroll
+  for (int qt = 0; qt < FT; ++qt) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < FT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s_[kt][qt][r]);
+    mx = wave_xor_max(mx, 16);
+    mx = wave_xor_max(mx, 32);
+    float ms = mx * p.c, rs = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < FT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pv = __builtin_amdgcn_exp2f(fmaf(s_[kt][qt][r], p.c, -ms));
+        rs += pv;
+        s_[kt][qt][r] = pv;
+      }
+    rs = wave_xor_sum(rs, 16);
+    rs = wave_xor_sum(rs, 32);
+    inv_l[qt] = 1.0f / rs;
+  }
+  uint4 pb[FT];
+#pragma unroll
+  for (int qt = 0; qt < FT; ++qt) {
+    const f32x4_t& a = s_[0][qt];
+    uint32_t hi0 = 0, hi1 = 0;
+    if (FT == 2) {
+      const f32x4_t& c2 = s_[FT - 1][qt];
+      hi0 = pack_bf16x2(c2[0], c2[1]);
+      hi1 = pack_bf16x2(c2[2], c2[3]);
+    }
+    pb[qt] = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), hi0, hi1);
+  }
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    int dcol = 16 * dt + i;
+    uint32_t w[4];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      bf16_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+      if (half < FT && dcol < 32 * KK) {
+        int fr0 = 16 * half + 4 * g;
+        e0 = vsm[wave][fr0 + 0][dcol]; e1 = vsm[wave][fr0 + 1][dcol];
+        e2 = vsm[wave][fr0 + 2][dcol]; e3 = vsm[wave][fr0 + 3][dcol];
+      }
+      w[2 * half + 0] = (uint32_t)e0 | ((uint32_t)e1 << 16);
+      w[2 * half + 1] = (uint32_t)e2 | ((uint32_t)e3 << 16);
+    }
+    uint4 vf = make_uint4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+    for (int qt = 0; qt < FT; ++qt) {
+      f32x4_t acc = mfma16(vf, pb[qt], f32x4_t{0.f, 0.f, 0.f, 0.f});
+      int fr = 16 * qt + i;
+      int dc = 16 * dt + 4 * g;
+      if (live && fr < p.f && dc < p.d) {
+        uint2 st;
+        st.x = pack_bf16x2(acc[0] * inv_l[qt], acc[1] * inv_l[qt]);
+        st.y = pack_bf16x2(acc[2] * inv_l[qt], acc[3] * inv_l[qt]);
+        *reinterpret_cast<uint2*>(p.out + ((size_t)(bb * p.f + fr) * p.hw + pix) * p.ldo + h * p.d + dc) = st;
+      }
+    }
+  }
+}
+
+template <int KK, int DT>
+int launch_temporal(const TemporalParams& p, hipStream_t stream) {
+  long waves = (long)p.b * p.hw * p.heads;
+  dim3 grid((unsigned)((waves + 3) / 4));
+  if (p.f <= 16) hipLaunchKernelGGL((temporal_attn_kernel<KK, DT, 1>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((temporal_attn_kernel<KK, DT, 2>), grid, dim3(256), 0, stream, p);
+  return vx_check_launch("vx_temporal_attention");
+}
+
+// -------------------------------------------------------------------------------------- short key-list attention
+constexpr int SKV_MAX = 16;
+
+__global__ __launch_bounds__(256) void small_kv_attn_kernel(const bf16_t* __restrict__ q, int ldq,
+                                                            const bf16_t* __restrict__ kv, int ldkv, int v_off,
+                                                            bf16_t* __restrict__ out, int ldo, int n_q, int n_kv,
+                                                            int heads, int d, float c) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* kvs = reinterpret_cast<bf16_t*>(smem);   // [n_kv][2][C]
+  const int C = heads * d;
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int cch = C >> 3;
+  for (int idx = tid; idx < n_kv * 2 * cch; idx += 256) {
+    int j = idx / (2 * cch), rem = idx % (2 * cch);
+    int which = rem / cch, ch = (rem % cch) * 8;
+    const bf16_t* src = kv + ((size_t)b * n_kv + j) * ldkv + (which ? v_off : 0) + ch;
+    *reinterpret_cast<uint4*>(kvs + ((size_t)(j * 2 + which)) * C + ch) = *reinterpret_cast<const uint4*>(src);
+  }
+  __syncthreads();
+  const long item = (long)blockIdx.x * 256 + tid;   // (token, head), head fastest
+  if (item >= (long)n_q * heads) return;
+  const int h = (int)(item % heads);
+  const int tok = (int)(item / heads);
+  const bf16_t* qp = q + ((size_t)b * n_q + tok) * ldq + h * d;
+  float sc[SKV_MAX];
+#pragma unroll
+  for (int j = 0; j < SKV_MAX; ++j) sc[j] = 0.f;
+  for (int ch = 0; ch < d; ch += 8) {
+    float qv[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(qp + ch), qv);
+#pragma unroll
+    for (int j = 0; j < SKV_MAX; ++j) {
+      if (j < n_kv) {
+        float kvv[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(kvs + (size_t)(j * 2) * C + h * d + ch), kvv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sc[j] = fmaf(qv[e], kvv[e], sc[j]);
+      }
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < SKV_MAX; ++j)
+    if (j < n_kv) mx = fmaxf(mx, sc[j]);
+  float den = 0.f;
+#pragma unroll
+  for (int j = 0; j < SKV_MAX; ++j) {
+    float pv = (j < n_kv) ? __builtin_amdgcn_exp2f((sc[j] - mx) * c) : 0.f;
+    sc[j] = pv;
+    den += pv;
+  }
+  const float inv = 1.0f / den;
+  bf16_t* op = out + ((size_t)b * n_q + tok) * ldo + h * d;
+  for (int ch = 0; ch < d; ch += 8) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < SKV_MAX; ++j) {
+      if (j < n_kv) {
+        float vv[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(kvs + (size_t)(j * 2 + 1) * C + h * d + ch), vv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(sc[j], vv[e], acc[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= inv;
+    *reinterpret_cast<uint4*>(op + ch) = pack_bf16x8(acc);
+  }
+}
+
+}  // namespace
+
+extern "C" int vx_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_pitch, void* out,
+                            int ldo, int batch, int heads, int n_q, int n_kv, int head_dim, int q_per_kv,
+                            float scale, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(q && k && vt && out, "vx_attention: null pointer");
+  VX_REQUIRE(batch > 0 && heads > 0 && n_q > 0 && n_kv > 0 && q_per_kv > 0 && (batch % q_per_kv) == 0,
+             "vx_attention: bad sizes");
+  VX_REQUIRE((head_dim % 8) == 0 && (ldq % 8) == 0 && (ldk % 8) == 0 && (vt_pitch % 8) == 0 && (ldo % 4) == 0 &&
+                 vt_pitch >= n_kv,
+             "vx_attention: alignment (head_dim=%d ldq=%d ldk=%d pitch=%d ldo=%d)", head_dim, ldq, ldk, vt_pitch, ldo);
+  VX_REQUIRE((long)batch * heads <= 65535, "vx_attention: batch*heads too large for grid.y");
+  AttnParams p{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)vt, vt_pitch, (bf16_t*)out, ldo,
+               batch, heads, n_q, n_kv, head_dim, q_per_kv, scale * 1.4426950408889634f};
+  const int d = head_dim;
+  if (d <= 32) return launch_attn<1, 2, 4, true>(p, stream);
+  if (d <= 48) return launch_attn<2, 3, 2, true>(p, stream);
+  if (d <= 64) return launch_attn<2, 4, 2, true>(p, stream);
+  if (d <= 80) return launch_attn<3, 5, 2, true>(p, stream);
+  if (d <= 96) return launch_attn<3, 6, 2, true>(p, stream);
+  if (d <= 128) return launch_attn<4, 8, 2, true>(p, stream);
+  if (d <= 160) return launch_attn<5, 10, 2, false>(p, stream);
+  if (d == 512) return launch_attn<16, 32, 1, false, 1>(p, stream);
+  vx_set_error("vx_attention: unsupported head_dim %d", d);
+  return VX_ERR_UNSUPPORTED;
+}
+
+extern "C" int vx_temporal_attention(const void* qkv, int ldqkv, void* out, int ldo, int b, int f, int hw, int heads,
+                                     int head_dim, float scale, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(qkv && out, "vx_temporal_attention: null pointer");
+  VX_REQUIRE(f >= 1 && f <= 32, "vx_temporal_attention: f=%d outside [1,32] (PositionalEncoding max_len)", f);
+  VX_REQUIRE((head_dim % 8) == 0 && (ldqkv % 8) == 0 && (ldo % 4) == 0, "vx_temporal_attention: alignment");
+  TemporalParams p{(const bf16_t*)qkv, ldqkv, (bf16_t*)out, ldo, b, f, hw, heads, head_dim,
+                   scale * 1.4426950408889634f};
+  const int d = head_dim;
+  if (d <= 32) return launch_temporal<1, 2>(p, stream);
+  if (d <= 64) return launch_temporal<2, 4>(p, stream);
+  if (d <= 96) return launch_temporal<3, 6>(p, stream);
+  if (d <= 128) return launch_temporal<4, 8>(p, stream);
+  if (d <= 160) return launch_temporal<5, 10>(p, stream);
+  vx_set_error("vx_temporal_attention: unsupported head_dim %d", d);
+  return VX_ERR_UNSUPPORTED;
+}
+
+extern "C" int vx_small_kv_attention(const void* q, int ldq, const void* kv, int ldkv, int v_off, void* out, int ldo,
+                                     int batch, int n_q, int n_kv, int heads, int head_dim, float scale,
+                                     void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(q && kv && out, "vx_small_kv_attention: null pointer");
+  VX_REQUIRE(n_kv >= 1 && n_kv <= SKV_MAX, "vx_small_kv_attention: n_kv=%d outside [1,%d]", n_kv, SKV_MAX);
+  VX_REQUIRE((head_dim % 8) == 0 && (ldq % 8) == 0 && (ldkv % 8) == 0 && (v_off % 8) == 0 && (ldo % 8) == 0,
+             "vx_small_kv_attention: alignment");
+  const int C = heads * head_dim;
+  size_t smem = (size_t)n_kv * 2 * C * sizeof(bf16_t);
+  VX_REQUIRE(smem <= 64 * 1024, "vx_small_kv_attention: K/V tile %zu B exceeds LDS budget", smem);
+  dim3 grid(ceil_div((long)n_q * heads, 256), batch);
+  hipLaunchKernelGGL(small_kv_attn_kernel, grid, dim3(256), smem, stream, (const bf16_t*)q, ldq, (const bf16_t*)kv,
+                     ldkv, v_off, (bf16_t*)out, ldo, n_q, n_kv, heads, head_dim, scale * 1.4426950408889634f);
+  return vx_check_launch("vx_small_kv_attention");
+}

@@ -1,0 +1,68 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of libvexpress_hip.so.
+// Wave = 64 lanes; MFMA = v_mfma_f32_16x16x32_bf16 (A: lane l holds row l&15, k = 8*(l>>4)..+7;
+// B: col l&15, same k; C/D: col = l&15, row = 4*(l>>4)+reg).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint16_t bf16_t;   // raw bfloat16 bits
+
+#define VX_OK 0
+#define VX_ERR_INVALID (-1)
+#define VX_ERR_UNSUPPORTED (-2)
+#define VX_ERR_HIP (-3)
+
+extern "C" void vx_set_error(const char* fmt, ...);
+int vx_check_launch(const char* what);
+
+#define VX_REQUIRE(cond, ...)                   \
+  do {                                          \
+    if (!(cond)) {                              \
+      vx_set_error(__VA_ARGS__);                \
+      return VX_ERR_INVALID;                    \
+    }                                           \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ void unpack_bf16x8(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+__device__ __forceinline__ uint4 pack_bf16x8(const float* f) {
+  uint4 v;
+  v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+  v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU, as torch.nn.functional.gelu default
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                 c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_xor_max(float v, int mask) { return fmaxf(v, __shfl_xor(v, mask, 64)); }
+__device__ __forceinline__ float wave_xor_sum(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,182 @@
+// Elementwise / layout kernels of the denoising loop (see include/vexpress_hip.h).  All are tiny next to the
+// UNet; they exist so that latents, predictions and the DDIM state never leave HBM (the reference round-trips
+// them through the host every window: pipelines/v_express_pipeline.py:521,538,572).
+#include "vx_common.h"
+#include "../../include/vexpress_hip.h"
+
+namespace {
+
+__global__ void add_row_bias_kernel(bf16_t* x, int ldx, int rows, int c, const float* bias, float alpha) {
+  const int cch = c >> 3;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * cch) return;
+  int row = (int)(idx / cch), ch = (int)(idx % cch) * 8;
+  bf16_t* p = x + (size_t)row * ldx + ch;
+  float f[8];
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(p), f);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] += alpha * bias[ch + e];
+  *reinterpret_cast<uint4*>(p) = pack_bf16x8(f);
+}
+
+// latents fp32 [1, C, F, hw] -> out bf16 [reps*f, hw, c_pad]
+__global__ void gather_latents_kernel(const float* latents, int c, int total_frames, int hw, const int32_t* frame_ids,
+                                      int f, int reps, int c_pad, bf16_t* out) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (rep, li, pixel)
+  long total = (long)reps * f * hw;
+  if (idx >= total) return;
+  int px = (int)(idx % hw);
+  int li = (int)((idx / hw) % f);
+  int fr = frame_ids[li];
+  bf16_t* o = out + idx * c_pad;
+  for (int ch = 0; ch < c_pad; ++ch) {
+    float v = ch < c ? latents[((size_t)ch * total_frames + fr) * hw + px] : 0.f;
+    o[ch] = f32_to_bf16(v);
+  }
+}
+
+// unet_out fp32 [2f, hw, ld] -> pred_slot fp32 [c, f, hw]
+__global__ void cfg_combine_kernel(const float* unet_out, int ld, int c, int f, int hw, float guidance,
+                                   float* pred_slot) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (li, pixel)
+  if (idx >= (long)f * hw) return;
+  const float* u = unet_out + idx * ld;
+  const float* cnd = unet_out + ((long)f * hw + idx) * ld;
+  for (int ch = 0; ch < c; ++ch) pred_slot[(size_t)ch * f * hw + idx] = u[ch] + guidance * (cnd[ch] - u[ch]);
+}
+
+__global__ void overlap_ddim_kernel(float* latents, int c, int total_frames, int hw, const float* preds, int f_window,
+                                    const int32_t* terms, int max_terms, const int32_t* frame_ids,
+                                    const float* count, int n_frames, float sqrt_a, float sqrt_1ma,
+                                    float sqrt_ap, float sqrt_1map) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (frame slot, channel, pixel)
+  long total = (long)n_frames * c * hw;
+  if (idx >= total) return;
+  int px = (int)(idx % hw);
+  int ch = (int)((idx / hw) % c);
+  int fs = (int)(idx / ((long)hw * c));
+  int fr = frame_ids[fs];
+  float ic = count[fs];
+  float v = 0.f;
+  bool first = true;
+  for (int t = 0; t < max_terms; ++t) {
+    int slot = terms[(fs * max_terms + t) * 2 + 0];
+    int li = terms[(fs * max_terms + t) * 2 + 1];
+    if (slot < 0) continue;
+    // the reference divides each window's prediction by the coverage count BEFORE summing (:553, :556-564)
+    float term = preds[(((size_t)slot * c + ch) * f_window + li) * hw + px] / ic;
+    v = first ? term : v + term;
+    first = false;
+  }
+  float* lp = latents + ((size_t)ch * total_frames + fr) * hw + px;
+  float x = *lp;
+  float x0 = sqrt_a * x - sqrt_1ma * v;
+  float eps = sqrt_a * v + sqrt_1ma * x;
+  *lp = sqrt_ap * x0 + sqrt_1map * eps;
+}
+
+// x fp32 [b, c, f, hw] -> out bf16 [(b f), hw, c_pad]; LDS transpose so both sides are coalesced for wide c
+__global__ void ncfhw_to_nhwc_kernel(const float* x, int b, int c, int f, int hw, int c_pad, bf16_t* out) {
+  __shared__ float tile[32][33];
+  // grid: x = pixel tiles of 32, y = channel tiles of 32, z = (b f)
+  int bf = blockIdx.z;
+  int bb = bf / f, fr = bf % f;
+  int px0 = blockIdx.x * 32, ch0 = blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
+  for (int r = ty; r < 32; r += 8) {
+    int ch = ch0 + r, px = px0 + tx;
+    float v = 0.f;
+    if (ch < c && px < hw) v = x[(((size_t)bb * c + ch) * f + fr) * hw + px];
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int px = px0 + r, ch = ch0 + tx;
+    if (px < hw && ch < c_pad) out[((size_t)bf * hw + px) * c_pad + ch] = f32_to_bf16(tile[tx][r]);
+  }
+}
+
+__global__ void nhwc_to_ncfhw_kernel(const float* x, int ld, int b, int c, int f, int hw, float* out) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, c, f, px)
+  long total = (long)b * c * f * hw;
+  if (idx >= total) return;
+  int px = (int)(idx % hw);
+  int fr = (int)((idx / hw) % f);
+  int ch = (int)((idx / ((long)hw * f)) % c);
+  int bb = (int)(idx / ((long)hw * f * c));
+  out[idx] = x[((size_t)(bb * f + fr) * hw + px) * ld + ch];
+}
+
+__global__ void vae_post_kernel(const float* x, int ld, int n, int c, int hw, float* out) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (n, px)
+  if (idx >= (long)n * hw) return;
+  int px = (int)(idx % hw);
+  int fr = (int)(idx / hw);
+  const float* src = x + idx * ld;
+  for (int ch = 0; ch < c; ++ch) {
+    float v = src[ch] * 0.5f + 0.5f;
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    out[((size_t)fr * c + ch) * hw + px] = v;
+  }
+}
+
+inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+}  // namespace
+
+extern "C" int vx_add_row_bias(void* x, int ldx, int rows, int c, const float* bias, float alpha, void* stream) {
+  VX_REQUIRE(x && bias && rows > 0 && (c % 8) == 0 && (ldx % 8) == 0, "vx_add_row_bias: bad arguments");
+  hipLaunchKernelGGL(add_row_bias_kernel, grid1d((long)rows * (c / 8)), dim3(256), 0, (hipStream_t)stream,
+                     (bf16_t*)x, ldx, rows, c, bias, alpha);
+  return vx_check_launch("vx_add_row_bias");
+}
+
+extern "C" int vx_gather_latents(const float* latents, int c, int total_frames, int hw, const int32_t* frame_ids,
+                                 int f, int reps, int c_pad, void* out, void* stream) {
+  VX_REQUIRE(latents && frame_ids && out && c_pad >= c && (c_pad % 8) == 0 && f > 0 && reps > 0,
+             "vx_gather_latents: bad arguments");
+  hipLaunchKernelGGL(gather_latents_kernel, grid1d((long)reps * f * hw), dim3(256), 0, (hipStream_t)stream, latents,
+                     c, total_frames, hw, frame_ids, f, reps, c_pad, (bf16_t*)out);
+  return vx_check_launch("vx_gather_latents");
+}
+
+extern "C" int vx_cfg_combine(const float* unet_out, int ld, int c, int f, int hw, float guidance, float* pred_slot,
+                              void* stream) {
+  VX_REQUIRE(unet_out && pred_slot && ld >= c, "vx_cfg_combine: bad arguments");
+  hipLaunchKernelGGL(cfg_combine_kernel, grid1d((long)f * hw), dim3(256), 0, (hipStream_t)stream, unet_out, ld, c, f,
+                     hw, guidance, pred_slot);
+  return vx_check_launch("vx_cfg_combine");
+}
+
+extern "C" int vx_overlap_ddim_step(float* latents, int c, int total_frames, int hw, const float* preds, int f_window,
+                                    const int32_t* terms, int max_terms, const int32_t* frame_ids,
+                                    const float* count, int n_frames, float sqrt_a, float sqrt_1ma, float sqrt_ap,
+                                    float sqrt_1map, void* stream) {
+  VX_REQUIRE(latents && preds && terms && frame_ids && count && n_frames > 0 && max_terms > 0,
+             "vx_overlap_ddim_step: bad arguments");
+  hipLaunchKernelGGL(overlap_ddim_kernel, grid1d((long)n_frames * c * hw), dim3(256), 0, (hipStream_t)stream, latents,
+                     c, total_frames, hw, preds, f_window, terms, max_terms, frame_ids, count, n_frames, sqrt_a,
+                     sqrt_1ma, sqrt_ap, sqrt_1map);
+  return vx_check_launch("vx_overlap_ddim_step");
+}
+
+extern "C" int vx_ncfhw_to_nhwc(const float* x, int b, int c, int f, int hw, int c_pad, void* out, void* stream) {
+  VX_REQUIRE(x && out && c_pad >= c && (long)b * f <= 65535, "vx_ncfhw_to_nhwc: bad arguments");
+  dim3 grid((hw + 31) / 32, (c_pad + 31) / 32, b * f);
+  hipLaunchKernelGGL(ncfhw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, b, c, f, hw, c_pad,
+                     (bf16_t*)out);
+  return vx_check_launch("vx_ncfhw_to_nhwc");
+}
+
+extern "C" int vx_nhwc_to_ncfhw(const float* x, int ld, int b, int c, int f, int hw, float* out, void* stream) {
+  VX_REQUIRE(x && out && ld >= c, "vx_nhwc_to_ncfhw: bad arguments");
+  hipLaunchKernelGGL(nhwc_to_ncfhw_kernel, grid1d((long)b * c * f * hw), dim3(256), 0, (hipStream_t)stream, x, ld, b,
+                     c, f, hw, out);
+  return vx_check_launch("vx_nhwc_to_ncfhw");
+}
+
+extern "C" int vx_vae_postprocess(const float* x, int ld, int n, int c, int hw, float* out, void* stream) {
+  VX_REQUIRE(x && out && ld >= c, "vx_vae_postprocess: bad arguments");
+  hipLaunchKernelGGL(vae_post_kernel, grid1d((long)n * hw), dim3(256), 0, (hipStream_t)stream, x, ld, n, c, hw, out);
+  return vx_check_launch("vx_vae_postprocess");
+}

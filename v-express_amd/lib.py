@@ -1,0 +1,110 @@
+"""ctypes binding of libvexpress_hip.so (C ABI: include/vexpress_hip.h).
+
+There is NO fallback: if the library is missing, unbuildable or lacks a symbol, importing this module
+raises.  The library is built in-tree (v-express_amd/libvexpress_hip.so) by `__graft_entry__.build()` /
+`make -C v-express_amd/csrc`, so it travels with the repo snapshot to the GPU box.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvexpress_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "vexpress_hip.h")
+
+VX_EPI_STORE, VX_EPI_GEGLU, VX_EPI_SPLIT = 0, 1, 2
+VX_PART_ROWS, VX_PART_VT = 0, 1
+VX_ACT_NONE, VX_ACT_SILU = 0, 1
+
+
+class GemmParams(C.Structure):
+    """Mirror of `vx_gemm_params` (include/vexpress_hip.h)."""
+    _fields_ = [
+        ("a", C.c_void_p), ("a2", C.c_void_p),
+        ("c1", C.c_int32), ("c2", C.c_int32),
+        ("lda1", C.c_int32), ("lda2", C.c_int32),
+        ("nb", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("upsample", C.c_int32),
+        ("h_out", C.c_int32), ("w_out", C.c_int32),
+        ("w", C.c_void_p),
+        ("n", C.c_int32), ("k", C.c_int32), ("m", C.c_int32),
+        ("epi", C.c_int32), ("act", C.c_int32),
+        ("alpha", C.c_float),
+        ("bias", C.c_void_p), ("rowbias", C.c_void_p),
+        ("rowbias_ld", C.c_int32), ("rows_per_group", C.c_int32),
+        ("residual", C.c_void_p), ("ldr", C.c_int32),
+        ("out", C.c_void_p), ("ldc", C.c_int32), ("out_f32", C.c_int32),
+        ("part_cols", C.c_int32), ("n_parts", C.c_int32),
+        ("part_out", C.c_void_p * 3), ("part_kind", C.c_int32 * 3), ("part_ld", C.c_int32 * 3),
+        ("seq_len", C.c_int32), ("head_dim", C.c_int32), ("vt_pitch", C.c_int32),
+    ]
+
+
+def declared_symbols():
+    """Every function name declared in include/vexpress_hip.h."""
+    with open(HEADER) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vx_[a-z0-9_]+)\s*\(", text)))
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 (cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    r = subprocess.run(["make", "-C", CSRC, "-j", str(os.cpu_count() or 4)], capture_output=True, text=True)
+    if r.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise RuntimeError("building libvexpress_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or `make -C v-express_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    if missing:
+        raise ImportError(f"{LIB_PATH} does not export {missing}; rebuild it")
+    i32, f32, vp, i64 = C.c_int32, C.c_float, C.c_void_p, C.c_int64
+    lib.vx_last_error_string.restype = C.c_char_p
+    lib.vx_abi_version.restype = i32
+    lib.vx_device_info.argtypes = [i32, C.POINTER(i32)]
+    lib.vx_gemm.argtypes = [C.POINTER(GemmParams), vp]
+    lib.vx_groupnorm_ws_floats.restype = i64
+    lib.vx_groupnorm_ws_floats.argtypes = [i32, i32, i32]
+    lib.vx_groupnorm.argtypes = [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, i32, vp]
+    lib.vx_layernorm.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp]
+    lib.vx_attention.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp]
+    lib.vx_temporal_attention.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp]
+    lib.vx_small_kv_attention.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp]
+    lib.vx_add_row_bias.argtypes = [vp, i32, i32, i32, vp, f32, vp]
+    lib.vx_gather_latents.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp]
+    lib.vx_cfg_combine.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
+    lib.vx_overlap_ddim_step.argtypes = [vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, f32, f32, f32, f32, vp]
+    lib.vx_ncfhw_to_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.vx_nhwc_to_ncfhw.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.vx_vae_postprocess.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    for name in declared_symbols():
+        fn = getattr(lib, name)
+        if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats"):
+            fn.restype = i32
+    if lib.vx_abi_version() != 1:
+        raise ImportError("libvexpress_hip.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+class VxError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.vx_last_error_string().decode("utf-8", "replace")
+        raise VxError(f"libvexpress_hip {what} failed (rc={rc}): {msg}")

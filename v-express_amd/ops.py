@@ -1,0 +1,334 @@
+"""Tensor-level wrappers around the C ABI (include/vexpress_hip.h).
+
+PyTorch is used for device memory and streams only: every wrapper passes raw device pointers, explicit
+shapes/strides and `torch.cuda.current_stream()` to libvexpress_hip.so.  Activations are bf16
+channels-last tokens `[frames, H*W, C]`; weights are pre-laid-out by `weights.py`.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+
+BF16 = torch.bfloat16
+_lib = L.lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class GemmProfile:
+    """Optional per-launch HIP-event timing of vx_gemm (bench.py's roofline leg).  Events are recorded on the
+    same stream the kernels are launched on (torch's current stream)."""
+    active = None
+
+    def __init__(self):
+        self.records = []          # (start_event, end_event, flops, tile_key)
+
+    def __enter__(self):
+        GemmProfile.active = self
+        return self
+
+    def __exit__(self, *a):
+        GemmProfile.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        by = {}
+        for s, e, fl, key in self.records:
+            d = by.setdefault(key, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += s.elapsed_time(e) * 1e-3
+            d[2] += fl
+        return {k: dict(launches=v[0], seconds=v[1], flops=v[2]) for k, v in by.items()}
+
+
+def _tile_key(p):
+    if p.epi == L.VX_EPI_GEGLU:
+        return "gemm_kernel<128,128,GEGLU>"
+    if p.epi == L.VX_EPI_STORE and p.n <= 32:
+        return "gemm_kernel<256,32,STORE>"
+    w160 = -(-p.n // 160) * 160 - p.n
+    w128 = -(-p.n // 128) * 128 - p.n
+    tile = "128,160" if w160 * 128 <= w128 * 160 else "128,128"
+    return f"gemm_kernel<{tile},{'STORE' if p.epi == L.VX_EPI_STORE else 'SPLIT'}>"
+
+
+def _launch_gemm(p, what):
+    prof = GemmProfile.active
+    if prof is None:
+        L.check(_lib.vx_gemm(C.byref(p), _stream()), what)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    L.check(_lib.vx_gemm(C.byref(p), _stream()), what)
+    e.record()
+    prof.records.append((s, e, 2.0 * p.m * p.n * p.k, _tile_key(p)))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk_bf16(t, name):
+    if t.dtype != BF16 or not t.is_cuda:
+        raise TypeError(f"{name}: expected a CUDA bf16 tensor, got {t.dtype} on {t.device}")
+
+
+def _row_stride(t):
+    """Row stride (elements) of a 2-D / [.., C] view whose last dim is contiguous."""
+    if t.stride(-1) != 1:
+        raise ValueError("last dimension must be contiguous")
+    t2 = t if t.dim() == 2 else t.reshape(-1, t.shape[-1]) if t.is_contiguous() else None
+    if t2 is None:
+        raise ValueError("activation view must be 2-D or contiguous")
+    return t2.stride(0), t2.shape[0]
+
+
+class ConvGeom:
+    """Geometry of an implicit-GEMM convolution over NHWC frames."""
+
+    def __init__(self, nb, h_in, w_in, kh=1, kw=1, stride=1, pad=0, upsample=0):
+        self.nb, self.h_in, self.w_in = nb, h_in, w_in
+        self.kh, self.kw, self.stride, self.pad, self.upsample = kh, kw, stride, pad, upsample
+        he, we = h_in << upsample, w_in << upsample
+        self.h_out = (he + 2 * pad - kh) // stride + 1
+        self.w_out = (we + 2 * pad - kw) // stride + 1
+
+    @property
+    def m(self):
+        return self.nb * self.h_out * self.w_out
+
+
+def _base_params(a, w, geom, a2=None):
+    """a: [rows, C1] view (row stride allowed); a2 likewise; w: [N, K] bf16 contiguous."""
+    _chk_bf16(a, "a")
+    _chk_bf16(w, "w")
+    p = L.GemmParams()
+    lda1, rows = _row_stride(a)
+    p.a, p.c1, p.lda1 = a.data_ptr(), a.shape[-1], lda1
+    if a2 is not None:
+        _chk_bf16(a2, "a2")
+        lda2, rows2 = _row_stride(a2)
+        if rows2 != rows:
+            raise ValueError("a/a2 row mismatch")
+        p.a2, p.c2, p.lda2 = a2.data_ptr(), a2.shape[-1], lda2
+    else:
+        p.a2, p.c2, p.lda2 = None, 0, 0
+    if geom is None:
+        geom = ConvGeom(1, rows, 1)
+    if rows != geom.nb * geom.h_in * geom.w_in:
+        raise ValueError(f"activation rows {rows} != nb*h*w {geom.nb * geom.h_in * geom.w_in}")
+    p.nb, p.h_in, p.w_in = geom.nb, geom.h_in, geom.w_in
+    p.kh, p.kw, p.stride, p.pad, p.upsample = geom.kh, geom.kw, geom.stride, geom.pad, geom.upsample
+    p.h_out, p.w_out = geom.h_out, geom.w_out
+    if not w.is_contiguous() or w.dim() != 2:
+        raise ValueError("weight must be a contiguous [N, K] matrix")
+    p.w, p.n, p.k, p.m = w.data_ptr(), w.shape[0], w.shape[1], geom.m
+    p.alpha = 1.0
+    return p, geom
+
+
+def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L.VX_ACT_NONE, rowbias=None,
+         rows_per_group=0, out=None, out_f32=False):
+    """out[m, n] = residual + alpha * act(sum_k A[m,k] W[n,k] + bias[n] + rowbias[m // rows_per_group, n])."""
+    p, geom = _base_params(a, w, geom, a2)
+    n = p.n
+    if out is None:
+        out = torch.empty((geom.m, n), device=a.device, dtype=torch.float32 if out_f32 else BF16)
+    ldc, orows = _row_stride(out)
+    if orows != geom.m or out.shape[-1] != n:
+        raise ValueError("bad output shape")
+    p.epi, p.act, p.alpha = L.VX_EPI_STORE, act, float(alpha)
+    p.bias = bias.data_ptr() if bias is not None else None
+    if rowbias is not None:
+        if rowbias.dtype != torch.float32 or rowbias.stride(-1) != 1:
+            raise TypeError("rowbias must be float32 with contiguous columns")
+        p.rowbias, p.rowbias_ld, p.rows_per_group = rowbias.data_ptr(), rowbias.stride(0), rows_per_group
+    if residual is not None:
+        _chk_bf16(residual, "residual")
+        p.residual, p.ldr = residual.data_ptr(), _row_stride(residual)[0]
+    p.out, p.ldc, p.out_f32 = out.data_ptr(), ldc, int(out_f32)
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError("bias must be float32")
+    _launch_gemm(p, "vx_gemm")
+    return out
+
+
+def geglu(a, w_interleaved, bias_interleaved, out=None):
+    """FeedForward first half: h * gelu(g) with value/gate weight rows interleaved in blocks of 16."""
+    p, geom = _base_params(a, w_interleaved, None)
+    if out is None:
+        out = torch.empty((geom.m, p.n // 2), device=a.device, dtype=BF16)
+    p.epi = L.VX_EPI_GEGLU
+    p.bias = bias_interleaved.data_ptr() if bias_interleaved is not None else None
+    p.out, p.ldc = out.data_ptr(), _row_stride(out)[0]
+    _launch_gemm(p, "vx_gemm(geglu)")
+    return out
+
+
+def vt_pitch(n):
+    return (n + 7) // 8 * 8
+
+
+def gemm_split(a, w, bias, parts, *, part_cols, seq_len=0, head_dim=0, geom=None):
+    """One GEMM whose column ranges go to different destinations.
+    parts: list of ("rows", tensor[m, part_cols]) or ("vt", tensor[seqs, heads, head_dim, pitch])."""
+    p, geom = _base_params(a, w, geom)
+    p.epi = L.VX_EPI_SPLIT
+    p.bias = bias.data_ptr() if bias is not None else None
+    p.part_cols, p.n_parts = part_cols, len(parts)
+    p.seq_len, p.head_dim = seq_len, head_dim
+    for i, (kind, t) in enumerate(parts):
+        _chk_bf16(t, "part")
+        p.part_out[i] = t.data_ptr()
+        if kind == "rows":
+            p.part_kind[i] = L.VX_PART_ROWS
+            p.part_ld[i] = _row_stride(t)[0]
+        else:
+            p.part_kind[i] = L.VX_PART_VT
+            p.part_ld[i] = 0
+            p.vt_pitch = t.shape[-1]
+            if not t.is_contiguous():
+                raise ValueError("V^T destination must be contiguous")
+    _launch_gemm(p, "vx_gemm(split)")
+
+
+def alloc_vt(seqs, heads, head_dim, n, device):
+    """V^T buffer [seqs, heads, head_dim, pitch]; zero-filled when the pitch pads the key axis."""
+    pitch = vt_pitch(n)
+    if pitch != n:
+        return torch.zeros((seqs, heads, head_dim, pitch), device=device, dtype=BF16)
+    return torch.empty((seqs, heads, head_dim, pitch), device=device, dtype=BF16)
+
+
+def _gn_slices(hw):
+    """Spatial slices per frame for the GroupNorm statistics.  A function of hw ONLY: the partial-sum grouping
+    (hence the fp32 rounding) must not depend on how many frames share the launch, so that a CFG half or a
+    window computed on another GPU is bit-identical to the batched call."""
+    return max(1, min(64, hw // 128))
+
+
+def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=None):
+    """x1: [frames, hw, C1] (+ x2: [frames, hw, C2] channel-concatenated) -> [frames, hw, C1+C2]."""
+    _chk_bf16(x1, "x1")
+    if not x1.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+        raise ValueError("groupnorm inputs must be contiguous")
+    c1 = x1.shape[-1]
+    c2 = x2.shape[-1] if x2 is not None else 0
+    if out is None:
+        out = torch.empty((frames, hw, c1 + c2), device=x1.device, dtype=BF16)
+    slices = _gn_slices(hw)
+    ws = torch.empty(int(_lib.vx_groupnorm_ws_floats(frames, slices, groups)), device=x1.device,
+                     dtype=torch.float32)
+    L.check(_lib.vx_groupnorm(_ptr(x1), c1, _ptr(x2), c2, frames, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
+                              int(silu), _ptr(out), _ptr(ws), slices, _stream()), "vx_groupnorm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_entries=1, out=None):
+    _chk_bf16(x, "x")
+    ldx, rows = _row_stride(x)
+    c = x.shape[-1]
+    if out is None:
+        out = torch.empty((rows, c), device=x.device, dtype=BF16)
+    L.check(_lib.vx_layernorm(_ptr(x), ldx, rows, c, float(eps), _ptr(gamma), _ptr(beta), _ptr(add),
+                              add_rows_per_entry, add_entries, _ptr(out), _row_stride(out)[0], _stream()),
+            "vx_layernorm")
+    return out
+
+
+def attention(q, k, vt, *, batch, heads, n_q, n_kv, head_dim, q_per_kv=1, out=None):
+    """q: [batch*n_q, *] view; k: [kv_batches*n_kv, *] view; vt: [kv_batches, heads, head_dim, pitch]."""
+    ldq, _ = _row_stride(q)
+    ldk, _ = _row_stride(k)
+    if out is None:
+        out = torch.empty((batch * n_q, heads * head_dim), device=q.device, dtype=BF16)
+    L.check(_lib.vx_attention(_ptr(q), ldq, _ptr(k), ldk, _ptr(vt), vt.shape[-1], _ptr(out), _row_stride(out)[0],
+                              batch, heads, n_q, n_kv, head_dim, q_per_kv, head_dim ** -0.5, _stream()),
+            "vx_attention")
+    return out
+
+
+def temporal_attention(qkv, *, b, f, hw, heads, head_dim, out=None):
+    """qkv: [(b f) hw, 3C] (Q | K | V columns) -> [(b f) hw, C]; attention runs over f per (b, pixel, head)."""
+    _chk_bf16(qkv, "qkv")
+    ld, rows = _row_stride(qkv)
+    if rows != b * f * hw:
+        raise ValueError("qkv rows != b*f*hw")
+    if out is None:
+        out = torch.empty((rows, heads * head_dim), device=qkv.device, dtype=BF16)
+    L.check(_lib.vx_temporal_attention(_ptr(qkv), ld, _ptr(out), _row_stride(out)[0], b, f, hw, heads, head_dim,
+                                       head_dim ** -0.5, _stream()), "vx_temporal_attention")
+    return out
+
+
+def small_kv_attention(q, kv, *, batch, n_q, n_kv, heads, head_dim, out=None):
+    """q: [batch*n_q, C]; kv: [batch*n_kv, 2C] (K | V columns) -> [batch*n_q, C]."""
+    ldq, _ = _row_stride(q)
+    ldkv, _ = _row_stride(kv)
+    c = heads * head_dim
+    if out is None:
+        out = torch.empty((batch * n_q, c), device=q.device, dtype=BF16)
+    L.check(_lib.vx_small_kv_attention(_ptr(q), ldq, _ptr(kv), ldkv, c, _ptr(out), _row_stride(out)[0], batch, n_q,
+                                       n_kv, heads, head_dim, head_dim ** -0.5, _stream()),
+            "vx_small_kv_attention")
+    return out
+
+
+def add_row_bias(x, bias, alpha=1.0):
+    ldx, rows = _row_stride(x)
+    L.check(_lib.vx_add_row_bias(_ptr(x), ldx, rows, x.shape[-1], _ptr(bias), float(alpha), _stream()),
+            "vx_add_row_bias")
+    return x
+
+
+def gather_latents(latents, frame_ids, reps, c_pad=8):
+    """latents fp32 [1, C, F, h, w], frame_ids int32 [f] (device) -> bf16 [reps*f, h*w, c_pad]."""
+    _, c, F, h, w = latents.shape
+    f = frame_ids.numel()
+    out = torch.empty((reps * f, h * w, c_pad), device=latents.device, dtype=BF16)
+    L.check(_lib.vx_gather_latents(_ptr(latents), c, F, h * w, _ptr(frame_ids), f, reps, c_pad, _ptr(out),
+                                   _stream()), "vx_gather_latents")
+    return out
+
+
+def cfg_combine(unet_out, c, f, hw, guidance, pred_slot):
+    """unet_out fp32 [2f*hw, ld] -> pred_slot fp32 [c, f, hw] = u + s (c - u)."""
+    L.check(_lib.vx_cfg_combine(_ptr(unet_out), unet_out.stride(0), c, f, hw, float(guidance), _ptr(pred_slot),
+                                _stream()), "vx_cfg_combine")
+
+
+def overlap_ddim_step(latents, preds, terms, frame_ids, counts, coef):
+    """latents fp32 [1,C,F,h,w] updated in place for `frame_ids`; preds fp32 [slots, C, f, hw]."""
+    _, c, F, h, w = latents.shape
+    n = frame_ids.numel()
+    L.check(_lib.vx_overlap_ddim_step(_ptr(latents), c, F, h * w, _ptr(preds), preds.shape[2], _ptr(terms),
+                                      terms.shape[1], _ptr(frame_ids), _ptr(counts), n, *[float(v) for v in coef],
+                                      _stream()), "vx_overlap_ddim_step")
+
+
+def ncfhw_to_nhwc(x, c_pad=None):
+    """fp32 [b, C, f, h, w] -> bf16 [(b f), h*w, c_pad]."""
+    b, c, f, h, w = x.shape
+    c_pad = c_pad or (c + 7) // 8 * 8
+    x = x.contiguous().float()
+    out = torch.empty((b * f, h * w, c_pad), device=x.device, dtype=BF16)
+    L.check(_lib.vx_ncfhw_to_nhwc(_ptr(x), b, c, f, h * w, c_pad, _ptr(out), _stream()), "vx_ncfhw_to_nhwc")
+    return out
+
+
+def nhwc_to_ncfhw(x, b, c, f, h, w):
+    """fp32 [(b f)*hw, ld] -> fp32 [b, c, f, h, w]."""
+    out = torch.empty((b, c, f, h, w), device=x.device, dtype=torch.float32)
+    L.check(_lib.vx_nhwc_to_ncfhw(_ptr(x), x.stride(0), b, c, f, h * w, _ptr(out), _stream()), "vx_nhwc_to_ncfhw")
+    return out
+
+
+def vae_postprocess(x, n, c, h, w):
+    """fp32 [n*hw, ld] -> fp32 [n, c, h, w] = clamp(x/2 + 0.5, 0, 1)."""
+    out = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    L.check(_lib.vx_vae_postprocess(_ptr(x), x.stride(0), n, c, h * w, _ptr(out), _stream()), "vx_vae_postprocess")
+    return out

@@ -1,0 +1,263 @@
+"""Drop-in for the reference `VExpressPipeline` (pipelines/v_express_pipeline.py:71-646) with the hot loop on
+libvexpress_hip kernels and everything resident in HBM.
+
+Same constructor kwargs and `__call__` signature/defaults as the reference (SURVEY.md §8b surface #1); returns
+a float32 `[1, 3, F, H, W]` tensor in [0, 1] (on the CPU like the reference unless `output_device` is given).
+
+Differences that change memory/time but not results: latents, kps features and
+predictions never visit the host (the reference keeps latents and kps features on the CPU and copies a window
+up/down every step: :363,:521,:531,:538,:572); the per-frame Python bookkeeping of :552-572 is replayed once on
+the host into a static plan (context.overlap_plan) and executed by two small kernels; CFG + 1/count + sum + DDIM
+step are fused; the VAE decodes frames in batches.  With `torch.distributed` initialised the (window, CFG-half)
+units of a timestep are sharded over the ranks (distributed.py) — the reference's
+`do_multi_devices_inference` flag is accepted and, as in the reference, changes nothing by itself.
+
+Out of scope: the once-per-clip prologue models (VKpsGuider, wav2vec2,
+AudioProjection, VAE encoder).  They are called through the reference's own hooks when provided as torch
+modules; the benchmark and the parity tests pass their outputs in directly (`reference_latents=`,
+`kps_features=`, `audio_embeddings=`, `latents=` keyword arguments).
+"""
+import math
+from typing import Callable, List, Optional, Union
+
+import torch
+
+from . import ops
+from .context import get_context_scheduler, overlap_plan
+from .distributed import DistContext, group_calls, partition_units, split_frames
+from .mutual_self_attention import ReferenceAttentionControl
+
+
+class VExpressPipeline:
+    def __init__(self, vae, reference_net, denoising_unet, v_kps_guider=None, audio_processor=None,
+                 audio_encoder=None, audio_projection=None, scheduler=None, image_proj_model=None, tokenizer=None,
+                 text_encoder=None):
+        self.vae = vae
+        self.reference_net = reference_net
+        self.denoising_unet = denoising_unet
+        self.v_kps_guider = v_kps_guider
+        self.audio_processor = audio_processor
+        self.audio_encoder = audio_encoder
+        self.audio_projection = audio_projection
+        self.scheduler = scheduler
+        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
+        self.dist = DistContext.from_env()
+        self.last_timing = {}
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def device(self):
+        return self.denoising_unet.device
+
+    @property
+    def dtype(self):
+        return self.denoising_unet.dtype
+
+    def to(self, *args, **kwargs):
+        for m in (self.vae, self.reference_net, self.denoising_unet):
+            m.to(*args, **kwargs)
+        return self
+
+    # ------------------------------------------------------------------ once-per-clip prologue (reference hooks)
+    def prepare_reference_latent(self, reference_image, height, width):
+        """pipelines/v_express_pipeline.py:343-348 (needs a VAE *encoder*, out of scope: pass reference_latents=)."""
+        raise NotImplementedError("VAE-encoding the reference image is out of the hot-path scope; "
+                                  "pass reference_latents=[1,4,h/8,w/8] (already scaled by 0.18215)")
+
+    def prepare_kps_feature(self, kps_images, height, width, do_classifier_free_guidance):
+        """pipelines/v_express_pipeline.py:350-372 through a user-provided torch VKpsGuider."""
+        if self.v_kps_guider is None:
+            raise NotImplementedError("no v_kps_guider given; pass kps_features=[2,320,F,h/8,w/8]")
+        import numpy as np
+        frames = []
+        for img in kps_images:
+            arr = np.asarray(img.convert("RGB").resize((width, height)), dtype=np.float32) / 255.0
+            frames.append(torch.from_numpy(arr).permute(2, 0, 1)[None, :, None])
+        x = torch.cat(frames, dim=2).to(self.device)
+        feats = [self.v_kps_guider(x[:, :, i:i + 16].to(next(self.v_kps_guider.parameters()).dtype)).float()
+                 for i in range(0, x.shape[2], 16)]
+        feat = torch.cat(feats, dim=2)
+        if do_classifier_free_guidance:
+            feat = torch.cat([torch.zeros_like(feat), feat], dim=0)
+        return feat
+
+    def prepare_audio_embeddings(self, audio_waveform, video_length, num_pad_audio_frames,
+                                 do_classifier_free_guidance):
+        """pipelines/v_express_pipeline.py:374-407 through user-provided wav2vec2 + AudioProjection modules."""
+        if self.audio_encoder is None or self.audio_projection is None or self.audio_processor is None:
+            raise NotImplementedError("no audio modules given; pass audio_embeddings=[2,F,5,768]")
+        wav = self.audio_processor(audio_waveform, return_tensors="pt", sampling_rate=16000)["input_values"]
+        enc_dtype = next(self.audio_encoder.parameters()).dtype
+        emb = self.audio_encoder(wav.to(self.device, enc_dtype)).last_hidden_state
+        emb = torch.nn.functional.interpolate(emb.float().permute(0, 2, 1), size=2 * video_length,
+                                              mode="linear")[0].permute(1, 0).to(enc_dtype)
+        pad = torch.zeros_like(emb)[:2 * num_pad_audio_frames]
+        emb = torch.cat([pad, emb, pad], dim=0)
+        per_frame = torch.stack([emb[2 * i:2 * (i + 2 * num_pad_audio_frames + 1)] for i in range(video_length)])
+        out = self.audio_projection(per_frame).unsqueeze(0)
+        if do_classifier_free_guidance:
+            out = torch.cat([torch.zeros_like(out), out], dim=0)
+        return out
+
+    def prepare_latents(self, batch_size, num_channels_latents, width, height, video_length, dtype, device,
+                        generator, latents=None):
+        """pipelines/v_express_pipeline.py:189-224: N(0,1) drawn on the CPU generator, times init_noise_sigma.
+        Drawn in fp32 so the draw does not depend on the compute dtype (SURVEY.md §8c RNG note)."""
+        shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor,
+                 width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(
+                f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            latents = torch.randn(shape, generator=generator, device="cpu", dtype=torch.float32)
+        return latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
+
+    # ------------------------------------------------------------------ the hot loop
+    def denoise(self, latents, kps_tokens, audio, timesteps, windows, guidance_scale, callback=None,
+                callback_steps=1):
+        """pipelines/v_express_pipeline.py:526-583.  latents fp32 [1,4,F,h,w] (device, updated in place);
+        kps_tokens bf16 [2, F, hw, C0]; audio bf16 [2, F, n_ctx, 768]."""
+        unet, dc, dev = self.denoising_unet, self.dist, latents.device
+        _, C, F, H, W = latents.shape
+        hw = H * W
+        f = len(windows[0])
+        if any(len(w) != f for w in windows):
+            raise ValueError("all context windows must have the same length")
+        nW = len(windows)
+        plan = overlap_plan(windows, F)
+        win_ids = torch.tensor(windows, dtype=torch.int32, device=dev)
+        win_ids_long = win_ids.long()
+        sf = plan["step_frames"]
+        terms = torch.full((len(sf), plan["max_terms"], 2), -1, dtype=torch.int32)
+        for i, fr in enumerate(sf):
+            for j, (wi, li) in enumerate(plan["terms"][fr]):
+                terms[i, j, 0], terms[i, j, 1] = wi, li
+        terms = terms.to(dev)
+        frame_ids = torch.tensor(sf, dtype=torch.int32, device=dev)
+        counts = torch.tensor([float(plan["counts"][fr]) for fr in sf], dtype=torch.float32, device=dev)
+        # work units of this rank
+        assign = partition_units(nW, dc.world_size)
+        my_calls = group_calls(assign[dc.rank])
+        max_units = max(len(a) for a in assign)
+        unit_slot = {}
+        for r, units in enumerate(assign):
+            for s, u in enumerate(units):
+                unit_slot[u] = (r, s)
+        n_out = 8
+        local = torch.zeros((max_units, f * hw, n_out), device=dev, dtype=torch.float32)
+        preds = torch.empty((nW, C, f, hw), device=dev, dtype=torch.float32)
+        pair = torch.empty((2 * f * hw, n_out), device=dev, dtype=torch.float32)
+        do_cfg = guidance_scale > 1.0
+        if not do_cfg:
+            raise NotImplementedError("guidance_scale <= 1 (no CFG) is not wired; V-Express defaults to 3.5")
+        # per-call constants (window ids, conditioning slices) do not depend on the timestep: build them once so
+        # the timestep loop issues kernels only (no host->device copies, no syncs)
+        calls = []
+        for wi, halves in my_calls:
+            hsel = torch.tensor(halves, device=dev)
+            kps = kps_tokens.index_select(0, hsel).index_select(1, win_ids_long[wi]).reshape(len(halves) * f, hw, -1)
+            ehs = audio.index_select(0, hsel).index_select(1, win_ids_long[wi])
+            calls.append((wi, halves, win_ids[wi], kps.contiguous(), ehs.reshape(-1, ehs.shape[-1]).contiguous()))
+        for i, t in enumerate(timesteps):
+            t = int(t)
+            for wi, halves, ids, kps, ehs in calls:
+                x_in = ops.gather_latents(latents, ids, reps=len(halves))
+                out = unet.forward_tokens(x_in, t, ehs, kps, b=len(halves), f=f, H=H, W=W, batch_rows=halves)
+                for j, hlf in enumerate(halves):
+                    local[unit_slot[(wi, hlf)][1]].copy_(out[j * f * hw:(j + 1) * f * hw])
+            gathered = dc.all_gather_units(local, max_units)          # [world, max_units, f*hw, 8]
+            for wi in range(nW):
+                ru, su = unit_slot[(wi, 0)]
+                rc, sc = unit_slot[(wi, 1)]
+                pair[:f * hw].copy_(gathered[ru, su])
+                pair[f * hw:].copy_(gathered[rc, sc])
+                ops.cfg_combine(pair, C, f, hw, guidance_scale, preds[wi])
+            ops.overlap_ddim_step(latents, preds, terms, frame_ids, counts, self.scheduler.step_coefficients(t))
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, latents)
+        return latents
+
+    @torch.no_grad()
+    def decode_latents(self, latents, chunk=8):
+        """pipelines/v_express_pipeline.py:152-166; frames are split evenly over the ranks when distributed."""
+        dc = self.dist
+        F = latents.shape[2]
+        if not dc.enabled:
+            return self.vae.decode_video(latents, chunk=chunk)
+        spans = split_frames(F, dc.world_size)
+        lo, hi = spans[dc.rank]
+        per = spans[0][1] - spans[0][0]
+        part = self.vae.decode_video(latents[:, :, lo:hi].contiguous(), chunk=chunk) if hi > lo else None
+        Hh, Ww = latents.shape[-2] * self.vae_scale_factor, latents.shape[-1] * self.vae_scale_factor
+        buf = torch.zeros((per, 3, Hh, Ww), device=latents.device, dtype=torch.float32)
+        if part is not None:
+            buf[:hi - lo].copy_(part[0].permute(1, 0, 2, 3))
+        allf = dc.all_gather_frames(buf).reshape(-1, 3, Hh, Ww)[:F]
+        return allf.permute(1, 0, 2, 3).unsqueeze(0)
+
+    # ------------------------------------------------------------------ reference call surface
+    @torch.no_grad()
+    def __call__(self, reference_image, kps_images, audio_waveform, width, height, video_length,
+                 num_inference_steps, guidance_scale, strength=1., num_images_per_prompt=1, eta: float = 0.0,
+                 generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None,
+                 output_type: Optional[str] = "tensor", return_dict: bool = True,
+                 callback: Optional[Callable[[int, int, torch.FloatTensor], None]] = None,
+                 callback_steps: Optional[int] = 1, context_schedule="uniform", context_frames=24,
+                 context_overlap=4, reference_attention_weight=1., audio_attention_weight=1.,
+                 num_pad_audio_frames=2, do_multi_devices_inference=False, save_gpu_memory=False,
+                 reference_latents=None, kps_features=None, audio_embeddings=None, latents=None,
+                 output_device="cpu", decode=True, **kwargs):
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0 is unused by V-Express")
+        dev = self.device
+        do_cfg = guidance_scale > 1.0
+        # timesteps (retrieve_timesteps + get_timesteps, :448-449)
+        self.scheduler.set_timesteps(num_inference_steps)
+        init_t = min(int(num_inference_steps * strength), num_inference_steps)
+        timesteps = self.scheduler.timesteps[max(num_inference_steps - init_t, 0):].tolist()
+        writer = ReferenceAttentionControl(self.reference_net, do_classifier_free_guidance=do_cfg, mode="write",
+                                           batch_size=1, fusion_blocks="full")
+        reader = ReferenceAttentionControl(self.denoising_unet, do_classifier_free_guidance=do_cfg, mode="read",
+                                           batch_size=1, fusion_blocks="full",
+                                           reference_attention_weight=reference_attention_weight,
+                                           audio_attention_weight=audio_attention_weight)
+        if reference_latents is None:
+            reference_latents = self.prepare_reference_latent(reference_image, height, width)
+        if kps_features is None:
+            kps_features = self.prepare_kps_feature(kps_images, height, width, do_cfg)
+        if audio_embeddings is None:
+            audio_embeddings = self.prepare_audio_embeddings(audio_waveform, video_length, num_pad_audio_frames,
+                                                             do_cfg)
+        windows = list(get_context_scheduler(context_schedule)(
+            step=0, num_frames=video_length, context_size=context_frames, context_stride=1,
+            context_overlap=context_overlap, closed_loop=False))
+        # ReferenceNet once per clip (:502-509)
+        ehs0 = torch.zeros((1, 1, self.denoising_unet.cfg.cross_attention_dim), dtype=torch.float32, device=dev)
+        self.reference_net(reference_latents.to(dev), timestep=0, encoder_hidden_states=ehs0, return_dict=False)
+        reader.update(writer, do_cfg, dtype=self.dtype)
+        lat = self.prepare_latents(num_images_per_prompt, self.denoising_unet.in_channels, width, height,
+                                   video_length, self.dtype, dev, generator, latents)
+        b2, c0, F, h, w = kps_features.shape
+        kps_tokens = ops.ncfhw_to_nhwc(kps_features.to(dev), c0).view(b2, F, h * w, c0)
+        audio = audio_embeddings.to(device=dev, dtype=ops.BF16).contiguous()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        self.denoise(lat, kps_tokens, audio, timesteps, windows, guidance_scale, callback, callback_steps or 1)
+        ev[1].record()
+        reader.clear()
+        writer.clear()
+        if not decode:
+            return lat
+        video = self.decode_latents(lat)
+        ev[2].record()
+        self._events = ev
+        if output_device is not None:
+            video = video.to(output_device)
+        return video
+
+    def timings_ms(self):
+        """(denoise loop, decode) GPU milliseconds of the last call."""
+        e = self._events
+        e[2].synchronize()
+        return e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])

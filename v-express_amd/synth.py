@@ -50,19 +50,31 @@ class VaeConfig:
 
 class _Gen:
     def __init__(self, seed, device="cpu", dtype=torch.float32):
+        self.meta = str(device) == "meta"          # shapes only (schema queries): nothing is drawn
         self.g = torch.Generator(device="cpu")
         self.g.manual_seed(seed)
         self.device = device
         self.dtype = dtype
         self.sd = {}
+        # draw_on_device: use the device's own generator (fast; values differ from the CPU draw, so only for
+        # benchmarks, never for parity tests that need identical weights on both sides)
+        self.dg = None
 
     def _out(self, t):
         return t.to(device=self.device, dtype=self.dtype)
 
     def uniform(self, shape, bound):
+        if self.meta:
+            return torch.empty(shape, device="meta", dtype=self.dtype)
+        if self.dg is not None:
+            return ((torch.rand(shape, generator=self.dg, device=self.device) * 2 - 1) * bound).to(self.dtype)
         return self._out((torch.rand(shape, generator=self.g) * 2 - 1) * bound)
 
     def normal(self, shape, std, mean=0.0):
+        if self.meta:
+            return torch.empty(shape, device="meta", dtype=self.dtype)
+        if self.dg is not None:
+            return (torch.randn(shape, generator=self.dg, device=self.device) * std + mean).to(self.dtype)
         return self._out(torch.randn(shape, generator=self.g) * std + mean)
 
     def linear(self, p, cin, cout, bias=True, small=False):
@@ -216,24 +228,32 @@ def _unet_common(g: _Gen, cfg: UNetConfig, three_d: bool):
     g.conv("conv_out", ch0, cfg.out_channels, 3)
 
 
-def unet3d_state_dict(cfg: UNetConfig = None, seed=42, device="cpu", dtype=torch.float32):
-    """Denoising UNet3DConditionModel weights (1386 tensors at the SD-1.5 config)."""
+def _gen(seed, device, dtype, draw_on_device):
     g = _Gen(seed, device, dtype)
+    if draw_on_device and str(device) not in ("cpu", "meta"):
+        g.dg = torch.Generator(device=device)
+        g.dg.manual_seed(seed)
+    return g
+
+
+def unet3d_state_dict(cfg: UNetConfig = None, seed=42, device="cpu", dtype=torch.float32, draw_on_device=False):
+    """Denoising UNet3DConditionModel weights (1386 tensors at the SD-1.5 config)."""
+    g = _gen(seed, device, dtype, draw_on_device)
     _unet_common(g, cfg or UNetConfig(), True)
     return g.sd
 
 
-def refnet_state_dict(cfg: UNetConfig = None, seed=43, device="cpu", dtype=torch.float32):
+def refnet_state_dict(cfg: UNetConfig = None, seed=43, device="cpu", dtype=torch.float32, draw_on_device=False):
     """ReferenceNet (UNet2DConditionModel, conv_norm_out=None: unet_2d_condition.py:650) weights."""
-    g = _Gen(seed, device, dtype)
+    g = _gen(seed, device, dtype, draw_on_device)
     _unet_common(g, cfg or UNetConfig(), False)
     return g.sd
 
 
-def vae_decoder_state_dict(cfg: VaeConfig = None, seed=44, device="cpu", dtype=torch.float32):
+def vae_decoder_state_dict(cfg: VaeConfig = None, seed=44, device="cpu", dtype=torch.float32, draw_on_device=False):
     """sd-vae-ft-mse decoder half of diffusers AutoencoderKL (post_quant_conv + decoder.*)."""
     cfg = cfg or VaeConfig()
-    g = _Gen(seed, device, dtype)
+    g = _gen(seed, device, dtype, draw_on_device)
     ch = list(cfg.block_out_channels)
     g.conv("post_quant_conv", cfg.latent_channels, cfg.latent_channels, 1)
     g.conv("decoder.conv_in", cfg.latent_channels, ch[-1], 3)

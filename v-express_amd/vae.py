@@ -1,0 +1,138 @@
+"""sd-vae-ft-mse decoder (diffusers AutoencoderKL.decode as called by VExpressPipeline.decode_latents,
+pipelines/v_express_pipeline.py:152-166) on libvexpress_hip kernels.
+
+The arithmetic lives in diffusers==0.29.2 (absent third-party dependency):
+post_quant_conv 1x1 -> conv_in 3x3 -> mid (resnet, single-head attention d=512 with GroupNorm pre-norm, biased
+q/k/v/out and a residual, resnet) -> 4 up blocks x 3 resnets (+ nearest-2x conv3x3 after the first three) ->
+GroupNorm(eps 1e-6) -> SiLU -> conv_out.  The reference decodes one frame at a time and copies each to the
+host (:158-162); here frames are decoded in batches on the device and returned as [n, 3, H, W] fp32.
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import blocks as B
+from . import ops
+from . import weights as Wt
+from .synth import VaeConfig
+
+
+class AutoencoderKLDecoder:
+    """Decoder half of AutoencoderKL with the reference's `vae.decode(z).sample` / `vae.config` surface."""
+
+    def __init__(self, cfg: VaeConfig = None):
+        self.cfg = cfg or VaeConfig()
+        self.config = SimpleNamespace(block_out_channels=tuple(self.cfg.block_out_channels),
+                                      scaling_factor=self.cfg.scaling_factor,
+                                      latent_channels=self.cfg.latent_channels)
+        self._device = torch.device("cpu")
+        self._dtype = torch.bfloat16
+        self._raw = {}
+        self._P = None
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    def to(self, *args, **kwargs):
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.dtype):
+                self._dtype = a
+            elif isinstance(a, (torch.device, str)):
+                self._device = torch.device(a)
+        self._P = None
+        return self
+
+    def eval(self):
+        return self
+
+    def load_state_dict(self, sd, strict=False):
+        keep = {k: v.detach() for k, v in sd.items() if k.startswith(("decoder.", "post_quant_conv."))}
+        self._raw.update(keep)
+        self._P = None
+        return SimpleNamespace(missing_keys=[], unexpected_keys=[k for k in sd if k not in keep])
+
+    def init_random(self, seed=44):
+        from . import synth
+        self.load_state_dict(synth.vae_decoder_state_dict(self.cfg, seed=seed))
+        return self
+
+    def _prepared(self):
+        if self._P is not None:
+            return self._P
+        if self._device.type != "cuda":
+            raise RuntimeError("v_express_amd models run on an MI355X only: call .to('cuda')")
+        sd, dev, cfg = self._raw, self._device, self.cfg
+        P = Wt.Prepared()
+        P["post_quant"] = Wt.prep_conv(sd, "post_quant_conv", dev)
+        P["conv_in"] = Wt.prep_conv(sd, "decoder.conv_in", dev)
+        for j in range(2):
+            P[f"mid.resnets.{j}"] = Wt.prep_resnet(sd, f"decoder.mid_block.resnets.{j}", dev)
+        a = "decoder.mid_block.attentions.0"
+        P["mid.attn"] = Wt.Prepared(norm=Wt.prep_norm(sd, a + ".group_norm", dev), attn=Wt.prep_self_attn(sd, a, dev))
+        n = len(cfg.block_out_channels)
+        for i in range(n):
+            for j in range(cfg.layers_per_block + 1):
+                P[f"up.{i}.resnets.{j}"] = Wt.prep_resnet(sd, f"decoder.up_blocks.{i}.resnets.{j}", dev)
+            if i != n - 1:
+                P[f"up.{i}.upsampler"] = Wt.prep_conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", dev)
+        P["norm_out"] = Wt.prep_norm(sd, "decoder.conv_norm_out", dev)
+        P["conv_out"] = Wt.prep_conv(sd, "decoder.conv_out", dev)
+        self._P = P
+        return P
+
+    def decode_tokens(self, z_tokens, n, H, W):
+        """z_tokens: bf16 [n, hw, 8] (latent channels zero-padded; already divided by the scaling factor)
+        -> fp32 [n*(8H)*(8W), 8] NHWC (columns >= 3 are zero)."""
+        P, cfg = self._prepared(), self.cfg
+        g = cfg.norm_num_groups
+        hw = H * W
+        x = ops.gemm(z_tokens.view(n * hw, -1), P.post_quant.w, P.post_quant.b)
+        x = ops.gemm(x, P.conv_in.w, P.conv_in.b, geom=ops.ConvGeom(n, H, W, 3, 3, 1, 1)).view(n, hw, -1)
+        x = B.resnet_block(P["mid.resnets.0"], x, n, H, W, groups=g, eps=1e-6)
+        # single-head attention with GroupNorm pre-norm and residual
+        c = x.shape[-1]
+        A = P["mid.attn"]
+        nrm = ops.groupnorm(x, A.norm.g, A.norm.b, frames=n, hw=hw, groups=g, eps=1e-6, silu=False)
+        h = x.reshape(n * hw, c).clone()
+        B._self_attention(A.attn, nrm.view(n * hw, c), h, seqs=n, n_tok=hw, heads=1)
+        x = h.view(n, hw, c)
+        x = B.resnet_block(P["mid.resnets.1"], x, n, H, W, groups=g, eps=1e-6)
+        nb = len(cfg.block_out_channels)
+        for i in range(nb):
+            for j in range(cfg.layers_per_block + 1):
+                x = B.resnet_block(P[f"up.{i}.resnets.{j}"], x, n, H, W, groups=g, eps=1e-6)
+            if i != nb - 1:
+                x, H, W = B.upsample(P[f"up.{i}.upsampler"], x, n, H, W)
+        hw = H * W
+        nrm = ops.groupnorm(x, P.norm_out.g, P.norm_out.b, frames=n, hw=hw, groups=g, eps=1e-6, silu=True)
+        out = ops.gemm(nrm.view(n * hw, -1), P.conv_out.w, P.conv_out.b, geom=ops.ConvGeom(n, H, W, 3, 3, 1, 1),
+                       out_f32=True)
+        return out, H, W
+
+    def decode(self, z):
+        """z: [n, 4, h, w] (any float dtype/device) -> SimpleNamespace(sample=[n, 3, 8h, 8w] fp32 on device)."""
+        n, c, h, w = z.shape
+        zt = ops.ncfhw_to_nhwc(z.to(self._device).float().unsqueeze(2), 8)
+        out, H, W = self.decode_tokens(zt, n, h, w)
+        img = ops.nhwc_to_ncfhw(out, n, self.cfg.out_channels, 1, H, W)[:, :, 0]
+        return SimpleNamespace(sample=img)
+
+    def decode_video(self, latents, chunk=8):
+        """VExpressPipeline.decode_latents (pipelines/v_express_pipeline.py:152-166) on device:
+        latents fp32 [1, 4, F, h, w] -> video fp32 [1, 3, F, 8h, 8w] in [0, 1]."""
+        b, c, F, h, w = latents.shape
+        lat = (latents.float() / self.cfg.scaling_factor)
+        frames = []
+        for f0 in range(0, F, chunk):
+            part = lat[:, :, f0:f0 + chunk]
+            n = part.shape[2] * b
+            zt = ops.ncfhw_to_nhwc(part.contiguous(), 8)
+            out, H, W = self.decode_tokens(zt, n, h, w)
+            frames.append(ops.vae_postprocess(out, n, self.cfg.out_channels, H, W))
+        video = torch.cat(frames)                                    # [(b F), 3, H, W]
+        return video.view(b, F, self.cfg.out_channels, video.shape[-2], video.shape[-1]).permute(0, 2, 1, 3, 4)

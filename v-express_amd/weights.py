@@ -1,0 +1,143 @@
+"""Weight ingestion: reference state_dict tensors -> device layouts the HIP kernels consume.
+
+The wire format stays the reference's (`state_dict` keys of modules/unet_3d.py, unet_2d_condition.py,
+diffusers AutoencoderKL — SURVEY.md Appendix C).  Re-layouts done once at load:
+  * conv weights [Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin] ((ky, kx, ci) K order, NHWC implicit GEMM), channel
+    padding to multiples of 8 for the 4-channel latent convs;
+  * attn1 / temporal to_q,to_k,to_v -> one fused [3C, C] matrix; cross-attention to_k,to_v -> [2C, ctx];
+  * GEGLU `ff.net.0.proj` [8C, C]: value rows and gate rows interleaved in blocks of 16 so that one MFMA
+    accumulator fragment pair holds (value, gate) of the same channels;
+  * every ResnetBlock3D.time_emb_proj concatenated into one [sum(Cout), 1280] matrix (one GEMM per timestep);
+  * weights -> bf16; biases, norm affine parameters and the motion-module sinusoid tables -> fp32.
+"""
+import torch
+
+BF16 = torch.bfloat16
+
+
+class Prepared(dict):
+    """prefix -> SimpleNamespace-like dict of device tensors."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def _dev(t, device, dtype):
+    return t.detach().to(device=device, dtype=dtype).contiguous()
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def prep_conv(sd, p, device, cin_pad=None, cout_pad=None):
+    w = sd[p + ".weight"].detach().to(device=device, dtype=torch.float32)
+    cout, cin, kh, kw = w.shape
+    cin_p = cin_pad or pad8(cin)
+    cout_p = cout_pad or pad8(cout)
+    wp = torch.zeros((cout_p, kh, kw, cin_p), device=device, dtype=torch.float32)
+    wp[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
+    b = torch.zeros(cout_p, device=device, dtype=torch.float32)
+    if (p + ".bias") in sd:
+        b[:cout] = sd[p + ".bias"].detach().to(device=device, dtype=torch.float32)
+    return Prepared(w=wp.reshape(cout_p, kh * kw * cin_p).to(BF16).contiguous(), b=b, k=kh, cout=cout)
+
+
+def prep_linear(sd, p, device):
+    w = _dev(sd[p + ".weight"], device, BF16)
+    if w.dim() == 4:     # 1x1 conv stored as [Cout, Cin, 1, 1]
+        w = w.reshape(w.shape[0], w.shape[1]).contiguous()
+    b = _dev(sd[p + ".bias"], device, torch.float32) if (p + ".bias") in sd else None
+    return Prepared(w=w, b=b)
+
+
+def prep_norm(sd, p, device):
+    return Prepared(g=_dev(sd[p + ".weight"], device, torch.float32), b=_dev(sd[p + ".bias"], device, torch.float32))
+
+
+def _cat_w(sd, keys, device):
+    return torch.cat([sd[k].detach().to(device=device, dtype=BF16) for k in keys], dim=0).contiguous()
+
+
+def _cat_b(sd, keys, device):
+    if keys[0] not in sd:
+        return None
+    return torch.cat([sd[k].detach().to(device=device, dtype=torch.float32) for k in keys], dim=0).contiguous()
+
+
+def prep_self_attn(sd, p, device):
+    """diffusers Attention used as self-attention: fused QKV + out projection."""
+    names = ["to_q", "to_k", "to_v"]
+    return Prepared(wqkv=_cat_w(sd, [f"{p}.{n}.weight" for n in names], device),
+                    bqkv=_cat_b(sd, [f"{p}.{n}.bias" for n in names], device),
+                    out=prep_linear(sd, p + ".to_out.0", device))
+
+
+def prep_cross_attn(sd, p, device):
+    """Attention whose K/V come from another sequence: Q alone, fused KV, out projection."""
+    return Prepared(wq=_dev(sd[p + ".to_q.weight"], device, BF16),
+                    wk=_dev(sd[p + ".to_k.weight"], device, BF16),
+                    wkv=_cat_w(sd, [p + ".to_k.weight", p + ".to_v.weight"], device),
+                    out=prep_linear(sd, p + ".to_out.0", device))
+
+
+def geglu_interleave(t):
+    """[8C, ...] (value rows then gate rows) -> blocks of 16 value rows followed by their 16 gate rows."""
+    half = t.shape[0] // 2
+    if half % 16:
+        raise ValueError(f"GEGLU inner width {half} is not a multiple of 16")
+    v = t[:half].reshape(half // 16, 16, *t.shape[1:])
+    g = t[half:].reshape(half // 16, 16, *t.shape[1:])
+    return torch.stack([v, g], dim=1).reshape(t.shape).contiguous()
+
+
+def prep_ff(sd, p, device):
+    w1 = sd[p + ".net.0.proj.weight"].detach().to(device=device, dtype=BF16)
+    b1 = sd[p + ".net.0.proj.bias"].detach().to(device=device, dtype=torch.float32)
+    return Prepared(w1=geglu_interleave(w1), b1=geglu_interleave(b1), out=prep_linear(sd, p + ".net.2", device))
+
+
+def prep_resnet(sd, p, device):
+    r = Prepared(norm1=prep_norm(sd, p + ".norm1", device), conv1=prep_conv(sd, p + ".conv1", device),
+                 norm2=prep_norm(sd, p + ".norm2", device), conv2=prep_conv(sd, p + ".conv2", device),
+                 shortcut=None)
+    if (p + ".conv_shortcut.weight") in sd:
+        r["shortcut"] = prep_linear(sd, p + ".conv_shortcut", device)
+    return r
+
+
+def prep_spatial_read(sd, p, device):
+    """Transformer3DModel + TemporalBasicTransformerBlock (attn1, attn1_5, attn2, ff)."""
+    t = p + ".transformer_blocks.0"
+    return Prepared(norm=prep_norm(sd, p + ".norm", device), proj_in=prep_linear(sd, p + ".proj_in", device),
+                    proj_out=prep_linear(sd, p + ".proj_out", device),
+                    norm1=prep_norm(sd, t + ".norm1", device), attn1=prep_self_attn(sd, t + ".attn1", device),
+                    norm1_5=prep_norm(sd, t + ".norm1_5", device), attn1_5=prep_cross_attn(sd, t + ".attn1_5", device),
+                    norm2=prep_norm(sd, t + ".norm2", device), attn2=prep_cross_attn(sd, t + ".attn2", device),
+                    norm3=prep_norm(sd, t + ".norm3", device), ff=prep_ff(sd, t + ".ff", device))
+
+
+def prep_spatial_write(sd, p, device):
+    """Transformer2DModel + BasicTransformerBlock of the ReferenceNet (attn1, attn2, ff)."""
+    t = p + ".transformer_blocks.0"
+    return Prepared(norm=prep_norm(sd, p + ".norm", device), proj_in=prep_linear(sd, p + ".proj_in", device),
+                    proj_out=prep_linear(sd, p + ".proj_out", device),
+                    norm1=prep_norm(sd, t + ".norm1", device), attn1=prep_self_attn(sd, t + ".attn1", device),
+                    norm2=prep_norm(sd, t + ".norm2", device), attn2=prep_cross_attn(sd, t + ".attn2", device),
+                    norm3=prep_norm(sd, t + ".norm3", device), ff=prep_ff(sd, t + ".ff", device))
+
+
+def prep_motion(sd, p, device):
+    t = p + ".temporal_transformer"
+    b = t + ".transformer_blocks.0"
+    attn = []
+    for i in range(2):
+        a = f"{b}.attention_blocks.{i}"
+        attn.append(Prepared(attn=prep_self_attn(sd, a, device), norm=prep_norm(sd, f"{b}.norms.{i}", device),
+                             pe=_dev(sd[a + ".pos_encoder.pe"][0], device, torch.float32)))
+    return Prepared(norm=prep_norm(sd, t + ".norm", device), proj_in=prep_linear(sd, t + ".proj_in", device),
+                    proj_out=prep_linear(sd, t + ".proj_out", device), attn=attn,
+                    ff_norm=prep_norm(sd, b + ".ff_norm", device), ff=prep_ff(sd, b + ".ff", device))
