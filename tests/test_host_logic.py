@@ -1,0 +1,164 @@
+"""CPU tests of the host-side logic: C-ABI loading, weight re-layouts, window plan, scheduler, unit sharding."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loop as OL
+from v_express_amd import context, distributed, synth, weights
+from v_express_amd.scheduler import DDIMScheduler
+
+SCHED_KW = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, steps_offset=1,
+                prediction_type="v_prediction", rescale_betas_zero_snr=True, timestep_spacing="trailing")
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    from v_express_amd import lib
+    names = lib.declared_symbols()
+    assert len(names) >= 17 and "vx_gemm" in names and "vx_attention" in names
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for n in names:
+        assert hasattr(so, n), n
+    assert lib.lib.vx_abi_version() == 1
+    assert ctypes.sizeof(lib.GemmParams) % 8 == 0
+    # argument validation happens before any launch, so it works without a GPU and never aborts the process
+    p = lib.GemmParams()
+    rc = lib.lib.vx_gemm(ctypes.byref(p), None)
+    assert rc < 0 and b"vx_gemm" in lib.lib.vx_last_error_string()
+    with pytest.raises(lib.VxError):
+        lib.check(rc, "vx_gemm")
+
+
+def test_gemm_params_struct_matches_header_layout():
+    """Compile a 3-line C probe against include/vexpress_hip.h and compare sizeof/offsets with the ctypes mirror."""
+    import subprocess
+    import tempfile
+    from v_express_amd import lib
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "vexpress_hip.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(vx_gemm_params), offsetof(vx_gemm_params, w),
+  offsetof(vx_gemm_params, alpha), offsetof(vx_gemm_params, residual), offsetof(vx_gemm_params, part_out),
+  offsetof(vx_gemm_params, vt_pitch)); return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "p.c"), "w").write(src)
+        inc = os.path.join(os.path.dirname(lib.HEADER))
+        subprocess.check_call(["gcc", "-I", inc, os.path.join(d, "p.c"), "-o", os.path.join(d, "p")])
+        got = list(map(int, subprocess.check_output([os.path.join(d, "p")]).split()))
+    G = lib.GemmParams
+    assert got == [ctypes.sizeof(G), G.w.offset, G.alpha.offset, G.residual.offset, G.part_out.offset,
+                   G.vt_pitch.offset]
+
+
+def test_windows_and_alignment_match_reference_context_py():
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "windows.pt"), weights_only=False)
+    for (F, cs, co), ref in gold.items():
+        got = list(context.uniform(step=0, num_frames=F, context_size=cs, context_stride=1, context_overlap=co,
+                                   closed_loop=False))
+        assert got == [list(map(int, r)) for r in ref]
+    assert context.aligned_video_length(128, 16, 4) == 124      # inference.py:255-264
+    assert context.aligned_video_length(930, 24, 4) == 924
+
+
+@pytest.mark.parametrize("F,cs,co", [(16, 16, 4), (64, 16, 4), (124, 16, 4), (128, 16, 4), (11, 4, 2), (100, 24, 4)])
+def test_overlap_plan_replays_reference_bookkeeping(F, cs, co):
+    """Plan -> (sum of terms / count, DDIM) must equal the oracle's replay of v_express_pipeline.py:552-572,
+    including the duplicated frame of a reflected last window (last write wins)."""
+    windows = OL.uniform_windows(F, cs, co)
+    plan = context.overlap_plan(windows, F)
+    f = len(windows[0])
+    g = torch.Generator().manual_seed(F)
+    lat = torch.randn(1, 4, F, 2, 2, generator=g)
+    outs = [torch.randn(2, 4, f, 2, 2, generator=g) for _ in windows]
+    it = iter(outs)
+    ddim = OL.DDIM()
+    ddim.set_timesteps(25)
+    ref = OL.mean_overlap(lambda x, t, e, k: next(it), lat, [479], ddim, windows, 3.5,
+                          torch.zeros(2, 1, F, 2, 2), torch.zeros(2, F, 1, 8))
+    s = DDIMScheduler(**SCHED_KW)
+    s.set_timesteps(25)
+    sa, s1a, sap, s1ap = s.step_coefficients(479)
+    preds = [o[0:1] + 3.5 * (o[1:2] - o[0:1]) for o in outs]
+    got = lat.clone()
+    for fr in plan["step_frames"]:
+        v = None
+        for (wi, li) in plan["terms"][fr]:
+            term = preds[wi][:, :, li] / float(plan["counts"][fr])
+            v = term if v is None else v + term
+        x = lat[:, :, fr]
+        x0 = sa * x - s1a * v
+        eps = sa * v + s1a * x
+        got[:, :, fr] = sap * x0 + s1ap * eps
+    assert torch.allclose(got, ref, atol=1e-6, rtol=1e-6)
+
+
+def test_scheduler_matches_oracle_and_golden():
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "ddim.pt"), weights_only=False)
+    s = DDIMScheduler(**SCHED_KW)
+    s.set_timesteps(25)
+    assert s.timesteps.tolist() == g["timesteps"].tolist()
+    assert torch.allclose(s.alphas_cumprod, g["alphas_cumprod"], atol=1e-7)
+    d = OL.DDIM()
+    d.set_timesteps(25)
+    x, v = torch.randn(1, 4, 3, 8, 8), torch.randn(1, 4, 3, 8, 8)
+    for t in (999, 519, 39):
+        assert torch.allclose(s.step(v, t, x).prev_sample, d.step(v, t, x), atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        s.step(v, 999, x, eta=0.5)
+
+
+def test_weight_relayouts():
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(64, 16, generator=g)
+    wi = weights.geglu_interleave(w)
+    assert torch.equal(wi[0:16], w[0:16]) and torch.equal(wi[16:32], w[32:48]) and torch.equal(wi[32:48], w[16:32])
+    sd = {"c.weight": torch.randn(6, 4, 3, 3, generator=g), "c.bias": torch.randn(6, generator=g)}
+    pc = weights.prep_conv(sd, "c", "cpu")
+    assert pc.w.shape == (8, 3 * 3 * 8) and pc.b.shape == (8,) and pc.cout == 6
+    w4 = pc.w.float().view(8, 3, 3, 8)
+    assert torch.allclose(w4[:6, :, :, :4], sd["c.weight"].permute(0, 2, 3, 1).to(torch.bfloat16).float())
+    assert (w4[6:] == 0).all() and (w4[..., 4:] == 0).all() and (pc.b[6:] == 0).all()
+    cfg = synth.UNetConfig(block_out_channels=(64, 128, 256, 256))
+    sd3 = synth.unet3d_state_dict(cfg)
+    a = weights.prep_self_attn(sd3, "down_blocks.0.attentions.0.transformer_blocks.0.attn1", "cpu")
+    assert a.wqkv.shape == (192, 64) and a.bqkv is None and a.out.b.dtype == torch.float32
+    m = weights.prep_motion(sd3, "mid_block.motion_modules.0", "cpu")
+    assert m.attn[0].pe.shape == (32, 256) and torch.allclose(m.attn[1].pe, synth.pe_table(32, 256)[0])
+
+
+def test_model_surface_and_errors_without_gpu():
+    import v_express_amd as vx
+    cfgd = dict(block_out_channels=[64, 128, 256, 256], attention_head_dim=8, cross_attention_dim=768)
+    unet = vx.UNet3DConditionModel.from_config_2d(cfgd, dict(use_motion_module=True, motion_module_kwargs=dict(
+        temporal_position_encoding_max_len=32)))
+    assert unet.config.cross_attention_dim == 768 and unet.in_channels == 4
+    sd = synth.unet3d_state_dict(unet.cfg)
+    r = unet.load_state_dict({k: v for k, v in sd.items() if "motion_modules" not in k}, strict=False)
+    assert r.missing_keys and all("motion_modules" in k for k in r.missing_keys)
+    r = unet.load_state_dict({k: v for k, v in sd.items() if "motion_modules" in k}, strict=False)   # inference.py:90-93
+    with pytest.raises(RuntimeError):
+        unet.load_state_dict({"nope": torch.zeros(1)}, strict=True)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        unet._prepared()                                   # still on the CPU: there is no CPU path
+    with pytest.raises(NotImplementedError):
+        vx.UNet3DConditionModel.from_config_2d(cfgd, dict(use_motion_module=False))
+
+
+def test_unit_partition_properties():
+    for W in (1, 2, 5, 10, 11):
+        for R in (1, 2, 4, 8):
+            parts = distributed.partition_units(W, R)
+            flat = [u for p in parts for u in p]
+            assert flat == [(w, h) for w in range(W) for h in range(2)]
+            sizes = [len(p) for p in parts]
+            assert max(sizes) - min(sizes) <= 1
+            sch = distributed.UnitSchedule(W, R)
+            assert sch.rounds() == -(-2 * W // R)
+            for r in range(R):
+                for w, halves in sch.calls(r):
+                    assert halves in ([0], [1], [0, 1])
+    assert distributed.UnitSchedule(10, 8).rounds() == 3          # 124 frames on 8 GPUs: 20 units -> 3 rounds
+    assert distributed.split_frames(124, 8)[0] == (0, 16) and distributed.split_frames(124, 8)[-1] == (112, 124)

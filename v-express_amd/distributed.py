@@ -41,6 +41,26 @@ def group_calls(units: List[Tuple[int, int]]) -> List[Tuple[int, List[int]]]:
     return calls
 
 
+class UnitSchedule:
+    """Static (window, cfg_half) -> (rank, slot) map of one clip; identical on every rank."""
+
+    def __init__(self, num_windows: int, world_size: int):
+        self.num_windows, self.world_size = num_windows, world_size
+        self.assign = partition_units(num_windows, world_size)
+        self.max_units = max(len(a) for a in self.assign)
+        self.slot = {}
+        for r, units in enumerate(self.assign):
+            for s, u in enumerate(units):
+                self.slot[u] = (r, s)
+
+    def calls(self, rank: int):
+        return group_calls(self.assign[rank])
+
+    def rounds(self) -> int:
+        """Half-window UNet passes on the critical path of one timestep (ideal speed-up = 2W / rounds)."""
+        return self.max_units
+
+
 @dataclass
 class DistContext:
     rank: int = 0

@@ -24,7 +24,7 @@ import torch
 
 from . import ops
 from .context import get_context_scheduler, overlap_plan
-from .distributed import DistContext, group_calls, partition_units, split_frames
+from .distributed import DistContext, UnitSchedule, split_frames
 from .mutual_self_attention import ReferenceAttentionControl
 
 
@@ -137,13 +137,8 @@ class VExpressPipeline:
         frame_ids = torch.tensor(sf, dtype=torch.int32, device=dev)
         counts = torch.tensor([float(plan["counts"][fr]) for fr in sf], dtype=torch.float32, device=dev)
         # work units of this rank
-        assign = partition_units(nW, dc.world_size)
-        my_calls = group_calls(assign[dc.rank])
-        max_units = max(len(a) for a in assign)
-        unit_slot = {}
-        for r, units in enumerate(assign):
-            for s, u in enumerate(units):
-                unit_slot[u] = (r, s)
+        sched_u = UnitSchedule(nW, dc.world_size)
+        my_calls, max_units, unit_slot = sched_u.calls(dc.rank), sched_u.max_units, sched_u.slot
         n_out = 8
         local = torch.zeros((max_units, f * hw, n_out), device=dev, dtype=torch.float32)
         preds = torch.empty((nW, C, f, hw), device=dev, dtype=torch.float32)
