@@ -1,0 +1,11 @@
+#!/bin/bash
+# rocprofv3 kernel trace + stats of one bench run; summaries are copied to gpurun_out/prof_* for profiles/.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+TAG=${1:-r01}
+rm -rf /tmp/prof && mkdir -p /tmp/prof
+timeout 1200 rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/prof_${TAG}_bench.log 2> gpurun_out/prof_${TAG}_bench.err
+find /tmp/prof -name "*stats*" | head > gpurun_out/prof_${TAG}_files.log
+for f in $(find /tmp/prof -name "*kernel_stats.csv"); do cp "$f" gpurun_out/prof_${TAG}_kernel_stats.csv; done
+ls -la /tmp/prof/* >> gpurun_out/prof_${TAG}_files.log 2>&1

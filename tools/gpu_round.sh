@@ -7,9 +7,9 @@ export TMPDIR=/tmp
 OUT=gpurun_out
 { rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -8; nproc; free -g | head -2; } > $OUT/box.log 2>&1
 make -C v-express_amd/csrc -j 2>&1 | tail -3 > $OUT/build.log
-GROUPS="test_gemm_plain test_gemm_epilogue_options test_conv test_geglu test_gemm_split_qkv_vt test_groupnorm test_layernorm test_flash_attention test_temporal_attention test_small_kv_attention test_add_row_bias test_layout_and_loop_kernels test_errors_are_reported_not_fatal"
+TEST_GROUPS="test_gemm_plain test_gemm_epilogue_options test_conv test_geglu test_gemm_split_qkv_vt test_groupnorm test_layernorm test_flash_attention test_temporal_attention test_small_kv_attention test_add_row_bias test_layout_and_loop_kernels test_errors_are_reported_not_fatal"
 : > $OUT/kernels.log
-for g in $GROUPS; do
+for g in $TEST_GROUPS; do
   echo "=== $g" >> $OUT/kernels.log
   timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=short -p no:cacheprovider -k "$g" 2>&1 | tail -40 >> $OUT/kernels.log
 done
