@@ -1,0 +1,20 @@
+"""Summarise a rocprofv3 kernel_trace.csv: per-kernel count / total / avg, with template args kept short."""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+rows = defaultdict(lambda: [0, 0.0])
+with open(sys.argv[1]) as f:
+    r = csv.DictReader(f)
+    for row in r:
+        name = row.get("Kernel_Name") or row.get("kernel_name")
+        s, e = int(row["Start_Timestamp"]), int(row["End_Timestamp"])
+        name = re.sub(r"\(anonymous namespace\)::", "", name)
+        name = name[:110]
+        rows[name][0] += 1
+        rows[name][1] += (e - s) * 1e-3
+tot = sum(v[1] for v in rows.values())
+print(f"total kernel time {tot/1e3:.1f} ms over {sum(v[0] for v in rows.values())} launches")
+for k, v in sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]:
+    print(f"{v[1]/1e3:10.2f} ms {100*v[1]/tot:5.1f}% n={v[0]:6d} avg={v[1]/v[0]:9.1f} us  {k}")
