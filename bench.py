@@ -18,8 +18,9 @@ Extra objects in the JSON line:
                 vx_gemm launch (2*M*N*K) / its HIP-event duration, measured on ONE extra instrumented DDIM step after
                 the timed region (events on the launch stream); `whole_path` = fps * algorithmic FLOP per frame
                 (66.4 TFLOP/frame at F=16) / peak.
-  cpu_baseline  the fp32 oracle (port of the reference path) on the host cores: one CFG UNet3D forward at 512^2 with a
-                4-frame window + one frame of VAE decode, extrapolated linearly (x4 frames, x25 steps, x16 frames).
+  cpu_baseline  the fp32 oracle (port of the reference path) on the host cores (thread count picked by a 1-second probe):
+                one CFG UNet3D forward at 512^2 with a 2-frame window + one frame of VAE decode (a bounded ~10-30 s
+                sample), extrapolated linearly (x8 windows-worth of frames, x25 steps, x16 frames of decode).
 """
 import argparse
 import json
@@ -43,16 +44,37 @@ def flop_per_frame(num_frames, windows, steps, scale):
     return (unet + VAE_TFLOP_PER_FRAME) * scale
 
 
+def _pick_threads():
+    """Thread count for the CPU leg: the fastest of a few candidates on a 1-second conv probe (a 256-thread box
+    runs the fp32 oracle several times SLOWER with all hardware threads than with one thread per few cores)."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cands = sorted({c for c in (8, 16, 32, 64, 128, avail) if c <= avail} or {avail})
+    x = torch.randn(2, 320, 64, 64)
+    wt = torch.randn(320, 320, 3, 3)
+    best, best_t = cands[0], float("inf")
+    for c in cands:
+        torch.set_num_threads(c)
+        torch.nn.functional.conv2d(x, wt, padding=1)
+        t0 = time.time()
+        for _ in range(3):
+            torch.nn.functional.conv2d(x, wt, padding=1)
+        dt = time.time() - t0
+        if dt < best_t:
+            best, best_t = c, dt
+    return best
+
+
 def cpu_baseline(size, seconds_budget):
     """Port (`oracle/`) of the reference path timed on the host cores, bounded sample."""
     import oracle
     from oracle import unet as OU
     from oracle import vae as OV
     from v_express_amd import synth
-    torch.set_num_threads(os.cpu_count())
+    threads = _pick_threads()
+    torch.set_num_threads(threads)
     cfg, ocfg = synth.UNetConfig(), oracle.UNetConfig()
     h = w = size // 8
-    f = 4
+    f = 2
     t0 = time.time()
     sd3 = synth.unet3d_state_dict(cfg)
     inp = synth.synthetic_inputs(cfg, f, h, w)
@@ -90,7 +112,7 @@ def cpu_baseline(size, seconds_budget):
         OV.vae_decode(sdv, oracle.VaeConfig(), z)
         vae_s = time.time() - t0
     clip_s = unet_s * (16 / f) * 25 + vae_s * 16
-    return dict(value=16.0 / clip_s, unit="frames/s", cores=os.cpu_count(), kind="port",
+    return dict(value=16.0 / clip_s, unit="frames/s", cores=threads, host_cpus=os.cpu_count(), kind="port",
                 sample=(f"oracle fp32: 1 CFG UNet3D forward {size}x{size} f={f} ({unet_s:.1f} s) + 1 frame VAE decode "
                         f"({vae_s:.1f} s) on {torch.get_num_threads()} threads; extrapolated x(16/{f}) frames x25 "
                         f"steps + x16 frames = {clip_s:.0f} s per 16-frame clip"),

@@ -28,6 +28,25 @@ __device__ __forceinline__ T sel3(int i, T a, T b, T c) { return i == 0 ? a : (i
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// 16 zero bytes: the source of every out-of-range chunk (conv padding, M/N/K tails), so the staging loads are
+// branch-free and can all be in flight at once
+__device__ __attribute__((aligned(16))) const uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// async 16-B global -> LDS copy (global_load_lds_dwordx4): LDS address = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// XCD-aware block remap (8 XCDs, blocks are dealt round-robin): logical ids that are adjacent run on the same
+// XCD, so the column tiles of one A row-tile share that XCD's L2.  Bijective for any block count.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const vx_gemm_params p) {
   constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
@@ -42,19 +61,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const vx_gemm_params 
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   const int n_tiles = (p.n + BN - 1) / BN;
-  const int tile_m = blockIdx.x / n_tiles, tile_n = blockIdx.x % n_tiles;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lid / n_tiles, tile_n = lid - tile_m * n_tiles;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const bf16_t* __restrict__ A1 = (const bf16_t*)p.a;
   const bf16_t* __restrict__ A2 = (const bf16_t*)p.a2;
   const bf16_t* __restrict__ Wt = (const bf16_t*)p.w;
   const int cin = p.c1 + p.c2;
-  const int h_eff = p.h_in << p.upsample, w_eff = p.w_in << p.upsample;
+  const int c1 = p.c1;
+  const int up = p.upsample;
+  const int h_eff = p.h_in << up, w_eff = p.w_in << up;
   const int hw_out = p.h_out * p.w_out;
+  const int w_in = p.w_in, kw = p.kw, kh = p.kh;
+  const int lda1 = p.lda1, lda2 = p.lda2;
+  const bf16_t* const zsrc = reinterpret_cast<const bf16_t*>(&g_zero16);
 
-  // ---- per-thread staging coordinates
-  const int cc = tid & 7;    // 16-B chunk within the K-tile row
-  const int r0 = tid >> 3;   // first row; rows r0 + 32*i
+  // ---- per-thread staging coordinates: LDS slot `s` of row r0 + 32*i holds K-chunk s ^ ((row >> 1) & 7)
+  const int r0 = tid >> 3;
+  const int cc = (tid & 7) ^ ((r0 >> 1) & 7);   // K-chunk (8 elements) this thread fetches
   RowInfo ri[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
@@ -73,51 +98,51 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const vx_gemm_params 
       ri[i].ix0 = -(1 << 28);
     }
   }
-
-  uint4 ra[A_IT], rb[B_IT];
-  auto load_tile = [&](int kt) {
-    const int kg = kt * BK + cc * 8;
-    const bool kval = kg < p.k;
+  long wrow[B_IT];   // element offset of weight row n (or -1: beyond N)
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    int n = n0 + r0 + 32 * i;
+    wrow[i] = n < p.n ? (long)n * p.k : -1;
+  }
+  // K position of this thread's chunk, tracked incrementally: (ky, kx, ci) with k = ((ky*kw)+kx)*cin + ci
+  int kg = cc * 8;
+  int ky, kx, ci;
+  {
     int tap = kg / cin;
-    int ci = kg - tap * cin;
-    int ky = tap / p.kw;
-    int kx = tap - ky * p.kw;
-    const bf16_t* src;
-    int cstride;
-    if (ci < p.c1) {
-      src = A1 + ci;
-      cstride = p.lda1;
-    } else {
-      src = A2 + (ci - p.c1);
-      cstride = p.lda2;
-    }
+    ci = kg - tap * cin;
+    ky = tap / kw;
+    kx = tap - ky * kw;
+  }
+  char* const lds_wave = smem + (wave * 8) * 128;   // this wave's 8-row (1 KiB) slab within each 32-row group
+
+  auto issue_tile = [&](int stage) {
+    char* sa = lds_wave + stage * STAGE_BYTES;
+    char* sb = sa + BM * 128;
+    const bool kval = ky < kh;
+    const bool first = ci < c1;
+    const bf16_t* src = first ? A1 + ci : A2 + (ci - c1);
+    const int cs = first ? lda1 : lda2;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       int iy = ri[i].iy0 + ky, ix = ri[i].ix0 + kx;
       bool ok = kval && (unsigned)iy < (unsigned)h_eff && (unsigned)ix < (unsigned)w_eff;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        int sy = iy >> p.upsample, sx = ix >> p.upsample;
-        size_t off = (size_t)(ri[i].pix_base + sy * p.w_in + sx) * (size_t)cstride;
-        v = *reinterpret_cast<const uint4*>(src + off);
-      }
-      ra[i] = v;
+      int pix = ri[i].pix_base + (iy >> up) * w_in + (ix >> up);
+      const bf16_t* g = ok ? src + (long)pix * (long)cs : zsrc;
+      glds16(g, sa + i * 32 * 128);
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      int n = n0 + r0 + 32 * i;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kval && n < p.n) v = *reinterpret_cast<const uint4*>(Wt + (size_t)n * p.k + kg);
-      rb[i] = v;
+      bool ok = kval && wrow[i] >= 0;
+      const bf16_t* g = ok ? Wt + wrow[i] + kg : zsrc;
+      glds16(g, sb + i * 32 * 128);
     }
-  };
-  auto store_tile = [&](int stage) {
-    char* sa = smem + stage * STAGE_BYTES;
-    char* sb = sa + BM * 128;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<uint4*>(sa + lds_off(r0 + 32 * i, cc)) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<uint4*>(sb + lds_off(r0 + 32 * i, cc)) = rb[i];
+    // advance to the next K-tile
+    kg += BK;
+    ci += BK;
+    while (ci >= cin) {
+      ci -= cin;
+      if (++kx == kw) { kx = 0; ++ky; }
+    }
   };
 
   f32x4_t acc[MI][NI];
@@ -127,14 +152,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const vx_gemm_params 
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.k + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+  issue_tile(0);
 
   const int frow = lane & 15, fgrp = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int stage = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+    // tile kt has landed (own DMAs drained, then the barrier covers everyone's); the barrier also orders the
+    // other stage's last reads (iteration kt-1) before it is refilled below
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) issue_tile(stage ^ 1);
     const char* sa = smem + stage * STAGE_BYTES;
     const char* sb = sa + BM * 128;
 #pragma unroll
@@ -151,9 +178,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const vx_gemm_params 
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(af[i], bfr[j], acc[i][j]);
     }
-    if (kt + 1 < nk) store_tile(stage ^ 1);
-    __syncthreads();
   }
+  __syncthreads();   // all fragment reads done before the epilogue reuses the stages
 
   // ------------------------------------------------------------------ epilogue (fp32 tile through LDS, 64-row slabs)
   constexpr int OUTW = (EPI == VX_EPI_GEGLU) ? BN / 2 : BN;   // staged tile width

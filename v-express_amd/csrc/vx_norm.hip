@@ -22,9 +22,48 @@ namespace {
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAX_SETS = 2;   // chunks per thread per pixel -> C <= 8*256*2 = 4096
 
-__device__ __forceinline__ const bf16_t* gn_src(const bf16_t* x1, int c1, const bf16_t* x2, int c2, size_t pix,
-                                                int ch) {
-  return ch < c1 ? x1 + pix * (size_t)c1 + ch : x2 + pix * (size_t)c2 + (ch - c1);
+// Per-thread plan shared by both kernels: thread -> (pixel lane pl, fixed 16-B channel chunks cc + u*GN_THREADS).
+// For every owned chunk the source pointer (x1 or x2 of the concat) and its pixel stride are resolved once, so the
+// pixel loops contain no division and no source select, and are unrolled GN_UNROLL deep to keep that many 16-B
+// loads per thread in flight.
+constexpr int GN_UNROLL = 4;
+constexpr int GN_SUBS = 8;      // parallel sub-sums of the per-slice partials in gn_apply
+
+struct GnPlan {
+  const bf16_t* base[GN_MAX_SETS];   // first pixel of the frame, at this thread's chunk (nullptr: no chunk)
+  int pstride[GN_MAX_SETS];          // elements between consecutive pixels
+  int chunk[GN_MAX_SETS];
+  int pl, pl_count;
+};
+
+__device__ __forceinline__ GnPlan gn_plan(const bf16_t* x1, int c1, const bf16_t* x2, int c2, int hw, int frame) {
+  GnPlan P;
+  const int nchunks = (c1 + c2) >> 3;
+  const int tid = threadIdx.x;
+  const int tp = nchunks < GN_THREADS ? nchunks : GN_THREADS;
+  P.pl_count = GN_THREADS / tp;
+  const int cc = tid % tp;
+  P.pl = tid / tp;
+  const bool active = P.pl < P.pl_count;
+#pragma unroll
+  for (int u = 0; u < GN_MAX_SETS; ++u) {
+    const int chunk = cc + u * GN_THREADS;
+    P.chunk[u] = chunk;
+    const int ch = chunk * 8;
+    if (active && chunk < nchunks) {
+      if (ch < c1) {
+        P.base[u] = x1 + (size_t)frame * hw * c1 + ch;
+        P.pstride[u] = c1;
+      } else {
+        P.base[u] = x2 + (size_t)frame * hw * c2 + (ch - c1);
+        P.pstride[u] = c2;
+      }
+    } else {
+      P.base[u] = nullptr;
+      P.pstride[u] = 0;
+    }
+  }
+  return P;
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __restrict__ x1, int c1,
@@ -33,13 +72,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
                                                               float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int C = c1 + c2;
-  const int nchunks = C >> 3;
   const int frame = blockIdx.x / slices, slice = blockIdx.x % slices;
   const int tid = threadIdx.x;
-  const int tp = nchunks < GN_THREADS ? nchunks : GN_THREADS;   // threads per pixel
-  const int pl_count = GN_THREADS / tp;                         // pixel lanes
-  const int cc = tid % tp, pl = tid / tp;
-  const bool active = pl < pl_count;
+  const GnPlan P = gn_plan(x1, c1, x2, c2, hw, frame);
   const int p_begin = slice * slice_pix;
   const int p_end = min(hw, p_begin + slice_pix);
 
@@ -49,44 +84,55 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[u][e] = q[u][e] = 0.f;
 
-  if (active) {
-    for (int px = p_begin + pl; px < p_end; px += pl_count) {
-      size_t pix = (size_t)frame * hw + px;
 #pragma unroll
-      for (int u = 0; u < GN_MAX_SETS; ++u) {
-        int chunk = cc + u * GN_THREADS;
-        if (chunk < nchunks) {
-          float f[8];
-          unpack_bf16x8(*reinterpret_cast<const uint4*>(gn_src(x1, c1, x2, c2, pix, chunk * 8)), f);
+  for (int u = 0; u < GN_MAX_SETS; ++u) {
+    if (P.base[u] == nullptr) continue;
+    const bf16_t* src = P.base[u];
+    const int ps = P.pstride[u];
+    int px = p_begin + P.pl;
+    // fixed summation order per thread: pixels ascending (the unrolled body adds in the same order)
+    for (; px + (GN_UNROLL - 1) * P.pl_count < p_end; px += GN_UNROLL * P.pl_count) {
+      uint4 raw[GN_UNROLL];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            s[u][e] += f[e];
-            q[u][e] += f[e] * f[e];
-          }
+      for (int k = 0; k < GN_UNROLL; ++k)
+        raw[k] = *reinterpret_cast<const uint4*>(src + (size_t)(px + k * P.pl_count) * ps);
+#pragma unroll
+      for (int k = 0; k < GN_UNROLL; ++k) {
+        float f[8];
+        unpack_bf16x8(raw[k], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s[u][e] += f[e];
+          q[u][e] += f[e] * f[e];
         }
+      }
+    }
+    for (; px < p_end; px += P.pl_count) {
+      float f[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(src + (size_t)px * ps), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s[u][e] += f[e];
+        q[u][e] += f[e] * f[e];
       }
     }
   }
   // per-channel partials: [pl_count][C][2]
   float* part = reinterpret_cast<float*>(smem);
-  if (active) {
 #pragma unroll
-    for (int u = 0; u < GN_MAX_SETS; ++u) {
-      int chunk = cc + u * GN_THREADS;
-      if (chunk < nchunks) {
+  for (int u = 0; u < GN_MAX_SETS; ++u) {
+    if (P.base[u] == nullptr) continue;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          part[((size_t)pl * C + chunk * 8 + e) * 2 + 0] = s[u][e];
-          part[((size_t)pl * C + chunk * 8 + e) * 2 + 1] = q[u][e];
-        }
-      }
+    for (int e = 0; e < 8; ++e) {
+      part[((size_t)P.pl * C + P.chunk[u] * 8 + e) * 2 + 0] = s[u][e];
+      part[((size_t)P.pl * C + P.chunk[u] * 8 + e) * 2 + 1] = q[u][e];
     }
   }
   __syncthreads();
   // channel totals (fixed order over pixel lanes), written back into lane 0's slot
   for (int ch = tid; ch < C; ch += GN_THREADS) {
     float a = 0.f, b = 0.f;
-    for (int l = 0; l < pl_count; ++l) {
+    for (int l = 0; l < P.pl_count; ++l) {
       a += part[((size_t)l * C + ch) * 2 + 0];
       b += part[((size_t)l * C + ch) * 2 + 1];
     }
@@ -115,19 +161,32 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
                                                               const float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int C = c1 + c2;
-  const int nchunks = C >> 3;
   const int frame = blockIdx.x / slices, slice = blockIdx.x % slices;
   const int tid = threadIdx.x;
   float* scale = reinterpret_cast<float*>(smem);   // [C]
   float* shift = scale + C;                        // [C]
   float* gstat = shift + C;                        // [groups][2] mean, rstd
+  double* dpart = reinterpret_cast<double*>(gstat + 2 * groups);   // [GN_SUBS][groups][2]
   const int cg = C / groups;
+  // re-reduce the frame's `slices` partials in fp64, all threads helping: sub-sum `sub` takes slices sub, sub+8, ...
+  // (ascending), then the GN_SUBS sub-sums are added in fixed order -> same bits in every block of the frame
+  for (int idx = tid; idx < groups * GN_SUBS; idx += GN_THREADS) {
+    const int g = idx % groups, sub = idx / groups;
+    double a = 0.0, b = 0.0;
+    for (int sl = sub; sl < slices; sl += GN_SUBS) {
+      const float2 o = *reinterpret_cast<const float2*>(ws + (((size_t)frame * slices + sl) * groups + g) * 2);
+      a += (double)o.x;
+      b += (double)o.y;
+    }
+    dpart[(sub * groups + g) * 2 + 0] = a;
+    dpart[(sub * groups + g) * 2 + 1] = b;
+  }
+  __syncthreads();
   for (int g = tid; g < groups; g += GN_THREADS) {
     double a = 0.0, b = 0.0;
-    for (int sl = 0; sl < slices; ++sl) {
-      const float* o = ws + (((size_t)frame * slices + sl) * groups + g) * 2;
-      a += (double)o[0];
-      b += (double)o[1];
+    for (int sub = 0; sub < GN_SUBS; ++sub) {
+      a += dpart[(sub * groups + g) * 2 + 0];
+      b += dpart[(sub * groups + g) * 2 + 1];
     }
     double cnt = (double)cg * (double)hw;
     double mean = a / cnt;
@@ -144,30 +203,52 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
     shift[ch] = beta[ch] - gstat[g * 2 + 0] * sc;
   }
   __syncthreads();
+  const GnPlan P = gn_plan(x1, c1, x2, c2, hw, frame);
   const int p_begin = slice * slice_pix;
   const int p_end = min(hw, p_begin + slice_pix);
-  const long total = (long)(p_end - p_begin) * nchunks;
-  for (long idx = tid; idx < total; idx += GN_THREADS) {
-    int px = p_begin + (int)(idx / nchunks);
-    int chunk = (int)(idx % nchunks);
-    size_t pix = (size_t)frame * hw + px;
-    float f[8];
-    unpack_bf16x8(*reinterpret_cast<const uint4*>(gn_src(x1, c1, x2, c2, pix, chunk * 8)), f);
-    const float4 s0 = *reinterpret_cast<const float4*>(scale + chunk * 8);
-    const float4 s1 = *reinterpret_cast<const float4*>(scale + chunk * 8 + 4);
-    const float4 h0 = *reinterpret_cast<const float4*>(shift + chunk * 8);
-    const float4 h1 = *reinterpret_cast<const float4*>(shift + chunk * 8 + 4);
-    f[0] = f[0] * s0.x + h0.x; f[1] = f[1] * s0.y + h0.y; f[2] = f[2] * s0.z + h0.z; f[3] = f[3] * s0.w + h0.w;
-    f[4] = f[4] * s1.x + h1.x; f[5] = f[5] * s1.y + h1.y; f[6] = f[6] * s1.z + h1.z; f[7] = f[7] * s1.w + h1.w;
-    if (silu) {
+  bf16_t* const oframe = out + (size_t)frame * hw * C;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+  for (int u = 0; u < GN_MAX_SETS; ++u) {
+    if (P.base[u] == nullptr) continue;
+    const bf16_t* src = P.base[u];
+    const int ps = P.pstride[u];
+    const int ch = P.chunk[u] * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = scale[ch + e];
+      sh[e] = shift[ch + e];
     }
-    *reinterpret_cast<uint4*>(out + pix * (size_t)C + chunk * 8) = pack_bf16x8(f);
+    auto emit = [&](const uint4& raw, int px) {
+      float f[8];
+      unpack_bf16x8(raw, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = f[e] * sc[e] + sh[e];
+      if (silu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+      }
+      *reinterpret_cast<uint4*>(oframe + (size_t)px * C + ch) = pack_bf16x8(f);
+    };
+    int px = p_begin + P.pl;
+    for (; px + (GN_UNROLL - 1) * P.pl_count < p_end; px += GN_UNROLL * P.pl_count) {
+      uint4 raw[GN_UNROLL];
+#pragma unroll
+      for (int k = 0; k < GN_UNROLL; ++k)
+        raw[k] = *reinterpret_cast<const uint4*>(src + (size_t)(px + k * P.pl_count) * ps);
+#pragma unroll
+      for (int k = 0; k < GN_UNROLL; ++k) emit(raw[k], px + k * P.pl_count);
+    }
+    for (; px < p_end; px += P.pl_count) emit(*reinterpret_cast<const uint4*>(src + (size_t)px * ps), px);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------- LayerNorm
+// One wave per row, LN_R rows per pass: the 16-B loads of all LN_R rows are issued before the first reduction, and a
+// wave keeps walking rows (grid-stride) with its gamma/beta chunks resident in registers, so the kernel is bound by
+// HBM rather than by one-load-per-wave latency.
+constexpr int LN_R = 4;
+
 template <int MAXC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, int ldx, int rows, int c,
                                                         float eps, const float* __restrict__ gamma,
@@ -175,56 +256,99 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
                                                         const float* __restrict__ add, int add_rows_per_entry,
                                                         int add_entries, bf16_t* __restrict__ out, int ldo) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
   const int nchunks = c >> 3;
-  float v[MAXC][8];
-  float sum = 0.f;
+  const float inv_c = 1.0f / (float)c;
+  bool live[MAXC];
+  float g[MAXC][8], b[MAXC][8];
 #pragma unroll
   for (int u = 0; u < MAXC; ++u) {
-    int chunk = lane + u * 64;
-    if (chunk < nchunks) {
-      unpack_bf16x8(*reinterpret_cast<const uint4*>(x + (size_t)row * ldx + chunk * 8), v[u]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sum += v[u][e];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
-    }
+    const int chunk = lane + u * 64;
+    live[u] = chunk < nchunks;
+    const int cs = live[u] ? chunk : 0;
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + cs * 8);
+    const float4 g1 = *reinterpret_cast<const float4*>(gamma + cs * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + cs * 8);
+    const float4 b1 = *reinterpret_cast<const float4*>(beta + cs * 8 + 4);
+    g[u][0] = g0.x; g[u][1] = g0.y; g[u][2] = g0.z; g[u][3] = g0.w;
+    g[u][4] = g1.x; g[u][5] = g1.y; g[u][6] = g1.z; g[u][7] = g1.w;
+    b[u][0] = b0.x; b[u][1] = b0.y; b[u][2] = b0.z; b[u][3] = b0.w;
+    b[u][4] = b1.x; b[u][5] = b1.y; b[u][6] = b1.z; b[u][7] = b1.w;
   }
+  for (int row0 = wave * LN_R; row0 < rows; row0 += nwaves * LN_R) {
+    uint4 raw[LN_R][MAXC];
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) sum = wave_xor_sum(sum, m);
-  const float mean = sum / (float)c;
-  float sq = 0.f;
+    for (int r = 0; r < LN_R; ++r) {
+      const int row = min(row0 + r, rows - 1);
 #pragma unroll
-  for (int u = 0; u < MAXC; ++u) {
-    int chunk = lane + u * 64;
-    if (chunk < nchunks) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float d = v[u][e] - mean;
-        sq += d * d;
+      for (int u = 0; u < MAXC; ++u) {
+        const int chunk = live[u] ? lane + u * 64 : 0;
+        raw[r][u] = *reinterpret_cast<const uint4*>(x + (size_t)row * ldx + chunk * 8);
       }
     }
-  }
+    float sum[LN_R];
 #pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) sq = wave_xor_sum(sq, m);
-  const float rstd = rsqrtf(sq / (float)c + eps);
-  const float* addrow = nullptr;
-  if (add != nullptr) addrow = add + (size_t)((row / add_rows_per_entry) % add_entries) * c;
+    for (int r = 0; r < LN_R; ++r) {
+      sum[r] = 0.f;
 #pragma unroll
-  for (int u = 0; u < MAXC; ++u) {
-    int chunk = lane + u * 64;
-    if (chunk < nchunks) {
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        int ch = chunk * 8 + e;
-        float y = (v[u][e] - mean) * rstd * gamma[ch] + beta[ch];
-        if (addrow != nullptr) y += addrow[ch];
-        o[e] = y;
+      for (int u = 0; u < MAXC; ++u) {
+        float v[8];
+        unpack_bf16x8(raw[r][u], v);
+        float t = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        sum[r] += live[u] ? t : 0.f;
       }
-      *reinterpret_cast<uint4*>(out + (size_t)row * ldo + chunk * 8) = pack_bf16x8(o);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+      for (int r = 0; r < LN_R; ++r) sum[r] = wave_xor_sum(sum[r], m);
+    float sq[LN_R];
+#pragma unroll
+    for (int r = 0; r < LN_R; ++r) {
+      const float mean = sum[r] * inv_c;
+      sq[r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < MAXC; ++u) {
+        float v[8];
+        unpack_bf16x8(raw[r][u], v);
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[e] - mean;
+          t += d * d;
+        }
+        sq[r] += live[u] ? t : 0.f;
+      }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+      for (int r = 0; r < LN_R; ++r) sq[r] = wave_xor_sum(sq[r], m);
+#pragma unroll
+    for (int r = 0; r < LN_R; ++r) {
+      const int row = row0 + r;
+      if (row >= rows) break;
+      const float mean = sum[r] * inv_c;
+      const float rstd = rsqrtf(sq[r] * inv_c + eps);
+      const float* addrow = nullptr;
+      if (add != nullptr) addrow = add + (size_t)((row / add_rows_per_entry) % add_entries) * c;
+#pragma unroll
+      for (int u = 0; u < MAXC; ++u) {
+        if (!live[u]) continue;
+        const int chunk = lane + u * 64;
+        float v[8], o[8];
+        unpack_bf16x8(raw[r][u], v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[e] - mean) * rstd * g[u][e] + b[u][e];
+        if (addrow != nullptr) {
+          const float4 a0 = *reinterpret_cast<const float4*>(addrow + chunk * 8);
+          const float4 a1 = *reinterpret_cast<const float4*>(addrow + chunk * 8 + 4);
+          o[0] += a0.x; o[1] += a0.y; o[2] += a0.z; o[3] += a0.w;
+          o[4] += a1.x; o[5] += a1.y; o[6] += a1.z; o[7] += a1.w;
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)row * ldo + chunk * 8) = pack_bf16x8(o);
+      }
     }
   }
 }
@@ -252,7 +376,8 @@ extern "C" int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int 
   const int tp = nchunks < GN_THREADS ? nchunks : GN_THREADS;
   const int pl_count = GN_THREADS / tp;
   size_t smem_stats = (size_t)pl_count * C * 2 * sizeof(float);
-  size_t smem_apply = (size_t)(2 * C + 2 * groups) * sizeof(float);
+  // scale[C] + shift[C] + gstat[2*groups] floats, then the fp64 sub-sums (8-byte aligned: C, groups even)
+  size_t smem_apply = (size_t)(2 * C + 2 * groups) * sizeof(float) + (size_t)GN_SUBS * groups * 2 * sizeof(double);
   VX_REQUIRE(smem_stats <= 64 * 1024, "vx_groupnorm: stats LDS %zu too large", smem_stats);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(frames * slices), dim3(GN_THREADS), smem_stats, stream,
                      (const bf16_t*)x1, c1, (const bf16_t*)x2, c2, hw, groups, slices, slice_pix, ws);
@@ -272,7 +397,10 @@ extern "C" int vx_layernorm(const void* x, int ldx, int rows, int c, float eps, 
   VX_REQUIRE(rows > 0 && c > 0 && (c % 8) == 0 && (ldx % 8) == 0 && (ldo % 8) == 0, "vx_layernorm: bad shape");
   VX_REQUIRE(add == nullptr || (add_rows_per_entry > 0 && add_entries > 0), "vx_layernorm: bad add table");
   const int nchunks = c / 8;
-  dim3 grid(ceil_div(rows, 4)), block(256);
+  // 4 waves per block, LN_R rows per wave-pass; cap the grid so that long inputs amortise the gamma/beta loads
+  int nblk = ceil_div(rows, 4 * LN_R);
+  if (nblk > 4096) nblk = 4096;
+  dim3 grid(nblk), block(256);
 #define VX_LN(MAXC)                                                                                              \
   hipLaunchKernelGGL(layernorm_kernel<MAXC>, grid, block, 0, stream, (const bf16_t*)x, ldx, rows, c, eps, gamma, \
                      beta, add, add_rows_per_entry, add_entries, (bf16_t*)out, ldo)

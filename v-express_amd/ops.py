@@ -208,7 +208,7 @@ def _gn_slices(hw):
     """Spatial slices per frame for the GroupNorm statistics.  A function of hw ONLY: the partial-sum grouping
     (hence the fp32 rounding) must not depend on how many frames share the launch, so that a CFG half or a
     window computed on another GPU is bit-identical to the batched call."""
-    return max(1, min(64, hw // 128))
+    return max(1, min(64, hw // 16))
 
 
 def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=None):
