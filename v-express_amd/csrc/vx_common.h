@@ -35,8 +35,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 pair with one v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved)
+typedef __bf16 vx_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float vx_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  vx_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vx_bf16x2_t));
 }
 
 __device__ __forceinline__ void unpack_bf16x8(const uint4& v, float* f) {

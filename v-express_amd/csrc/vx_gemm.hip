@@ -2,21 +2,28 @@
 //
 //   out[m, n] = epilogue( sum_k A[m, k] * W[n, k] ),   bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16)
 //
-// Block = 256 threads = 4 waves (WARPS_M x WARPS_N), tile BM x BN x 64.  Both operands are K-contiguous, so a
-// K-tile row is 128 B = eight 16-B chunks.  Each thread stages (BM+BN)/32 chunks global -> VGPR -> LDS; the A
-// gather computes (frame, iy, ix, ci) per chunk so 3x3/1x1 convs (stride 1/2, fused nearest-2x upsample, channel
-// concat of two sources) and plain linears share one kernel.  LDS rows are XOR-swizzled at 16-B granularity
-// (chunk ^= (row>>1)&7) so the ds_read_b128 fragment reads of 16 rows x 4 k-groups are bank-conflict-free.
-// Software pipeline: the next K-tile's global loads are issued before the MFMAs of the current one and written to
-// the other LDS stage afterwards (one barrier per K-tile).  The epilogue stages the fp32 tile through LDS in
-// 64-row slabs so that bias / time-embedding / activation / residual / bf16 packing happen on 16-B coalesced rows.
+// Block = WARPS_M x WARPS_N waves (4 or 8), tile BM x BN x 64, every wave owns a 64 x (BN/WARPS_N) sub-tile.
+// Both operands are K-contiguous, so a K-tile row is 128 B = eight 16-B chunks.  Staging is asynchronous
+// global -> LDS DMA (global_load_lds_dwordx4, no VGPR round trip): each thread issues (BM+BN)/(NT/8) 16-B copies
+// per K-tile; the A gather computes (frame, iy, ix, ci) per chunk so 3x3/1x1 convs (stride 1/2, fused nearest-2x
+// upsample, channel concat of two sources) and plain linears share one kernel, and every out-of-range chunk
+// (conv padding, M/N/K tails) is fetched from a 16-byte zero constant so the copies are branch-free.
+// LDS rows are XOR-swizzled at 16-B granularity (slot = chunk ^ ((row>>1)&7)); because the DMA writes
+// lane-linearly, the swizzle is applied to the per-lane *global* address.  The ds_read_b128 fragment reads of
+// 16 rows x 4 k-groups are then bank-conflict-free.
+// Pipeline: STAGES LDS buffers, tiles kt+1 .. kt+STAGES-1 in flight while tile kt is multiplied; one raw
+// s_barrier per K-tile and a counted s_waitcnt vmcnt (never 0 in steady state when STAGES > 2).
+// Epilogue: the MFMAs produce C^T fragments (4 consecutive output columns per lane), stored straight from registers
+// with bias / time-embedding rows / activation / residual fused; only V^T parts are transposed through LDS.
 #include "vx_common.h"
 #include "../../include/vexpress_hip.h"
+
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
 constexpr int BK = 64;
-constexpr int NTHREADS = 256;
 
 struct RowInfo {
   int pix_base;  // frame * h_in * w_in
@@ -47,18 +54,33 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const vx_gemm_params p) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// FAST = every (row, tap) of the A gather is in range (pad == 0, no upsample: linears and convs over a
+// pre-padded input), cin, c1 and K are multiples of 64 and both operands span < 4 GiB.  Then the per-thread part
+// of every DMA address is a loop-invariant 32-bit byte offset and the per-tile part is wave-uniform (SGPRs):
+// the K loop spends no VALU instructions on addressing (a wave64 VALU op costs 4 cycles = 1/8 of an MFMA).
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const vx_gemm_params p) {
+  constexpr int NTHREADS = 64 * WARPS_M * WARPS_N;
+  constexpr int RPP = NTHREADS / 8;   // tile rows staged per pass of the whole block
   constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
   constexpr int MI = WM / 16, NI = WN / 16;
-  constexpr int A_IT = BM / 32, B_IT = BN / 32;
+  constexpr int NJ = NI <= 5 ? NI : NI / 2;   // B fragments live at once
+  constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
+  constexpr int G = A_IT + B_IT;              // DMA instructions per thread per K-tile
   constexpr int STAGE_BYTES = (BM + BN) * 128;
-  static_assert(WM == 64, "epilogue assumes 64-row wave slabs");
-  static_assert(WARPS_M * WARPS_N == 4, "4 waves");
+  static_assert(WM == 64, "every wave owns a 64-row slab");
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
+  static_assert(NI % NJ == 0, "fragment grouping");
+  static_assert(G * (STAGES - 2) < 64, "vmcnt is 6 bits");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   const int n_tiles = (p.n + BN - 1) / BN;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -77,71 +99,111 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const vx_gemm_params 
   const int lda1 = p.lda1, lda2 = p.lda2;
   const bf16_t* const zsrc = reinterpret_cast<const bf16_t*>(&g_zero16);
 
-  // ---- per-thread staging coordinates: LDS slot `s` of row r0 + 32*i holds K-chunk s ^ ((row >> 1) & 7)
+  // ---- per-thread staging coordinates: LDS slot `s` of row r0 + RPP*i holds K-chunk s ^ ((row >> 1) & 7)
   const int r0 = tid >> 3;
   const int cc = (tid & 7) ^ ((r0 >> 1) & 7);   // K-chunk (8 elements) this thread fetches
+  // ---- FAST path state
+  uint32_t aoff1[A_IT], aoff2[A_IT], boff[B_IT];
+  int s_ci = 0, s_kx = 0, s_ky = 0, s_kt = 0;   // wave-uniform K position of the next tile to issue
+  // ---- general path state
   RowInfo ri[A_IT];
+  long wrow[B_IT];   // element offset of weight row n (or -1: beyond N)
+  int kg = cc * 8;   // K position of this thread's chunk, tracked incrementally: k = ((ky*kw)+kx)*cin + ci
+  int ky = 0, kx = 0, ci = 0;
+  char* const lds_wave = smem + (wave * 8) * 128;   // this wave's 8-row (1 KiB) slab within each RPP-row group
+
+  if constexpr (FAST) {
+    // rows / weight rows beyond M / N are clamped to the last valid one: their products are never stored
 #pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    int m = m0 + r0 + 32 * i;
-    if (m < p.m) {
+    for (int i = 0; i < A_IT; ++i) {
+      int m = min(m0 + r0 + RPP * i, p.m - 1);
       int fr = m / hw_out;
       int rem = m - fr * hw_out;
       int oy = rem / p.w_out;
       int ox = rem - oy * p.w_out;
-      ri[i].pix_base = fr * p.h_in * p.w_in;
-      ri[i].iy0 = oy * p.stride - p.pad;
-      ri[i].ix0 = ox * p.stride - p.pad;
-    } else {
-      ri[i].pix_base = 0;
-      ri[i].iy0 = -(1 << 28);
-      ri[i].ix0 = -(1 << 28);
+      uint32_t pix = (uint32_t)(fr * p.h_in * p.w_in + oy * p.stride * w_in + ox * p.stride);
+      aoff1[i] = (pix * (uint32_t)lda1 + (uint32_t)(cc * 8)) * 2u;
+      aoff2[i] = (pix * (uint32_t)lda2 + (uint32_t)(cc * 8)) * 2u;
     }
-  }
-  long wrow[B_IT];   // element offset of weight row n (or -1: beyond N)
 #pragma unroll
-  for (int i = 0; i < B_IT; ++i) {
-    int n = n0 + r0 + 32 * i;
-    wrow[i] = n < p.n ? (long)n * p.k : -1;
-  }
-  // K position of this thread's chunk, tracked incrementally: (ky, kx, ci) with k = ((ky*kw)+kx)*cin + ci
-  int kg = cc * 8;
-  int ky, kx, ci;
-  {
+    for (int i = 0; i < B_IT; ++i) {
+      int n = min(n0 + r0 + RPP * i, p.n - 1);
+      boff[i] = ((uint32_t)n * (uint32_t)p.k + (uint32_t)(cc * 8)) * 2u;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int m = m0 + r0 + RPP * i;
+      if (m < p.m) {
+        int fr = m / hw_out;
+        int rem = m - fr * hw_out;
+        int oy = rem / p.w_out;
+        int ox = rem - oy * p.w_out;
+        ri[i].pix_base = fr * p.h_in * p.w_in;
+        ri[i].iy0 = oy * p.stride - p.pad;
+        ri[i].ix0 = ox * p.stride - p.pad;
+      } else {
+        ri[i].pix_base = 0;
+        ri[i].iy0 = -(1 << 28);
+        ri[i].ix0 = -(1 << 28);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      int n = n0 + r0 + RPP * i;
+      wrow[i] = n < p.n ? (long)n * p.k : -1;
+    }
     int tap = kg / cin;
     ci = kg - tap * cin;
     ky = tap / kw;
     kx = tap - ky * kw;
   }
-  char* const lds_wave = smem + (wave * 8) * 128;   // this wave's 8-row (1 KiB) slab within each 32-row group
 
   auto issue_tile = [&](int stage) {
     char* sa = lds_wave + stage * STAGE_BYTES;
     char* sb = sa + BM * 128;
-    const bool kval = ky < kh;
-    const bool first = ci < c1;
-    const bf16_t* src = first ? A1 + ci : A2 + (ci - c1);
-    const int cs = first ? lda1 : lda2;
+    if constexpr (FAST) {
+      // wave-uniform: source, its row stride and the tap's byte offset
+      const bool first = s_ci < c1;
+      const char* abase = first ? (const char*)(A1 + s_ci) + (long)(s_ky * w_in + s_kx) * lda1 * 2
+                                : (const char*)(A2 + (s_ci - c1)) + (long)(s_ky * w_in + s_kx) * lda2 * 2;
+      const char* bbase = (const char*)Wt + (long)s_kt * (BK * 2);
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      int iy = ri[i].iy0 + ky, ix = ri[i].ix0 + kx;
-      bool ok = kval && (unsigned)iy < (unsigned)h_eff && (unsigned)ix < (unsigned)w_eff;
-      int pix = ri[i].pix_base + (iy >> up) * w_in + (ix >> up);
-      const bf16_t* g = ok ? src + (long)pix * (long)cs : zsrc;
-      glds16(g, sa + i * 32 * 128);
-    }
+      for (int i = 0; i < A_IT; ++i) glds16(abase + (first ? aoff1[i] : aoff2[i]), sa + i * RPP * 128);
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      bool ok = kval && wrow[i] >= 0;
-      const bf16_t* g = ok ? Wt + wrow[i] + kg : zsrc;
-      glds16(g, sb + i * 32 * 128);
-    }
-    // advance to the next K-tile
-    kg += BK;
-    ci += BK;
-    while (ci >= cin) {
-      ci -= cin;
-      if (++kx == kw) { kx = 0; ++ky; }
+      for (int i = 0; i < B_IT; ++i) glds16(bbase + boff[i], sb + i * RPP * 128);
+      ++s_kt;
+      s_ci += BK;
+      if (s_ci >= cin) {
+        s_ci = 0;
+        if (++s_kx == kw) { s_kx = 0; ++s_ky; }
+      }
+    } else {
+      const bool kval = ky < kh;
+      const bool first = ci < c1;
+      const bf16_t* src = first ? A1 + ci : A2 + (ci - c1);
+      const int cs = first ? lda1 : lda2;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        int iy = ri[i].iy0 + ky, ix = ri[i].ix0 + kx;
+        bool ok = kval && (unsigned)iy < (unsigned)h_eff && (unsigned)ix < (unsigned)w_eff;
+        int pix = ri[i].pix_base + (iy >> up) * w_in + (ix >> up);
+        const bf16_t* g = ok ? src + (long)pix * (long)cs : zsrc;
+        glds16(g, sa + i * RPP * 128);
+      }
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        bool ok = kval && wrow[i] >= 0;
+        const bf16_t* g = ok ? Wt + wrow[i] + kg : zsrc;
+        glds16(g, sb + i * RPP * 128);
+      }
+      // advance to the next K-tile
+      kg += BK;
+      ci += BK;
+      while (ci >= cin) {
+        ci -= cin;
+        if (++kx == kw) { kx = 0; ++ky; }
+      }
     }
   };
 
@@ -152,185 +214,241 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const vx_gemm_params 
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.k + BK - 1) / BK;
-  issue_tile(0);
+#pragma unroll
+  for (int t = 0; t < STAGES - 1; ++t)
+    if (t < nk) issue_tile(t);
 
   const int frow = lane & 15, fgrp = lane >> 4;
+  int stage = 0;                 // kt % STAGES
+  int fill = STAGES - 1;         // (kt + STAGES - 1) % STAGES: the stage freed by iteration kt-1
   for (int kt = 0; kt < nk; ++kt) {
-    const int stage = kt & 1;
-    // tile kt has landed (own DMAs drained, then the barrier covers everyone's); the barrier also orders the
-    // other stage's last reads (iteration kt-1) before it is refilled below
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) issue_tile(stage ^ 1);
+    // Tile kt has landed once this wave's own DMAs for it are retired (in-order: at most the G*(STAGES-2) copies
+    // of the younger tiles may still be pending) and the barrier has collected every wave's.  The same barrier
+    // orders everyone's fragment reads of iteration kt-1 before that stage is refilled below.
+    if (STAGES > 2 && kt + STAGES - 2 < nk) wait_vmcnt<G * (STAGES - 2)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + STAGES - 1 < nk) issue_tile(fill);
     const char* sa = smem + stage * STAGE_BYTES;
     const char* sb = sa + BM * 128;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      uint4 af[MI], bfr[NI];
+      uint4 af[MI];
 #pragma unroll
       for (int i = 0; i < MI; ++i)
         af[i] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * WM + i * 16 + frow, kk * 4 + fgrp));
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-        bfr[j] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * WN + j * 16 + frow, kk * 4 + fgrp));
+      for (int j0 = 0; j0 < NI; j0 += NJ) {
+        uint4 bfr[NJ];
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(af[i], bfr[j], acc[i][j]);
-    }
-  }
-  __syncthreads();   // all fragment reads done before the epilogue reuses the stages
-
-  // ------------------------------------------------------------------ epilogue (fp32 tile through LDS, 64-row slabs)
-  constexpr int OUTW = (EPI == VX_EPI_GEGLU) ? BN / 2 : BN;   // staged tile width
-  constexpr int CT_LD = OUTW + 4;                             // floats; keeps 16-B alignment, spreads banks
-  float* ct = reinterpret_cast<float*>(smem);
-  const float* __restrict__ bias = p.bias;
-
-  for (int pass = 0; pass < WARPS_M; ++pass) {
-    if (wm == pass) {
-      if constexpr (EPI == VX_EPI_GEGLU) {
-        // fragment pairs (2q, 2q+1) hold the value / gate columns of the same 16 output channels
-#pragma unroll
-        for (int j = 0; j < NI; j += 2) {
-          int ncol = n0 + wn * WN + j * 16 + frow;           // interleaved weight row of the value column
-          float bh = 0.f, bg = 0.f;
-          if (bias != nullptr) {
-            if (ncol < p.n) bh = bias[ncol];
-            if (ncol + 16 < p.n) bg = bias[ncol + 16];
-          }
-          int ocol = (wn * WN + j * 16) / 2 + frow;
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float hval = acc[i][j][r] + bh;
-              float gval = acc[i][j + 1][r] + bg;
-              ct[(i * 16 + fgrp * 4 + r) * CT_LD + ocol] = hval * gelu_f(gval);
-            }
-        }
-      } else {
+        for (int j = 0; j < NJ; ++j)
+          bfr[j] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * WN + (j0 + j) * 16 + frow, kk * 4 + fgrp));
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j0 + j] = mfma16(bfr[j], af[i], acc[i][j0 + j]);   // D = C^T fragment
+      }
+    }
+    stage = stage + 1 == STAGES ? 0 : stage + 1;
+    fill = fill + 1 == STAGES ? 0 : fill + 1;
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // The MFMAs were issued with the operands swapped (weights as the row operand), so each accumulator fragment is a
+  // 16x16 block of C^T: lane l holds output row m = i*16 + (l & 15) and the FOUR CONSECUTIVE columns
+  // n = j*16 + 4*(l >> 4) + {0..3}.  STORE / GEGLU / row-major SPLIT parts therefore go straight from registers to
+  // global memory as 8-byte (4 x bf16) stores - no LDS round trip, no barrier; bias / time-embedding rows /
+  // residual are fetched with the same 4-wide pattern.  Only V^T parts are transposed through LDS.
+  const float* __restrict__ bias = p.bias;
+  const int lrow = lane & 15, lq = lane >> 4;
+  const int wrow0 = m0 + wm * WM, wcol0 = n0 + wn * WN;
+
+  if constexpr (EPI == VX_EPI_STORE) {
+    // Optional addends are fetched in batches of NJ fragments under kernel-uniform branches (clamped addresses for
+    // out-of-range rows / columns), so the loads of a row group are in flight together; only stores are predicated.
+    const float* __restrict__ rowbias = p.rowbias;
+    const bf16_t* __restrict__ resid = (const bf16_t*)p.residual;
+    const bool do_silu = p.act == VX_ACT_SILU;
+    const bool out_is_f32 = p.out_f32 != 0;
+    const float alpha = p.alpha;
+#pragma unroll
+    for (int j0 = 0; j0 < NI; j0 += NJ) {
+      int ncol[NJ], nc[NJ];
+      float4 bv[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        ncol[j] = wcol0 + (j0 + j) * 16 + lq * 4;
+        nc[j] = min(ncol[j], p.n - 4);
+        bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (bias != nullptr) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const float4*>(bias + nc[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = wrow0 + i * 16 + lrow;
+        const int mc = min(m, p.m - 1);
+        uint2 rv[NJ];
+        float4 rb[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          rv[j] = make_uint2(0u, 0u);
+          rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (resid != nullptr) {
+          const bf16_t* rrow = resid + (size_t)mc * p.ldr;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) rv[j] = *reinterpret_cast<const uint2*>(rrow + nc[j]);
+        }
+        if (rowbias != nullptr) {
+          const float* rbrow = rowbias + (size_t)(mc / p.rows_per_group) * p.rowbias_ld;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) rb[j] = *reinterpret_cast<const float4*>(rbrow + nc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const f32x4_t a4 = acc[i][j0 + j];
+          float v[4] = {a4[0] + bv[j].x + rb[j].x, a4[1] + bv[j].y + rb[j].y, a4[2] + bv[j].z + rb[j].z,
+                        a4[3] + bv[j].w + rb[j].w};
+          if (do_silu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= alpha;
+          v[0] += __uint_as_float(rv[j].x << 16); v[1] += __uint_as_float(rv[j].x & 0xffff0000u);
+          v[2] += __uint_as_float(rv[j].y << 16); v[3] += __uint_as_float(rv[j].y & 0xffff0000u);
+          if (m < p.m && ncol[j] < p.n) {
+            if (out_is_f32) {
+              *reinterpret_cast<float4*>((float*)p.out + (size_t)m * p.ldc + ncol[j]) =
+                  make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+              *reinterpret_cast<uint2*>((bf16_t*)p.out + (size_t)m * p.ldc + ncol[j]) =
+                  make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            }
+          }
+        }
+      }
+    }
+  } else if constexpr (EPI == VX_EPI_GEGLU) {
+    // fragment pairs (2q, 2q+1) hold the value / gate columns of the same 16 output channels
+    const int nout = p.n / 2;
+#pragma unroll
+    for (int j = 0; j < NI; j += 2) {
+      const int ncol = wcol0 + j * 16 + lq * 4;   // interleaved weight row of the first value column
+      if (ncol + 16 >= p.n) continue;
+      float bh[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias != nullptr) {
+        const float4 h4 = *reinterpret_cast<const float4*>(bias + ncol);
+        const float4 g4 = *reinterpret_cast<const float4*>(bias + ncol + 16);
+        bh[0] = h4.x; bh[1] = h4.y; bh[2] = h4.z; bh[3] = h4.w;
+        bg[0] = g4.x; bg[1] = g4.y; bg[2] = g4.z; bg[3] = g4.w;
+      }
+      const int ocol = (wcol0 + j * 16) / 2 + lq * 4;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = wrow0 + i * 16 + lrow;
+        if (m >= p.m || ocol >= nout) continue;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (acc[i][j][r] + bh[r]) * gelu_f(acc[i][j + 1][r] + bg[r]);
+        *reinterpret_cast<uint2*>((bf16_t*)p.out + (size_t)m * p.ldc + ocol) =
+            make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+      }
+    }
+  } else {  // VX_EPI_SPLIT
+    // (a) row-major parts: direct 8-byte stores (a 16-column fragment never straddles parts: part_cols % 16 == 0)
+    bool any_vt = false;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = wcol0 + j * 16 + lq * 4;
+      const int nfrag = wcol0 + j * 16;
+      if (nfrag >= p.n) continue;
+      const int part = nfrag / p.part_cols;
+      if (sel3(part, p.part_kind[0], p.part_kind[1], p.part_kind[2]) != VX_PART_ROWS) {
+        any_vt = true;
+        continue;
+      }
+      const int nn = n - part * p.part_cols;
+      bf16_t* dst = (bf16_t*)sel3(part, p.part_out[0], p.part_out[1], p.part_out[2]);
+      const int ldp = sel3(part, p.part_ld[0], p.part_ld[1], p.part_ld[2]);
+      float b[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias != nullptr) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+        b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = wrow0 + i * 16 + lrow;
+        if (m >= p.m) continue;
+        *reinterpret_cast<uint2*>(dst + (size_t)m * ldp + nn) =
+            make_uint2(pack_bf16x2(acc[i][j][0] + b[0], acc[i][j][1] + b[1]),
+                       pack_bf16x2(acc[i][j][2] + b[2], acc[i][j][3] + b[3]));
+      }
+    }
+    // (b) transposed (V^T) parts: [seq, head, dim, key] with keys contiguous.  The tile goes through LDS as
+    // ct[col][row] (fp32, row-contiguous) in 64-row slabs, then 8 consecutive tokens per 16-byte store with the 8
+    // token groups of a column on consecutive threads (128 contiguous bytes).
+    const int tile_has_vt = __syncthreads_or(any_vt ? 1 : 0);   // also: all fragment reads of the K loop are done
+    if (tile_has_vt) {
+      constexpr int CT_LD = 64 + 4;   // floats per column
+      float* ct = reinterpret_cast<float*>(smem);
+      for (int pass = 0; pass < WARPS_M; ++pass) {
+        if (wm == pass) {
+#pragma unroll
           for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              ct[(i * 16 + fgrp * 4 + r) * CT_LD + wn * WN + j * 16 + frow] = acc[i][j][r];
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                ct[(wn * WN + j * 16 + lq * 4 + r) * CT_LD + i * 16 + lrow] = acc[i][j][r];
+        }
+        __syncthreads();
+        const int mbase = m0 + pass * 64;
+        for (int idx = tid; idx < 8 * BN; idx += NTHREADS) {
+          const int col = idx >> 3, rg = idx & 7;
+          const int n = n0 + col;
+          const int mfirst = mbase + rg * 8;
+          if (n >= p.n || mfirst >= p.m) continue;
+          const int part = n / p.part_cols;
+          if (sel3(part, p.part_kind[0], p.part_kind[1], p.part_kind[2]) != VX_PART_VT) continue;
+          const int nn = n - part * p.part_cols;
+          const int head = nn / p.head_dim, dd = nn - head * p.head_dim;
+          const int heads = p.part_cols / p.head_dim;
+          const float bv = bias != nullptr ? bias[n] : 0.f;
+          const float4 lo = *reinterpret_cast<const float4*>(ct + col * CT_LD + rg * 8);
+          const float4 hi = *reinterpret_cast<const float4*>(ct + col * CT_LD + rg * 8 + 4);
+          float v[8] = {lo.x + bv, lo.y + bv, lo.z + bv, lo.w + bv, hi.x + bv, hi.y + bv, hi.z + bv, hi.w + bv};
+          bf16_t* vt = (bf16_t*)sel3(part, p.part_out[0], p.part_out[1], p.part_out[2]);
+          const int seq = mfirst / p.seq_len, tok = mfirst - seq * p.seq_len;
+          if ((p.seq_len & 7) == 0 && mfirst + 8 <= p.m) {
+            const size_t off = ((size_t)(seq * heads + head) * p.head_dim + dd) * p.vt_pitch + tok;
+            *reinterpret_cast<uint4*>(vt + off) = pack_bf16x8(v);
+          } else {
+            for (int e = 0; e < 8; ++e) {
+              const int m = mfirst + e;
+              if (m >= p.m) break;
+              const int s2 = m / p.seq_len, t = m - s2 * p.seq_len;
+              vt[((size_t)(s2 * heads + head) * p.head_dim + dd) * p.vt_pitch + t] = f32_to_bf16(v[e]);
+            }
+          }
+        }
+        __syncthreads();
       }
     }
-    __syncthreads();
-
-    const int mbase = m0 + pass * 64;
-    if constexpr (EPI == VX_EPI_STORE || EPI == VX_EPI_GEGLU) {
-      const int nout = (EPI == VX_EPI_GEGLU) ? p.n / 2 : p.n;
-      const int nbase = (EPI == VX_EPI_GEGLU) ? n0 / 2 : n0;
-      constexpr int CPR = OUTW / 8;   // 8-column chunks per row
-      for (int idx = tid; idx < 64 * CPR; idx += NTHREADS) {
-        int row = idx / CPR, c8 = idx - row * CPR;
-        int m = mbase + row, n = nbase + c8 * 8;
-        if (m >= p.m || n >= nout) continue;
-        float v[8];
-        const float4 lo = *reinterpret_cast<const float4*>(ct + row * CT_LD + c8 * 8);
-        const float4 hi = *reinterpret_cast<const float4*>(ct + row * CT_LD + c8 * 8 + 4);
-        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-        if constexpr (EPI == VX_EPI_STORE) {
-          if (bias != nullptr) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bias[n + e];
-          }
-          if (p.rowbias != nullptr) {
-            const float* rbp = p.rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld + n;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rbp[e];
-          }
-          if (p.act == VX_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-          }
-          if (p.alpha != 1.0f) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-          }
-          if (p.residual != nullptr) {
-            float rr[8];
-            unpack_bf16x8(*reinterpret_cast<const uint4*>((const bf16_t*)p.residual + (size_t)m * p.ldr + n), rr);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rr[e];
-          }
-        }
-        if (EPI == VX_EPI_STORE && p.out_f32) {
-          float* o = (float*)p.out + (size_t)m * p.ldc + n;
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          *reinterpret_cast<uint4*>((bf16_t*)p.out + (size_t)m * p.ldc + n) = pack_bf16x8(v);
-        }
-      }
-    } else {  // VX_EPI_SPLIT
-      constexpr int CPR = BN / 8;
-      // (a) row-major parts: 16-B coalesced rows
-      for (int idx = tid; idx < 64 * CPR; idx += NTHREADS) {
-        int row = idx / CPR, c8 = idx - row * CPR;
-        int m = mbase + row, n = n0 + c8 * 8;
-        if (m >= p.m || n >= p.n) continue;
-        int part = n / p.part_cols;
-        if (sel3(part, p.part_kind[0], p.part_kind[1], p.part_kind[2]) != VX_PART_ROWS) continue;
-        int nn = n - part * p.part_cols;
-        float v[8];
-        const float4 lo = *reinterpret_cast<const float4*>(ct + row * CT_LD + c8 * 8);
-        const float4 hi = *reinterpret_cast<const float4*>(ct + row * CT_LD + c8 * 8 + 4);
-        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-        if (bias != nullptr) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bias[n + e];
-        }
-        bf16_t* dst = (bf16_t*)sel3(part, p.part_out[0], p.part_out[1], p.part_out[2]);
-        int ldp = sel3(part, p.part_ld[0], p.part_ld[1], p.part_ld[2]);
-        *reinterpret_cast<uint4*>(dst + (size_t)m * ldp + nn) = pack_bf16x8(v);
-      }
-      // (b) transposed (V^T) parts: [seq, head, dim, key] with keys contiguous; 8 consecutive tokens per store
-      for (int idx = tid; idx < 8 * BN; idx += NTHREADS) {
-        int rg = idx / BN, col = idx - rg * BN;
-        int n = n0 + col;
-        int mfirst = mbase + rg * 8;
-        if (n >= p.n || mfirst >= p.m) continue;
-        int part = n / p.part_cols;
-        if (sel3(part, p.part_kind[0], p.part_kind[1], p.part_kind[2]) != VX_PART_VT) continue;
-        int nn = n - part * p.part_cols;
-        int head = nn / p.head_dim, dd = nn - head * p.head_dim;
-        int heads = p.part_cols / p.head_dim;
-        float bv = bias != nullptr ? bias[n] : 0.f;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = ct[(rg * 8 + e) * CT_LD + col] + bv;
-        bf16_t* vt = (bf16_t*)sel3(part, p.part_out[0], p.part_out[1], p.part_out[2]);
-        int seq = mfirst / p.seq_len, tok = mfirst - seq * p.seq_len;
-        if ((p.seq_len & 7) == 0 && mfirst + 8 <= p.m) {
-          size_t off = ((size_t)(seq * heads + head) * p.head_dim + dd) * p.vt_pitch + tok;
-          *reinterpret_cast<uint4*>(vt + off) = pack_bf16x8(v);
-        } else {
-          for (int e = 0; e < 8; ++e) {
-            int m = mfirst + e;
-            if (m >= p.m) break;
-            int s = m / p.seq_len, t = m - s * p.seq_len;
-            vt[((size_t)(s * heads + head) * p.head_dim + dd) * p.vt_pitch + t] = f32_to_bf16(v[e]);
-          }
-        }
-      }
-    }
-    __syncthreads();
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int EPI>
-int launch(const vx_gemm_params& p, hipStream_t stream) {
-  constexpr int stage_bytes = 2 * (BM + BN) * 128;
-  constexpr int outw = (EPI == VX_EPI_GEGLU) ? BN / 2 : BN;
-  constexpr int epi_bytes = 64 * (outw + 4) * 4;
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST>
+int launch_impl(const vx_gemm_params& p, hipStream_t stream) {
+  constexpr int stage_bytes = STAGES * (BM + BN) * 128;
+  constexpr int epi_bytes = (EPI == VX_EPI_SPLIT) ? BN * (64 + 4) * 4 : 0;   // V^T transposition slab
   constexpr int smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+  constexpr int nthreads = 64 * WARPS_M * WARPS_N;
   static bool attr_set = false;
-  auto kern = gemm_kernel<BM, BN, WARPS_M, WARPS_N, EPI>;
+  auto kern = gemm_kernel<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, FAST>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
@@ -340,8 +458,28 @@ int launch(const vx_gemm_params& p, hipStream_t stream) {
     attr_set = true;
   }
   long tiles = (long)ceil_div(p.m, BM) * ceil_div(p.n, BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NTHREADS), smem, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(nthreads), smem, stream, p);
   return vx_check_launch("vx_gemm");
+}
+
+// FAST-path eligibility (see gemm_kernel)
+bool fast_ok(const vx_gemm_params& p) {
+  static int disabled = -1;
+  if (disabled < 0) disabled = getenv("VX_GEMM_NOFAST") != nullptr;
+  if (disabled) return false;
+  const int cin = p.c1 + p.c2;
+  const unsigned long long rows_in = (unsigned long long)p.nb * p.h_in * p.w_in;
+  return p.pad == 0 && p.upsample == 0 && (cin % 64) == 0 && (p.c1 % 64) == 0 && (p.k % 64) == 0 &&
+         rows_in * (unsigned long long)p.lda1 * 2ull < (1ull << 32) &&
+         (p.c2 == 0 || rows_in * (unsigned long long)p.lda2 * 2ull < (1ull << 32)) &&
+         (unsigned long long)p.n * p.k * 2ull < (1ull << 32) &&
+         (p.h_out - 1) * p.stride + p.kh <= p.h_in && (p.w_out - 1) * p.stride + p.kw <= p.w_in;
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI>
+int launch(const vx_gemm_params& p, hipStream_t stream) {
+  if (fast_ok(p)) return launch_impl<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, true>(p, stream);
+  return launch_impl<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, false>(p, stream);
 }
 
 // column-tile width with the least padding (ties -> 160: fewer, fatter tiles)
@@ -350,8 +488,30 @@ bool prefer160(int n) {
   return w160 * 128 <= w128 * 160;
 }
 
-}  // namespace
+// Tile configuration.  BIG = 256x320 tile, 8 waves, one block per CU: A is streamed once for N = 320 and a
+// K-tile's DMA (72 KiB) is covered by 2x the MFMA work of the 128-row tiles -> used when N is a multiple of 320 and
+// the launch still has >= 1 tile per CU.  VX_GEMM_TILE=big|small|small3 overrides (benchmarking only).
+enum { CFG_AUTO = 0, CFG_BIG = 1, CFG_SMALL = 2 };
+int forced_cfg() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VX_GEMM_TILE");
+    v = CFG_AUTO;
+    if (e && !strcmp(e, "big")) v = CFG_BIG;
+    if (e && !strcmp(e, "small")) v = CFG_SMALL;
+  }
+  return v;
+}
+bool use_big(const vx_gemm_params& p) {
+  if ((p.n % 320) != 0) return false;
+  int f = forced_cfg();
+  if (f == CFG_BIG) return true;
+  if (f == CFG_SMALL) return false;
+  long tiles = (long)ceil_div(p.m, 256) * (p.n / 320);
+  return tiles >= 256;
+}
 
+}  // namespace
 extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
   const vx_gemm_params& p = *pp;
   hipStream_t stream = (hipStream_t)stream_;
@@ -371,17 +531,19 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
     VX_REQUIRE(p.out != nullptr && (p.ldc % 8) == 0, "vx_gemm: STORE needs out and ldc%%8==0");
     VX_REQUIRE(p.residual == nullptr || (p.ldr % 8) == 0, "vx_gemm: ldr%%8");
     VX_REQUIRE(p.rowbias == nullptr || p.rows_per_group > 0, "vx_gemm: rows_per_group");
-    if (p.n <= 32) return launch<256, 32, 4, 1, VX_EPI_STORE>(p, stream);
-    if (prefer160(p.n)) return launch<128, 160, 2, 2, VX_EPI_STORE>(p, stream);
-    return launch<128, 128, 2, 2, VX_EPI_STORE>(p, stream);
+    if (p.n <= 32) return launch<256, 32, 4, 1, 2, VX_EPI_STORE>(p, stream);
+    if (use_big(p)) return launch<256, 320, 4, 2, 2, VX_EPI_STORE>(p, stream);
+    if (prefer160(p.n)) return launch<128, 160, 2, 2, 2, VX_EPI_STORE>(p, stream);
+    return launch<128, 128, 2, 2, 2, VX_EPI_STORE>(p, stream);
   } else if (p.epi == VX_EPI_GEGLU) {
     VX_REQUIRE(p.out != nullptr && (p.n % 32) == 0 && (p.ldc % 8) == 0,
                "vx_gemm: GEGLU needs n%%32==0 (16-wide value/gate interleave)");
-    return launch<128, 128, 2, 2, VX_EPI_GEGLU>(p, stream);
+    if (use_big(p)) return launch<256, 320, 4, 2, 2, VX_EPI_GEGLU>(p, stream);
+    return launch<128, 128, 2, 2, 2, VX_EPI_GEGLU>(p, stream);
   } else if (p.epi == VX_EPI_SPLIT) {
     VX_REQUIRE(p.n_parts >= 1 && p.n_parts <= 3 && p.part_cols > 0 && p.n == p.n_parts * p.part_cols,
                "vx_gemm: SPLIT n=%d != n_parts*part_cols", p.n);
-    VX_REQUIRE((p.part_cols % 8) == 0, "vx_gemm: part_cols%%8");
+    VX_REQUIRE((p.part_cols % 16) == 0, "vx_gemm: part_cols%%16 (a 16-column fragment must not straddle parts)");
     for (int i = 0; i < p.n_parts; ++i) {
       VX_REQUIRE(p.part_out[i] != nullptr, "vx_gemm: SPLIT part %d has no destination", i);
       if (p.part_kind[i] == VX_PART_VT)
@@ -391,8 +553,9 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
       else
         VX_REQUIRE((p.part_ld[i] % 8) == 0, "vx_gemm: part_ld%%8");
     }
-    if (prefer160(p.n)) return launch<128, 160, 2, 2, VX_EPI_SPLIT>(p, stream);
-    return launch<128, 128, 2, 2, VX_EPI_SPLIT>(p, stream);
+    if (use_big(p)) return launch<256, 320, 4, 2, 2, VX_EPI_SPLIT>(p, stream);
+    if (prefer160(p.n)) return launch<128, 160, 2, 2, 2, VX_EPI_SPLIT>(p, stream);
+    return launch<128, 128, 2, 2, 2, VX_EPI_SPLIT>(p, stream);
   }
   vx_set_error("vx_gemm: unknown epilogue %d", p.epi);
   return VX_ERR_UNSUPPORTED;
