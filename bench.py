@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="override the clip length (default 12*gpus+4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-shapes", default="", help="write the per-shape vx_gemm timing table of the roofline leg here")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -236,6 +237,11 @@ def main():
             pipe.denoise(lat, kps_tokens, audio, timesteps[:1], windows, 3.5)
             pipe.vae.decode_video(lat[:, :, :min(F, 4)].contiguous(), chunk=4)
         summ = prof.summary()
+        if args.gemm_shapes:
+            with open(args.gemm_shapes, "w") as fsh:
+                for (m_, n_, k_, kern), (cnt, sec, fl) in prof.by_shape().items():
+                    fsh.write(f"{m_:8d} {n_:6d} {k_:6d} x{cnt:4d} {1e6 * sec / cnt:9.1f} us {1e3 * sec:8.2f} ms "
+                              f"{fl / sec / 1e12:7.1f} TF/s  {kern}\n")
         tot_s = sum(v["seconds"] for v in summ.values())
         tot_f = sum(v["flops"] for v in summ.values())
         dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 1
+#define VX_ABI_VERSION 2
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
@@ -73,14 +73,20 @@ typedef struct {
 } vx_gemm_params;
 
 int vx_gemm(const vx_gemm_params* p, void* stream);
+/* name of the tile configuration vx_gemm would launch for p (profiling / roofline reports); thread-local storage */
+const char* vx_gemm_config_name(const vx_gemm_params* p);
 
 /* ---- GroupNorm (+SiLU), per-frame statistics, NHWC, optional dual (concat) source --------------------------
  * Replaces F.group_norm via InflatedGroupNorm (modules/resnet.py:20-28; :220-221,:235,:241), Transformer3DModel.norm
  * (modules/transformer_3d.py:124), motion-module norm (modules/motion_module.py:156), conv_norm_out + SiLU
- * (modules/unet_3d.py:571-572).  ws: float32 workspace of vx_groupnorm_ws_floats() elements. */
+ * (modules/unet_3d.py:571-572).  ws: float32 workspace of vx_groupnorm_ws_floats() elements.
+ * out_pad = 0: out is [frames, hw, C].  out_pad = p > 0: out is the interior of a zero-bordered
+ * [frames, H + 2p, W + 2p, C] image (W = width, H = hw / width) whose border the caller keeps zero, so that the
+ * following 3x3 convolution runs as a pad-0 ("valid") conv without bounds checks (vx_gemm fast addressing). */
 int64_t vx_groupnorm_ws_floats(int frames, int slices, int groups);
 int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int frames, int hw, int groups, float eps,
-                 const float* gamma, const float* beta, int silu, void* out, float* ws, int slices, void* stream);
+                 const float* gamma, const float* beta, int silu, void* out, float* ws, int slices, int width,
+                 int out_pad, void* stream);
 
 /* ---- LayerNorm over the channel axis (+ optional additive table: motion-module positional encoding) -------
  * Replaces F.layer_norm (modules/attention.py:329-376 norms via mutual_self_attention.py:176-247;

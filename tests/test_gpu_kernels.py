@@ -162,6 +162,32 @@ def test_groupnorm(ops, frames, hw, c1, c2, groups, silu):
     check(out, ref, f"groupnorm C={c} hw={hw}", rel=8e-3, mx=2 ** -6)
 
 
+@pytest.mark.parametrize("frames,H,W,c1,c2,cout", [(3, 8, 8, 320, 0, 320), (2, 16, 8, 128, 64, 160), (2, 6, 12, 64, 0, 64),
+                                                   (1, 64, 64, 320, 320, 320)])
+def test_groupnorm_padded_output_feeds_pad0_conv(ops, frames, H, W, c1, c2, cout):
+    """GroupNorm(+SiLU) written into the zero-bordered (H+2)x(W+2) image + pad-0 3x3 conv (vx_gemm fast addressing)
+    == GroupNorm + pad-1 conv; the border stays zero and the interior equals the plain output bit for bit."""
+    hw, c = H * W, c1 + c2
+    x1 = (rnd(frames, hw, c1, scale=2.0) + 0.3).to(BF)
+    x2 = rnd(frames, hw, c2, seed=5) if c2 else None
+    gamma, beta = rnd(c, seed=1, dtype=torch.float32) * 0.1 + 1, rnd(c, seed=2, dtype=torch.float32) * 0.1
+    plain = ops.groupnorm(x1, gamma, beta, frames=frames, hw=hw, groups=32, eps=1e-5, silu=True, x2=x2)
+    for _ in range(2):   # twice: the persistent buffer is reused
+        padded = ops.groupnorm(x1, gamma, beta, frames=frames, hw=hw, groups=32, eps=1e-5, silu=True, x2=x2,
+                               pad_hw=(H, W))
+    img = padded.view(frames, H + 2, W + 2, c)
+    assert torch.equal(img[:, 1:-1, 1:-1], plain.view(frames, H, W, c))
+    assert (img[:, 0] == 0).all() and (img[:, -1] == 0).all() and (img[:, :, 0] == 0).all() and (img[:, :, -1] == 0).all()
+    wt = rnd(cout, c, 3, 3, scale=(9 * c) ** -0.5, seed=3)
+    bias = rnd(cout, seed=4, dtype=torch.float32)
+    w2d = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    out = ops.gemm(padded.view(frames * (H + 2) * (W + 2), c), w2d, bias, geom=ops.ConvGeom(frames, H + 2, W + 2, 3, 3, 1, 0))
+    ref = _conv_ref(plain.view(frames, H, W, c), wt, bias, 1, 1, 0)
+    check(out.view(frames, H, W, cout), ref, f"padded GN -> pad-0 conv {c}->{cout}")
+    same = ops.gemm(plain.view(frames * hw, c), w2d, bias, geom=ops.ConvGeom(frames, H, W, 3, 3, 1, 1))
+    assert torch.equal(out, same), "fast (pre-padded) and general conv paths must agree bit for bit"
+
+
 @pytest.mark.parametrize("rows,c", [(100, 64), (257, 320), (64, 640), (33, 1280)])
 def test_layernorm(ops, rows, c):
     x = (rnd(rows, c, scale=1.5) + 0.3).to(BF)

@@ -96,6 +96,7 @@ struct Shape {
   const char* name;
   int nb, h, w, c1, c2, ks, stride, up, n, epi;   // epi: 0 store(+bias), 1 geglu, 2 split(qkv), 3 store + residual
   int per_fwd;                                    // launches of this shape per CFG forward (approximate; for weights)
+  int prepad;                                     // 1: h, w already include a zero border, conv runs with pad 0
 };
 
 static const Shape SHAPES[] = {
@@ -108,6 +109,12 @@ static const Shape SHAPES[] = {
     {"L0 geglu 320>2560", 32, 64, 64, 320, 0, 1, 1, 0, 2560, 1, 10},
     {"L0 ffout 1280>320 +res", 32, 64, 64, 1280, 0, 1, 1, 0, 320, 3, 10},
     {"L0 down s2 320>320", 32, 64, 64, 320, 0, 3, 2, 0, 320, 0, 1},
+    {"L0 conv3x3 320>320 prepad", 32, 66, 66, 320, 0, 3, 1, 0, 320, 0, 0, 1},
+    {"L0 conv3x3 640cat>320 prepad", 32, 66, 66, 320, 320, 3, 1, 0, 320, 0, 0, 1},
+    {"L1 conv3x3 640>640 prepad", 32, 34, 34, 640, 0, 3, 1, 0, 640, 0, 0, 1},
+    {"L2 conv3x3 1280>1280 prepad", 32, 18, 18, 1280, 0, 3, 1, 0, 1280, 0, 0, 1},
+    {"L3 conv3x3 1280>1280 prepad", 32, 10, 10, 1280, 0, 3, 1, 0, 1280, 0, 0, 1},
+    {"VAE 512^2 128>128 prepad", 4, 514, 514, 128, 0, 3, 1, 0, 128, 0, 0, 1},
     // ---- level 1: 32x32, C=640
     {"L1 conv3x3 640>640", 32, 32, 32, 640, 0, 3, 1, 0, 640, 0, 7},
     {"L1 conv3x3 1280cat>640", 32, 32, 32, 640, 640, 3, 1, 0, 640, 0, 2},
@@ -140,7 +147,7 @@ typedef int (*gemm_fn)(const vx_gemm_params*, void*);
 typedef int (*ln_fn)(const void*, int, int, int, float, const float*, const float*, const float*, int, int, void*, int,
                      void*);
 typedef int (*gn_fn)(const void*, int, const void*, int, int, int, int, float, const float*, const float*, int, void*,
-                     float*, int, void*);
+                     float*, int, int, int, void*);
 
 // HBM-bound kernels: LayerNorm / GroupNorm at the UNet sizes; GB/s = algorithmic bytes (LN: read+write; GN: 2 reads +
 // 1 write) / time
@@ -174,9 +181,9 @@ static void norm_bench(void* lib, hipStream_t st, int reps) {
       CK(hipEventElapsedTime(&ms_ln, e0, e1));
     }
     int slices = c.hw / 16 < 1 ? 1 : (c.hw / 16 > 64 ? 64 : c.hw / 16);
-    for (int i = 0; i < 2; ++i) gn(x, c.c, nullptr, 0, c.frames, c.hw, 32, 1e-5f, gamma, beta, 1, y, ws, slices, st);
+    for (int i = 0; i < 2; ++i) gn(x, c.c, nullptr, 0, c.frames, c.hw, 32, 1e-5f, gamma, beta, 1, y, ws, slices, c.hw, 0, st);
     CK(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; ++i) gn(x, c.c, nullptr, 0, c.frames, c.hw, 32, 1e-5f, gamma, beta, 1, y, ws, slices, st);
+    for (int i = 0; i < reps; ++i) gn(x, c.c, nullptr, 0, c.frames, c.hw, 32, 1e-5f, gamma, beta, 1, y, ws, slices, c.hw, 0, st);
     CK(hipEventRecord(e1, st));
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms_gn, e0, e1));
@@ -216,10 +223,10 @@ int main(int argc, char** argv) {
   std::vector<int> sm(NS), sn(NS);
   std::vector<float> ref(NS), got(NS);
   double tot_us = 0, tot_fl = 0;
-  printf("%-28s %8s %6s %6s %9s %8s %9s %s\n", "shape", "M", "N", "K", "us", "TF/s", "maxrelerr", "ok");
+  printf("%-30s %8s %6s %6s %9s %8s %9s %s\n", "shape", "M", "N", "K", "us", "TF/s", "maxrelerr", "ok");
   for (const Shape& s : SHAPES) {
     if (filter && !strstr(s.name, filter)) continue;
-    int pad = s.ks / 2;
+    int pad = s.prepad ? 0 : s.ks / 2;
     int he = s.h << s.up, we = s.w << s.up;
     int ho = (he + 2 * pad - s.ks) / s.stride + 1, wo = (we + 2 * pad - s.ks) / s.stride + 1;
     int cin = s.c1 + s.c2, K = s.ks * s.ks * cin, M = s.nb * ho * wo, N = s.n;
@@ -268,7 +275,7 @@ int main(int argc, char** argv) {
     }
     int rc = gemm(&p, st);
     if (rc != 0) {
-      printf("%-28s launch error %d: %s\n", s.name, rc, lasterr());
+      printf("%-30s launch error %d: %s\n", s.name, rc, lasterr());
       continue;
     }
     CK(hipStreamSynchronize(st));
@@ -309,7 +316,7 @@ int main(int argc, char** argv) {
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     double us = 1e3 * ms / reps, fl = 2.0 * M * N * K;
-    printf("%-28s %8d %6d %6d %9.1f %8.1f %9.2e %s\n", s.name, M, N, K, us, fl / us * 1e-6, maxrel,
+    printf("%-30s %8d %6d %6d %9.1f %8.1f %9.2e %s\n", s.name, M, N, K, us, fl / us * 1e-6, maxrel,
            ok ? "ok" : "MISMATCH");
     fflush(stdout);
     tot_us += us * s.per_fwd;

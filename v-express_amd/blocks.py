@@ -20,12 +20,15 @@ def resnet_block(P, x, frames, H, W, *, groups, eps, temb=None, rows_per_group=0
     temb: fp32 [b, Cout] view = time_emb_proj(silu(emb)) rows (resnet.py:225-233)."""
     hw = H * W
     c1 = x.shape[-1]
-    n = ops.groupnorm(x, P.norm1.g, P.norm1.b, frames=frames, hw=hw, groups=groups, eps=eps, silu=True, x2=skip)
-    g3 = ConvGeom(frames, H, W, 3, 3, 1, 1)
-    h = ops.gemm(n.view(frames * hw, -1), P.conv1.w, P.conv1.b, geom=g3, rowbias=temb, rows_per_group=rows_per_group)
+    # GroupNorm writes into a zero-bordered (H+2)x(W+2) image, so the 3x3 convs are pad-0 convs (vx_gemm fast path)
+    n = ops.groupnorm(x, P.norm1.g, P.norm1.b, frames=frames, hw=hw, groups=groups, eps=eps, silu=True, x2=skip,
+                      pad_hw=(H, W))
+    g3 = ConvGeom(frames, H + 2, W + 2, 3, 3, 1, 0)
+    hp = (H + 2) * (W + 2)
+    h = ops.gemm(n.view(frames * hp, -1), P.conv1.w, P.conv1.b, geom=g3, rowbias=temb, rows_per_group=rows_per_group)
     cout = h.shape[-1]
     n2 = ops.groupnorm(h.view(frames, hw, cout), P.norm2.g, P.norm2.b, frames=frames, hw=hw, groups=groups, eps=eps,
-                       silu=True)
+                       silu=True, pad_hw=(H, W))
     if P.shortcut is not None:
         sc = ops.gemm(x.view(frames * hw, c1), P.shortcut.w, P.shortcut.b,
                       a2=None if skip is None else skip.view(frames * hw, -1))
@@ -33,7 +36,7 @@ def resnet_block(P, x, frames, H, W, *, groups, eps, temb=None, rows_per_group=0
         if skip is not None:
             raise ValueError("concat input needs a conv_shortcut")
         sc = x.view(frames * hw, c1)
-    out = ops.gemm(n2.view(frames * hw, cout), P.conv2.w, P.conv2.b, geom=g3, residual=sc)
+    out = ops.gemm(n2.view(frames * hp, cout), P.conv2.w, P.conv2.b, geom=g3, residual=sc)
     return out.view(frames, hw, cout)
 
 

@@ -18,6 +18,7 @@
 #include "vx_common.h"
 #include "../../include/vexpress_hip.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -512,6 +513,20 @@ bool use_big(const vx_gemm_params& p) {
 }
 
 }  // namespace
+extern "C" const char* vx_gemm_config_name(const vx_gemm_params* pp) {
+  const vx_gemm_params& p = *pp;
+  const bool fast = fast_ok(p);
+  const char* epi = p.epi == VX_EPI_STORE ? "STORE" : (p.epi == VX_EPI_GEGLU ? "GEGLU" : "SPLIT");
+  const char* tile;
+  if (p.epi == VX_EPI_STORE && p.n <= 32) tile = "256x32x64,4w";
+  else if (use_big(p)) tile = "256x320x64,8w";
+  else if (p.epi != VX_EPI_GEGLU && prefer160(p.n)) tile = "128x160x64,4w";
+  else tile = "128x128x64,4w";
+  static thread_local char buf[96];
+  snprintf(buf, sizeof(buf), "gemm_kernel<%s,%s,%s>", tile, epi, fast ? "fast" : "gather");
+  return buf;
+}
+
 extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
   const vx_gemm_params& p = *pp;
   hipStream_t stream = (hipStream_t)stream_;

@@ -158,7 +158,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
                                                               int groups, float eps, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int silu,
                                                               bf16_t* __restrict__ out, int slices, int slice_pix,
-                                                              const float* __restrict__ ws) {
+                                                              const float* __restrict__ ws, int width, int w_shift,
+                                                              int out_pad) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int C = c1 + c2;
   const int frame = blockIdx.x / slices, slice = blockIdx.x % slices;
@@ -206,7 +207,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
   const GnPlan P = gn_plan(x1, c1, x2, c2, hw, frame);
   const int p_begin = slice * slice_pix;
   const int p_end = min(hw, p_begin + slice_pix);
-  bf16_t* const oframe = out + (size_t)frame * hw * C;
+  // out_pad > 0: the destination is the interior of a [frames, H + 2*pad, W + 2*pad, C] image whose border the
+  // caller keeps zero (so the following 3x3 conv needs no bounds checks: vx_gemm FAST path)
+  const int wp = width + 2 * out_pad;
+  const int hp = hw / width + 2 * out_pad;
+  bf16_t* const oframe = out + (size_t)frame * hp * wp * C;
+  auto opix = [&](int px) {
+    if (out_pad == 0) return px;
+    const int y = w_shift >= 0 ? px >> w_shift : px / width;
+    return (y + out_pad) * wp + (px - y * width) + out_pad;
+  };
 #pragma unroll
   for (int u = 0; u < GN_MAX_SETS; ++u) {
     if (P.base[u] == nullptr) continue;
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
       }
-      *reinterpret_cast<uint4*>(oframe + (size_t)px * C + ch) = pack_bf16x8(f);
+      *reinterpret_cast<uint4*>(oframe + (size_t)opix(px) * C + ch) = pack_bf16x8(f);
     };
     int px = p_begin + P.pl;
     for (; px + (GN_UNROLL - 1) * P.pl_count < p_end; px += GN_UNROLL * P.pl_count) {
@@ -361,7 +371,7 @@ extern "C" int64_t vx_groupnorm_ws_floats(int frames, int slices, int groups) {
 
 extern "C" int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int frames, int hw, int groups, float eps,
                             const float* gamma, const float* beta, int silu, void* out, float* ws, int slices,
-                            void* stream_) {
+                            int width, int out_pad, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int C = c1 + c2;
   VX_REQUIRE(x1 != nullptr && out != nullptr && ws != nullptr && gamma != nullptr && beta != nullptr,
@@ -371,6 +381,12 @@ extern "C" int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int 
   VX_REQUIRE(groups > 0 && (C % groups) == 0, "vx_groupnorm: C=%d not divisible by groups=%d", C, groups);
   VX_REQUIRE(C <= 8 * GN_THREADS * GN_MAX_SETS, "vx_groupnorm: C=%d too large", C);
   VX_REQUIRE(frames > 0 && hw > 0 && slices > 0 && slices <= hw, "vx_groupnorm: bad geometry");
+  VX_REQUIRE(out_pad >= 0 && (out_pad == 0 || (width > 0 && hw % width == 0)),
+             "vx_groupnorm: padded output needs the image width (hw=%d width=%d)", hw, width);
+  if (out_pad == 0) width = hw;
+  int w_shift = -1;
+  for (int sft = 0; sft < 31; ++sft)
+    if ((1 << sft) == width) w_shift = sft;
   const int slice_pix = ceil_div(hw, slices);
   const int nchunks = C / 8;
   const int tp = nchunks < GN_THREADS ? nchunks : GN_THREADS;
@@ -385,7 +401,7 @@ extern "C" int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int 
   if (rc) return rc;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(frames * slices), dim3(GN_THREADS), smem_apply, stream,
                      (const bf16_t*)x1, c1, (const bf16_t*)x2, c2, hw, groups, eps, gamma, beta, silu,
-                     (bf16_t*)out, slices, slice_pix, (const float*)ws);
+                     (bf16_t*)out, slices, slice_pix, (const float*)ws, width, w_shift, out_pad);
   return vx_check_launch("vx_groupnorm(apply)");
 }
 

@@ -74,9 +74,11 @@ def _load():
     lib.vx_abi_version.restype = i32
     lib.vx_device_info.argtypes = [i32, C.POINTER(i32)]
     lib.vx_gemm.argtypes = [C.POINTER(GemmParams), vp]
+    lib.vx_gemm_config_name.argtypes = [C.POINTER(GemmParams)]
+    lib.vx_gemm_config_name.restype = C.c_char_p
     lib.vx_groupnorm_ws_floats.restype = i64
     lib.vx_groupnorm_ws_floats.argtypes = [i32, i32, i32]
-    lib.vx_groupnorm.argtypes = [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, i32, vp]
+    lib.vx_groupnorm.argtypes = [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, i32, i32, i32, vp]
     lib.vx_layernorm.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp]
     lib.vx_attention.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp]
     lib.vx_temporal_attention.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp]
@@ -90,9 +92,9 @@ def _load():
     lib.vx_vae_postprocess.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     for name in declared_symbols():
         fn = getattr(lib, name)
-        if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats"):
+        if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name"):
             fn.restype = i32
-    if lib.vx_abi_version() != 1:
+    if lib.vx_abi_version() != 2:
         raise ImportError("libvexpress_hip.so ABI version mismatch")
     return lib
 

@@ -25,7 +25,7 @@ class GemmProfile:
     active = None
 
     def __init__(self):
-        self.records = []          # (start_event, end_event, flops, tile_key)
+        self.records = []          # (start_event, end_event, flops, tile_key, shape)
 
     def __enter__(self):
         GemmProfile.active = self
@@ -37,23 +37,27 @@ class GemmProfile:
     def summary(self):
         torch.cuda.synchronize()
         by = {}
-        for s, e, fl, key in self.records:
+        for s, e, fl, key, _ in self.records:
             d = by.setdefault(key, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += s.elapsed_time(e) * 1e-3
             d[2] += fl
         return {k: dict(launches=v[0], seconds=v[1], flops=v[2]) for k, v in by.items()}
 
+    def by_shape(self):
+        """{(m, n, k, kernel): [launches, seconds, flops]} sorted by time (tools / tuning)."""
+        torch.cuda.synchronize()
+        by = {}
+        for s, e, fl, key, shape in self.records:
+            d = by.setdefault(shape + (key,), [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += s.elapsed_time(e) * 1e-3
+            d[2] += fl
+        return dict(sorted(by.items(), key=lambda kv: -kv[1][1]))
+
 
 def _tile_key(p):
-    if p.epi == L.VX_EPI_GEGLU:
-        return "gemm_kernel<128,128,GEGLU>"
-    if p.epi == L.VX_EPI_STORE and p.n <= 32:
-        return "gemm_kernel<256,32,STORE>"
-    w160 = -(-p.n // 160) * 160 - p.n
-    w128 = -(-p.n // 128) * 128 - p.n
-    tile = "128,160" if w160 * 128 <= w128 * 160 else "128,128"
-    return f"gemm_kernel<{tile},{'STORE' if p.epi == L.VX_EPI_STORE else 'SPLIT'}>"
+    return _lib.vx_gemm_config_name(C.byref(p)).decode()
 
 
 def _launch_gemm(p, what):
@@ -65,7 +69,7 @@ def _launch_gemm(p, what):
     s.record()
     L.check(_lib.vx_gemm(C.byref(p), _stream()), what)
     e.record()
-    prof.records.append((s, e, 2.0 * p.m * p.n * p.k, _tile_key(p)))
+    prof.records.append((s, e, 2.0 * p.m * p.n * p.k, _tile_key(p), (p.m, p.n, p.k)))
 
 
 def _ptr(t):
@@ -211,20 +215,44 @@ def _gn_slices(hw):
     return max(1, min(64, hw // 16))
 
 
-def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=None):
-    """x1: [frames, hw, C1] (+ x2: [frames, hw, C2] channel-concatenated) -> [frames, hw, C1+C2]."""
+_PADDED = {}
+
+
+def padded_buffer(device, frames, H, W, c):
+    """Persistent zero-bordered NHWC image [frames, (H+2)*(W+2), c] per shape.  Only `groupnorm(pad_hw=...)` writes
+    into it (interior pixels only), so the border stays zero for the life of the process; the one buffer per shape
+    is reused stream-ordered (the conv that reads it is enqueued before the next GroupNorm that refills it)."""
+    key = (device, frames, H, W, c)
+    buf = _PADDED.get(key)
+    if buf is None:
+        buf = torch.zeros((frames, (H + 2) * (W + 2), c), device=device, dtype=BF16)
+        _PADDED[key] = buf
+    return buf
+
+
+def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=None, pad_hw=None):
+    """x1: [frames, hw, C1] (+ x2: [frames, hw, C2] channel-concatenated) -> [frames, hw, C1+C2];
+    pad_hw=(H, W): -> the zero-bordered image [frames, (H+2)*(W+2), C] (see `padded_buffer`), to be convolved with
+    ConvGeom(frames, H+2, W+2, 3, 3, 1, pad=0)."""
     _chk_bf16(x1, "x1")
     if not x1.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
         raise ValueError("groupnorm inputs must be contiguous")
     c1 = x1.shape[-1]
     c2 = x2.shape[-1] if x2 is not None else 0
-    if out is None:
+    width, pad = hw, 0
+    if pad_hw is not None:
+        H, W = pad_hw
+        if H * W != hw or out is not None:
+            raise ValueError("pad_hw must factor hw and excludes `out`")
+        out = padded_buffer(x1.device, frames, H, W, c1 + c2)
+        width, pad = W, 1
+    elif out is None:
         out = torch.empty((frames, hw, c1 + c2), device=x1.device, dtype=BF16)
     slices = _gn_slices(hw)
     ws = torch.empty(int(_lib.vx_groupnorm_ws_floats(frames, slices, groups)), device=x1.device,
                      dtype=torch.float32)
     L.check(_lib.vx_groupnorm(_ptr(x1), c1, _ptr(x2), c2, frames, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
-                              int(silu), _ptr(out), _ptr(ws), slices, _stream()), "vx_groupnorm")
+                              int(silu), _ptr(out), _ptr(ws), slices, width, pad, _stream()), "vx_groupnorm")
     return out
 
 

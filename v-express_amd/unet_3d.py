@@ -308,9 +308,10 @@ class UNet3DConditionModel(_UNetBase):
                 x = layer(p, j, blk["attn"], x, skip)
             if blk["sampler"]:
                 x, h_, w_ = B.upsample(P[f"{p}.upsamplers.0"], x, frames, h_, w_)
-        n = ops.groupnorm(x, P.conv_norm_out.g, P.conv_norm_out.b, frames=frames, hw=hw, groups=g, eps=eps, silu=True)
-        return ops.gemm(n.view(frames * hw, -1), P.conv_out.w, P.conv_out.b,
-                        geom=ops.ConvGeom(frames, H, W, 3, 3, 1, 1), out_f32=True)
+        n = ops.groupnorm(x, P.conv_norm_out.g, P.conv_norm_out.b, frames=frames, hw=hw, groups=g, eps=eps, silu=True,
+                          pad_hw=(H, W))
+        return ops.gemm(n.view(frames * (H + 2) * (W + 2), -1), P.conv_out.w, P.conv_out.b,
+                        geom=ops.ConvGeom(frames, H + 2, W + 2, 3, 3, 1, 0), out_f32=True)
 
     # ---- reference call surface
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, kps_features=None,

@@ -109,9 +109,10 @@ class AutoencoderKLDecoder:
             if i != nb - 1:
                 x, H, W = B.upsample(P[f"up.{i}.upsampler"], x, n, H, W)
         hw = H * W
-        nrm = ops.groupnorm(x, P.norm_out.g, P.norm_out.b, frames=n, hw=hw, groups=g, eps=1e-6, silu=True)
-        out = ops.gemm(nrm.view(n * hw, -1), P.conv_out.w, P.conv_out.b, geom=ops.ConvGeom(n, H, W, 3, 3, 1, 1),
-                       out_f32=True)
+        nrm = ops.groupnorm(x, P.norm_out.g, P.norm_out.b, frames=n, hw=hw, groups=g, eps=1e-6, silu=True,
+                            pad_hw=(H, W))
+        out = ops.gemm(nrm.view(n * (H + 2) * (W + 2), -1), P.conv_out.w, P.conv_out.b,
+                       geom=ops.ConvGeom(n, H + 2, W + 2, 3, 3, 1, 0), out_f32=True)
         return out, H, W
 
     def decode(self, z):
