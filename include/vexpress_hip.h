@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 2
+#define VX_ABI_VERSION 3
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
@@ -70,9 +70,16 @@ typedef struct {
   int32_t part_kind[3];      /* VX_PART_ROWS: [m, part_ld] ; VX_PART_VT: [m/seq_len, heads, head_dim, vt_pitch] */
   int32_t part_ld[3];
   int32_t seq_len, head_dim, vt_pitch;
+  /* split-K (STORE only): splitk >= 2 cuts the K loop into that many contiguous slices, each computed by its own
+   * blocks into the float32 workspace splitk_ws[splitk][m][n] (caller-owned, vx_gemm_splitk_ws_bytes()); a second
+   * launch adds the slices in slice order (deterministic) and applies the epilogue.  For tall-K, few-row problems
+   * (the 8x8 level: M = 2048) that would otherwise fill half of the 256 CUs.  0 / 1 = off. */
+  int32_t splitk;
+  void* splitk_ws;
 } vx_gemm_params;
 
 int vx_gemm(const vx_gemm_params* p, void* stream);
+int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk);
 /* name of the tile configuration vx_gemm would launch for p (profiling / roofline reports); thread-local storage */
 const char* vx_gemm_config_name(const vx_gemm_params* p);
 

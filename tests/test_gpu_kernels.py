@@ -53,6 +53,34 @@ def test_gemm_plain(ops, m, n, k):
     check(out, a.float() @ w.float().t() + bias, f"gemm {m}x{n}x{k}")
 
 
+def test_gemm_split_k(ops):
+    """8x8-level problems run split-K (slices summed in slice order by a second launch): parity with the fp32
+    reference, and a half-batch launch is bit-identical to the matching rows of the full one (the split depends on the
+    per-frame geometry, N and K only)."""
+    from v_express_amd import lib as L
+    nb, H, W, cin, cout = 6, 8, 8, 256, 320
+    x = rnd(nb, H + 2, W + 2, cin)
+    wt = rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=1)
+    bias = rnd(cout, seed=2, dtype=torch.float32)
+    res = rnd(nb * H * W, cout, seed=3)
+    w2d = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    g = ops.ConvGeom(nb, H + 2, W + 2, 3, 3, 1, 0)
+    with ops.GemmProfile() as prof:
+        out = ops.gemm(x.view(-1, cin), w2d, bias, geom=g, residual=res, alpha=0.9, act=L.VX_ACT_SILU)
+    assert "splitk" in prof.records[0][3], prof.records[0][3]
+    ref = F.silu(_conv_ref(x, wt, bias, 1, 0, 0)).reshape(nb * H * W, cout) * 0.9 + res.float()
+    check(out, ref, "split-K conv + silu + residual")
+    half = ops.gemm(x[:3].reshape(-1, cin), w2d, bias, geom=ops.ConvGeom(3, H + 2, W + 2, 3, 3, 1, 0),
+                    residual=res[:3 * H * W], alpha=0.9, act=L.VX_ACT_SILU)
+    assert torch.equal(half, out[:3 * H * W])
+    # plain linear under the frame_rows hint, f32 output
+    a, w = rnd(2 * 64, 1280), rnd(320, 1280, scale=1280 ** -0.5, seed=4)
+    with ops.frame_rows(64), ops.GemmProfile() as prof:
+        o2 = ops.gemm(a, w, bias, out_f32=True)
+    assert "splitk" in prof.records[0][3]
+    check(o2, a.float() @ w.float().t() + bias, "split-K linear f32", rel=1e-4, mx=1e-4)
+
+
 def test_gemm_epilogue_options(ops):
     from v_express_amd import lib as L
     m, n, k, grp = 384, 320, 256, 96

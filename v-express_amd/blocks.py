@@ -76,6 +76,12 @@ def _feed_forward(P, h):
 
 
 def spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_ref, w_aud):
+    with ops.frame_rows(H * W):
+        return _spatial_transformer_read(P, x, b=b, f=f, H=H, W=W, heads=heads, groups=groups, ehs=ehs, bank=bank,
+                                         w_ref=w_ref, w_aud=w_aud)
+
+
+def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_ref, w_aud):
     """Transformer3DModel.forward (modules/transformer_3d.py:103-169) with the block forward patched by
     ReferenceAttentionControl in *read* mode (modules/mutual_self_attention.py:176-267).
     x: [b*f, HW, C]; ehs: bf16 [b*f*n_ctx, 768] audio tokens; bank: list over the b batch rows of
@@ -116,6 +122,11 @@ def spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_re
 
 
 def spatial_transformer_write(P, x, *, frames, H, W, heads, groups, ehs):
+    with ops.frame_rows(H * W):
+        return _spatial_transformer_write(P, x, frames=frames, H=H, W=W, heads=heads, groups=groups, ehs=ehs)
+
+
+def _spatial_transformer_write(P, x, *, frames, H, W, heads, groups, ehs):
     """Transformer2DModel.forward (modules/transformer_2d.py:216-399) with the BasicTransformerBlock forward
     patched in *write* mode (modules/mutual_self_attention.py:145-174, FF tail :269-284).
     Returns (output, bank) with bank = norm2(h + attn1(norm1 h)) as [frames*HW, C]."""
@@ -138,6 +149,11 @@ def spatial_transformer_write(P, x, *, frames, H, W, heads, groups, ehs):
 
 
 def motion_module(P, x, *, b, f, H, W, heads, groups):
+    with ops.frame_rows(H * W):
+        return _motion_module(P, x, b=b, f=f, H=H, W=W, heads=heads, groups=groups)
+
+
+def _motion_module(P, x, *, b, f, H, W, heads, groups):
     """VanillaTemporalModule -> TemporalTransformer3DModel.forward (modules/motion_module.py:146-182), one
     TemporalTransformerBlock (:236-259): 2x [LN, +pe, QKV, attention over f, out-proj + residual], LN, GEGLU FF.
     The additive sinusoid table goes through the LayerNorm kernel (pe enters Q, K and V: :365-366)."""

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   const int n_tiles = (p.n + BN - 1) / BN;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int nsplit = (EPI == VX_EPI_STORE && p.splitk > 1) ? p.splitk : 1;
+  const int lid0 = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = lid0 % nsplit, lid = lid0 / nsplit;
   const int tile_m = lid / n_tiles, tile_n = lid - tile_m * n_tiles;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -105,11 +107,20 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
   const int cc = (tid & 7) ^ ((r0 >> 1) & 7);   // K-chunk (8 elements) this thread fetches
   // ---- FAST path state
   uint32_t aoff1[A_IT], aoff2[A_IT], boff[B_IT];
-  int s_ci = 0, s_kx = 0, s_ky = 0, s_kt = 0;   // wave-uniform K position of the next tile to issue
+  // this block's K-tile range (the whole K loop unless split-K)
+  const int nk_total = (p.k + BK - 1) / BK;
+  const int kt_begin = (int)((long)split * nk_total / nsplit), kt_end = (int)((long)(split + 1) * nk_total / nsplit);
+  int s_kt = kt_begin, s_ci, s_kx, s_ky;   // wave-uniform K position of the next tile to issue
+  {
+    const int tap0 = (kt_begin * BK) / cin;
+    s_ci = kt_begin * BK - tap0 * cin;
+    s_ky = tap0 / kw;
+    s_kx = tap0 - s_ky * kw;
+  }
   // ---- general path state
   RowInfo ri[A_IT];
   long wrow[B_IT];   // element offset of weight row n (or -1: beyond N)
-  int kg = cc * 8;   // K position of this thread's chunk, tracked incrementally: k = ((ky*kw)+kx)*cin + ci
+  int kg = kt_begin * BK + cc * 8;   // K position of this thread's chunk, tracked incrementally: k = ((ky*kw)+kx)*cin + ci
   int ky = 0, kx = 0, ci = 0;
   char* const lds_wave = smem + (wave * 8) * 128;   // this wave's 8-row (1 KiB) slab within each RPP-row group
 
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.k + BK - 1) / BK;
+  const int nk = kt_end - kt_begin;
 #pragma unroll
   for (int t = 0; t < STAGES - 1; ++t)
     if (t < nk) issue_tile(t);
@@ -265,6 +276,22 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
   const int lrow = lane & 15, lq = lane >> 4;
   const int wrow0 = m0 + wm * WM, wcol0 = n0 + wn * WN;
 
+  if (EPI == VX_EPI_STORE && nsplit > 1) {
+    // split-K slice: raw fp32 partial sums to the workspace, 16 bytes (4 columns) per lane
+    float* ws = (float*)p.splitk_ws + (size_t)split * p.m * p.n;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = wrow0 + i * 16 + lrow;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = wcol0 + j * 16 + lq * 4;
+        if (m < p.m && n < p.n)
+          *reinterpret_cast<float4*>(ws + (size_t)m * p.n + n) =
+              make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+    return;
+  }
   if constexpr (EPI == VX_EPI_STORE) {
     // Optional addends are fetched in batches of NJ fragments under kernel-uniform branches (clamped addresses for
     // out-of-range rows / columns), so the loads of a row group are in flight together; only stores are predicated.
@@ -442,6 +469,49 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
   }
 }
 
+// Second launch of a split-K GEMM: out = epilogue(sum over slices, in slice order), 4 columns per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const vx_gemm_params p) {
+  const int n4 = p.n >> 2;
+  const long total = (long)p.m * n4;
+  const float* __restrict__ ws = (const float*)p.splitk_ws;
+  const size_t slab = (size_t)p.m * p.n;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
+    float4 a = *reinterpret_cast<const float4*>(ws + (size_t)m * p.n + n);
+    for (int s = 1; s < p.splitk; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(ws + s * slab + (size_t)m * p.n + n);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (p.bias != nullptr) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (p.rowbias != nullptr) {
+      const float4 b =
+          *reinterpret_cast<const float4*>(p.rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld + n);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (p.act == VX_ACT_SILU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+    if (p.residual != nullptr) {
+      const uint2 r2 = *reinterpret_cast<const uint2*>((const bf16_t*)p.residual + (size_t)m * p.ldr + n);
+      v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+      v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+    }
+    if (p.out_f32) {
+      *reinterpret_cast<float4*>((float*)p.out + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      *reinterpret_cast<uint2*>((bf16_t*)p.out + (size_t)m * p.ldc + n) =
+          make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
+  }
+}
+
 template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST>
 int launch_impl(const vx_gemm_params& p, hipStream_t stream) {
   constexpr int stage_bytes = STAGES * (BM + BN) * 128;
@@ -458,9 +528,14 @@ int launch_impl(const vx_gemm_params& p, hipStream_t stream) {
     }
     attr_set = true;
   }
-  long tiles = (long)ceil_div(p.m, BM) * ceil_div(p.n, BN);
+  const int nsplit = (EPI == VX_EPI_STORE && p.splitk > 1) ? p.splitk : 1;
+  long tiles = (long)ceil_div(p.m, BM) * ceil_div(p.n, BN) * nsplit;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(nthreads), smem, stream, p);
-  return vx_check_launch("vx_gemm");
+  int rc = vx_check_launch("vx_gemm");
+  if (rc != 0 || nsplit == 1) return rc;
+  long work = ((long)p.m * (p.n >> 2) + 255) / 256;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(work < 2048 ? work : 2048)), dim3(256), 0, stream, p);
+  return vx_check_launch("vx_gemm(split-K reduce)");
 }
 
 // FAST-path eligibility (see gemm_kernel)
@@ -504,7 +579,7 @@ int forced_cfg() {
   return v;
 }
 bool use_big(const vx_gemm_params& p) {
-  if ((p.n % 320) != 0) return false;
+  if ((p.n % 320) != 0 || p.splitk > 1) return false;   // split-K wants many small tiles
   int f = forced_cfg();
   if (f == CFG_BIG) return true;
   if (f == CFG_SMALL) return false;
@@ -513,6 +588,10 @@ bool use_big(const vx_gemm_params& p) {
 }
 
 }  // namespace
+extern "C" int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk) {
+  return splitk > 1 ? (int64_t)splitk * m * n * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" const char* vx_gemm_config_name(const vx_gemm_params* pp) {
   const vx_gemm_params& p = *pp;
   const bool fast = fast_ok(p);
@@ -523,7 +602,10 @@ extern "C" const char* vx_gemm_config_name(const vx_gemm_params* pp) {
   else if (p.epi != VX_EPI_GEGLU && prefer160(p.n)) tile = "128x160x64,4w";
   else tile = "128x128x64,4w";
   static thread_local char buf[96];
-  snprintf(buf, sizeof(buf), "gemm_kernel<%s,%s,%s>", tile, epi, fast ? "fast" : "gather");
+  if (p.splitk > 1)
+    snprintf(buf, sizeof(buf), "gemm_kernel<%s,%s,%s,splitk%d>", tile, epi, fast ? "fast" : "gather", p.splitk);
+  else
+    snprintf(buf, sizeof(buf), "gemm_kernel<%s,%s,%s>", tile, epi, fast ? "fast" : "gather");
   return buf;
 }
 
@@ -542,6 +624,9 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
   VX_REQUIRE((p.lda1 % 8) == 0 && (p.c2 == 0 || (p.lda2 % 8) == 0), "vx_gemm: lda must be a multiple of 8");
   VX_REQUIRE(p.upsample == 0 || p.upsample == 1, "vx_gemm: upsample must be 0/1");
   VX_REQUIRE(p.stride >= 1 && p.kh >= 1 && p.kw >= 1, "vx_gemm: bad conv geometry");
+  VX_REQUIRE(p.splitk <= 1 || (p.epi == VX_EPI_STORE && p.splitk_ws != nullptr && p.splitk <= 16 &&
+                               p.splitk <= (p.k + BK - 1) / BK),
+             "vx_gemm: split-K needs the STORE epilogue, a workspace and splitk <= min(16, K/64)");
   if (p.epi == VX_EPI_STORE) {
     VX_REQUIRE(p.out != nullptr && (p.ldc % 8) == 0, "vx_gemm: STORE needs out and ldc%%8==0");
     VX_REQUIRE(p.residual == nullptr || (p.ldr % 8) == 0, "vx_gemm: ldr%%8");

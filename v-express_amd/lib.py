@@ -40,6 +40,7 @@ class GemmParams(C.Structure):
         ("part_cols", C.c_int32), ("n_parts", C.c_int32),
         ("part_out", C.c_void_p * 3), ("part_kind", C.c_int32 * 3), ("part_ld", C.c_int32 * 3),
         ("seq_len", C.c_int32), ("head_dim", C.c_int32), ("vt_pitch", C.c_int32),
+        ("splitk", C.c_int32), ("splitk_ws", C.c_void_p),
     ]
 
 
@@ -76,6 +77,8 @@ def _load():
     lib.vx_gemm.argtypes = [C.POINTER(GemmParams), vp]
     lib.vx_gemm_config_name.argtypes = [C.POINTER(GemmParams)]
     lib.vx_gemm_config_name.restype = C.c_char_p
+    lib.vx_gemm_splitk_ws_bytes.argtypes = [i32, i32, i32]
+    lib.vx_gemm_splitk_ws_bytes.restype = i64
     lib.vx_groupnorm_ws_floats.restype = i64
     lib.vx_groupnorm_ws_floats.argtypes = [i32, i32, i32]
     lib.vx_groupnorm.argtypes = [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, i32, i32, i32, vp]
@@ -92,9 +95,10 @@ def _load():
     lib.vx_vae_postprocess.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     for name in declared_symbols():
         fn = getattr(lib, name)
-        if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name"):
+        if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name",
+                        "vx_gemm_splitk_ws_bytes"):
             fn.restype = i32
-    if lib.vx_abi_version() != 2:
+    if lib.vx_abi_version() != 3:
         raise ImportError("libvexpress_hip.so ABI version mismatch")
     return lib
 

@@ -135,9 +135,49 @@ def _base_params(a, w, geom, a2=None):
     return p, geom
 
 
+_SPLITK_WS = {}
+_FRAME_ROWS = [None]
+
+
+class frame_rows:
+    """`with ops.frame_rows(hw):` tells plain (geometry-less) GEMMs how many token rows one frame holds; only the
+    split-K policy reads it (convolutions carry their own geometry)."""
+
+    def __init__(self, hw):
+        self.hw = hw
+
+    def __enter__(self):
+        self.prev = _FRAME_ROWS[0]
+        _FRAME_ROWS[0] = self.hw
+
+    def __exit__(self, *a):
+        _FRAME_ROWS[0] = self.prev
+
+
+def _splitk(p, geom, device, plain):
+    """Split-K factor for the 8x8-level problems (M = frames * 64 rows: half the CUs idle otherwise).  A function of
+    the per-frame geometry, N and K only - never of the number of frames - so a CFG half or a window computed alone
+    sums in the same order as the batched call (bit-identical)."""
+    nk = -(-p.k // 64)
+    hw = _FRAME_ROWS[0] if plain else geom.h_out * geom.w_out
+    if hw is None or hw > 64 or p.k < 1024:
+        return
+    tiles = 16 * -(-p.n // 160)                      # nominal 32-frame launch
+    s = min(-(-512 // tiles), 8, nk // 4)
+    if s < 2:
+        return
+    nbytes = int(_lib.vx_gemm_splitk_ws_bytes(p.m, p.n, s))
+    key = (device, nbytes)
+    ws = _SPLITK_WS.get(key)
+    if ws is None:
+        ws = _SPLITK_WS[key] = torch.empty(nbytes, device=device, dtype=torch.uint8)
+    p.splitk, p.splitk_ws = s, ws.data_ptr()
+
+
 def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L.VX_ACT_NONE, rowbias=None,
          rows_per_group=0, out=None, out_f32=False):
     """out[m, n] = residual + alpha * act(sum_k A[m,k] W[n,k] + bias[n] + rowbias[m // rows_per_group, n])."""
+    plain = geom is None
     p, geom = _base_params(a, w, geom, a2)
     n = p.n
     if out is None:
@@ -157,6 +197,7 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
     p.out, p.ldc, p.out_f32 = out.data_ptr(), ldc, int(out_f32)
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be float32")
+    _splitk(p, geom, a.device, plain)
     _launch_gemm(p, "vx_gemm")
     return out
 
