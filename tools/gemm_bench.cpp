@@ -208,6 +208,26 @@ int main(int argc, char** argv) {
   }
   gemm_fn gemm = (gemm_fn)dlsym(lib, "vx_gemm");
   err_fn lasterr = (err_fn)dlsym(lib, "vx_last_error_string");
+  // optional ablation build (make -C v-express_amd/csrc ablate): ABLATE=0,1,3,4,8,16 times every shape once per flag set
+  typedef int (*abl_fn)(int);
+  abl_fn set_ablate = (abl_fn)dlsym(lib, "vx_gemm_set_ablate");
+  std::vector<int> ablate_list = {0};
+  if (set_ablate && getenv("ABLATE")) {
+    ablate_list.clear();
+    std::string e = getenv("ABLATE");
+    size_t pos = 0;
+    while (pos < e.size()) {
+      ablate_list.push_back(atoi(e.c_str() + pos));
+      size_t c = e.find(',', pos);
+      if (c == std::string::npos) break;
+      pos = c + 1;
+    }
+  }
+  // RING_TRACE=1 (ablation build): dump the slot timestamps of waves 0 / 4 of block 0 of the ring kernel
+  typedef int (*trace_fn)(void*);
+  trace_fn set_trace = (trace_fn)dlsym(lib, "vx_gemm_ring_set_trace");
+  unsigned long long* d_trace = nullptr;
+  if (set_trace && getenv("RING_TRACE")) CK(hipMalloc(&d_trace, 2 * 512 * 8));
   int reps = argc > 2 ? atoi(argv[2]) : 5;
   const char* filter = argc > 3 ? argv[3] : nullptr;
   const int NS = 4096;
@@ -308,16 +328,49 @@ int main(int argc, char** argv) {
       for (int i = 0; i < NS; ++i) maxrel = fmax(maxrel, fabs(ref[i] - got[i]) / (scale + 1e-20));
       ok = maxrel < 1.0 / 128;   // bf16 output rounding: 2^-8 relative to the value, <= 2^-7 of max
     }
-    for (int i = 0; i < 2; ++i) gemm(&p, st);
-    CK(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; ++i) gemm(&p, st);
-    CK(hipEventRecord(e1, st));
-    CK(hipEventSynchronize(e1));
-    float ms;
-    CK(hipEventElapsedTime(&ms, e0, e1));
-    double us = 1e3 * ms / reps, fl = 2.0 * M * N * K;
-    printf("%-30s %8d %6d %6d %9.1f %8.1f %9.2e %s\n", s.name, M, N, K, us, fl / us * 1e-6, maxrel,
-           ok ? "ok" : "MISMATCH");
+    double us = 0, fl = 2.0 * M * N * K;
+    for (size_t ai = 0; ai < ablate_list.size(); ++ai) {
+      if (set_ablate) set_ablate(ablate_list[ai]);
+      for (int i = 0; i < 2; ++i) gemm(&p, st);
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < reps; ++i) gemm(&p, st);
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      double u = 1e3 * ms / reps;
+      if (ai == 0) {
+        us = u;
+        printf("%-30s %8d %6d %6d %9.1f %8.1f %9.2e %s\n", s.name, M, N, K, us, fl / us * 1e-6, maxrel,
+               ok ? "ok" : "MISMATCH");
+      } else {
+        printf("    ablate=%-3d %9.1f us\n", ablate_list[ai], u);
+      }
+    }
+    if (set_ablate) set_ablate(0);
+    if (d_trace) {
+      CK(hipMemset(d_trace, 0, 2 * 512 * 8));
+      set_trace(d_trace);
+      gemm(&p, st);
+      CK(hipStreamSynchronize(st));
+      set_trace(nullptr);
+      std::vector<unsigned long long> tr(1024);
+      CK(hipMemcpy(tr.data(), d_trace, 1024 * 8, hipMemcpyDeviceToHost));
+      if (tr[0]) {
+        // 7 stamps per phase: reads issued, DMA issued, vmcnt waited, lgkmcnt waited, barrier, MFMAs done, barrier
+        for (int g = 0; g < 2; ++g) {
+          printf("  trace wave %d (ticks per phase: rd|dma|vmwait|lgkm|bar|M|bar):\n   ", g * 4);
+          for (int i = 7; i + 6 < 512 && tr[g * 512 + i + 6]; i += 7) {
+            unsigned long long* q = &tr[g * 512 + i];
+            printf(" [%ld|%ld|%ld|%ld|%ld|%ld|%ld]", (long)(q[0] - q[-1]), (long)(q[1] - q[0]), (long)(q[2] - q[1]),
+                   (long)(q[3] - q[2]), (long)(q[4] - q[3]), (long)(q[5] - q[4]), (long)(q[6] - q[5]));
+            if ((i / 7) % 4 == 0) printf("\n   ");
+            if (i >= 7 * 40) break;
+          }
+          printf("\n");
+        }
+      }
+    }
     fflush(stdout);
     tot_us += us * s.per_fwd;
     tot_fl += fl * s.per_fwd;

@@ -16,6 +16,7 @@
 // Epilogue: the MFMAs produce C^T fragments (4 consecutive output columns per lane), stored straight from registers
 // with bias / time-embedding rows / activation / residual fused; only V^T parts are transposed through LDS.
 #include "vx_common.h"
+#include "vx_gemm_common.h"
 #include "../../include/vexpress_hip.h"
 
 #include <stdio.h>
@@ -24,7 +25,14 @@
 
 namespace {
 
-constexpr int BK = 64;
+// Ablation switches (tools/gemm_bench only; compiled in with -DVX_ABLATE, never in the product library):
+//   1 no epilogue stores   2 no bias/rowbias/residual loads   4 no DMA inside the K loop   8 no MFMA   16 no LDS reads
+#ifdef VX_ABLATE
+__device__ int g_ablate = 0;
+#define ABL(bit) ((ablate & (bit)) != 0)
+#else
+#define ABL(bit) false
+#endif
 
 struct RowInfo {
   int pix_base;  // frame * h_in * w_in
@@ -34,26 +42,9 @@ struct RowInfo {
 template <typename T>
 __device__ __forceinline__ T sel3(int i, T a, T b, T c) { return i == 0 ? a : (i == 1 ? b : c); }
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
 // 16 zero bytes: the source of every out-of-range chunk (conv padding, M/N/K tails), so the staging loads are
 // branch-free and can all be in flight at once
 __device__ __attribute__((aligned(16))) const uint4 g_zero16 = {0u, 0u, 0u, 0u};
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// async 16-B global -> LDS copy (global_load_lds_dwordx4): LDS address = wave-uniform base + lane*16
-__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
-}
-
-// XCD-aware block remap (8 XCDs, blocks are dealt round-robin): logical ids that are adjacent run on the same
-// XCD, so the column tiles of one A row-tile share that XCD's L2.  Bijective for any block count.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -79,6 +70,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
   static_assert(NI % NJ == 0, "fragment grouping");
   static_assert(G * (STAGES - 2) < 64, "vmcnt is 6 bits");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef VX_ABLATE
+  const int ablate = __builtin_amdgcn_readfirstlane(g_ablate);
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,7 +116,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
   long wrow[B_IT];   // element offset of weight row n (or -1: beyond N)
   int kg = kt_begin * BK + cc * 8;   // K position of this thread's chunk, tracked incrementally: k = ((ky*kw)+kx)*cin + ci
   int ky = 0, kx = 0, ci = 0;
-  char* const lds_wave = smem + (wave * 8) * 128;   // this wave's 8-row (1 KiB) slab within each RPP-row group
+  const uint32_t lds_wave = lds_addr_of(smem) + (wave * 8) * 128;   // this wave's 8-row (1 KiB) slab within each RPP-row group
 
   if constexpr (FAST) {
     // rows / weight rows beyond M / N are clamped to the last valid one: their products are never stored
@@ -172,8 +166,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
   }
 
   auto issue_tile = [&](int stage) {
-    char* sa = lds_wave + stage * STAGE_BYTES;
-    char* sb = sa + BM * 128;
+    const uint32_t sa = lds_wave + stage * STAGE_BYTES;
+    const uint32_t sb = sa + BM * 128;
     if constexpr (FAST) {
       // wave-uniform: source, its row stride and the tap's byte offset
       const bool first = s_ci < c1;
@@ -181,9 +175,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
                                 : (const char*)(A2 + (s_ci - c1)) + (long)(s_ky * w_in + s_kx) * lda2 * 2;
       const char* bbase = (const char*)Wt + (long)s_kt * (BK * 2);
 #pragma unroll
-      for (int i = 0; i < A_IT; ++i) glds16(abase + (first ? aoff1[i] : aoff2[i]), sa + i * RPP * 128);
+      for (int i = 0; i < A_IT; ++i) glds16_s(abase, first ? aoff1[i] : aoff2[i], sa + i * RPP * 128);
 #pragma unroll
-      for (int i = 0; i < B_IT; ++i) glds16(bbase + boff[i], sb + i * RPP * 128);
+      for (int i = 0; i < B_IT; ++i) glds16_s(bbase, boff[i], sb + i * RPP * 128);
       ++s_kt;
       s_ci += BK;
       if (s_ci >= cin) {
@@ -201,13 +195,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
         bool ok = kval && (unsigned)iy < (unsigned)h_eff && (unsigned)ix < (unsigned)w_eff;
         int pix = ri[i].pix_base + (iy >> up) * w_in + (ix >> up);
         const bf16_t* g = ok ? src + (long)pix * (long)cs : zsrc;
-        glds16(g, sa + i * RPP * 128);
+        glds16_v(g, sa + i * RPP * 128);
       }
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) {
         bool ok = kval && wrow[i] >= 0;
         const bf16_t* g = ok ? Wt + wrow[i] + kg : zsrc;
-        glds16(g, sb + i * RPP * 128);
+        glds16_v(g, sb + i * RPP * 128);
       }
       // advance to the next K-tile
       kg += BK;
@@ -241,11 +235,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + STAGES - 1 < nk) issue_tile(fill);
+    if (kt + STAGES - 1 < nk && !ABL(4)) issue_tile(fill);
     const char* sa = smem + stage * STAGE_BYTES;
     const char* sb = sa + BM * 128;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
+      if (ABL(16)) continue;
       uint4 af[MI];
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -259,7 +254,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j0 + j] = mfma16(bfr[j], af[i], acc[i][j0 + j]);   // D = C^T fragment
+          for (int j = 0; j < NJ; ++j) {
+            if (ABL(8)) {
+              asm volatile("" ::"v"(bfr[j].x), "v"(af[i].x));
+              continue;
+            }
+            acc[i][j0 + j] = mfma16(bfr[j], af[i], acc[i][j0 + j]);   // D = C^T fragment
+          }
       }
     }
     stage = stage + 1 == STAGES ? 0 : stage + 1;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
         nc[j] = min(ncol[j], p.n - 4);
         bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (bias != nullptr) {
+      if (bias != nullptr && !ABL(2)) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const float4*>(bias + nc[j]);
       }
@@ -325,12 +326,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
           rv[j] = make_uint2(0u, 0u);
           rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (resid != nullptr) {
+        if (resid != nullptr && !ABL(2)) {
           const bf16_t* rrow = resid + (size_t)mc * p.ldr;
 #pragma unroll
           for (int j = 0; j < NJ; ++j) rv[j] = *reinterpret_cast<const uint2*>(rrow + nc[j]);
         }
-        if (rowbias != nullptr) {
+        if (rowbias != nullptr && !ABL(2)) {
           const float* rbrow = rowbias + (size_t)(mc / p.rows_per_group) * p.rowbias_ld;
 #pragma unroll
           for (int j = 0; j < NJ; ++j) rb[j] = *reinterpret_cast<const float4*>(rbrow + nc[j]);
@@ -348,7 +349,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
           for (int e = 0; e < 4; ++e) v[e] *= alpha;
           v[0] += __uint_as_float(rv[j].x << 16); v[1] += __uint_as_float(rv[j].x & 0xffff0000u);
           v[2] += __uint_as_float(rv[j].y << 16); v[3] += __uint_as_float(rv[j].y & 0xffff0000u);
-          if (m < p.m && ncol[j] < p.n) {
+          if (ABL(1)) {
+            asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+          } else if (m < p.m && ncol[j] < p.n) {
             if (out_is_f32) {
               *reinterpret_cast<float4*>((float*)p.out + (size_t)m * p.ldc + ncol[j]) =
                   make_float4(v[0], v[1], v[2], v[3]);
@@ -382,6 +385,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (acc[i][j][r] + bh[r]) * gelu_f(acc[i][j + 1][r] + bg[r]);
+        if (ABL(1)) {
+          asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+          continue;
+        }
         *reinterpret_cast<uint2*>((bf16_t*)p.out + (size_t)m * p.ldc + ocol) =
             make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
       }
@@ -539,7 +546,9 @@ int launch_impl(const vx_gemm_params& p, hipStream_t stream) {
 }
 
 // FAST-path eligibility (see gemm_kernel)
-bool fast_ok(const vx_gemm_params& p) {
+bool fast_ok(const vx_gemm_params& p) { return vx_gemm_fast_ok(p); }
+}  // namespace
+bool vx_gemm_fast_ok(const vx_gemm_params& p) {
   static int disabled = -1;
   if (disabled < 0) disabled = getenv("VX_GEMM_NOFAST") != nullptr;
   if (disabled) return false;
@@ -551,6 +560,7 @@ bool fast_ok(const vx_gemm_params& p) {
          (unsigned long long)p.n * p.k * 2ull < (1ull << 32) &&
          (p.h_out - 1) * p.stride + p.kh <= p.h_in && (p.w_out - 1) * p.stride + p.kw <= p.w_in;
 }
+namespace {
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI>
 int launch(const vx_gemm_params& p, hipStream_t stream) {
@@ -588,6 +598,12 @@ bool use_big(const vx_gemm_params& p) {
 }
 
 }  // namespace
+#ifdef VX_ABLATE
+extern "C" int vx_gemm_set_ablate(int flags) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &flags, sizeof(int)) == hipSuccess ? 0 : VX_ERR_HIP;
+}
+#endif
+
 extern "C" int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk) {
   return splitk > 1 ? (int64_t)splitk * m * n * (int64_t)sizeof(float) : 0;
 }
@@ -597,6 +613,7 @@ extern "C" const char* vx_gemm_config_name(const vx_gemm_params* pp) {
   const bool fast = fast_ok(p);
   const char* epi = p.epi == VX_EPI_STORE ? "STORE" : (p.epi == VX_EPI_GEGLU ? "GEGLU" : "SPLIT");
   const char* tile;
+  if (vx_gemm_ring_eligible(p)) return "gemm_ring_kernel<256x320x64,8w,STORE,fast>";
   if (p.epi == VX_EPI_STORE && p.n <= 32) tile = "256x32x64,4w";
   else if (use_big(p)) tile = "256x320x64,8w";
   else if (p.epi != VX_EPI_GEGLU && prefer160(p.n)) tile = "128x160x64,4w";
@@ -631,6 +648,7 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
     VX_REQUIRE(p.out != nullptr && (p.ldc % 8) == 0, "vx_gemm: STORE needs out and ldc%%8==0");
     VX_REQUIRE(p.residual == nullptr || (p.ldr % 8) == 0, "vx_gemm: ldr%%8");
     VX_REQUIRE(p.rowbias == nullptr || p.rows_per_group > 0, "vx_gemm: rows_per_group");
+    if (vx_gemm_ring_eligible(p)) return vx_gemm_ring_launch(p, stream);
     if (p.n <= 32) return launch<256, 32, 4, 1, 2, VX_EPI_STORE>(p, stream);
     if (use_big(p)) return launch<256, 320, 4, 2, 2, VX_EPI_STORE>(p, stream);
     if (prefer160(p.n)) return launch<128, 160, 2, 2, 2, VX_EPI_STORE>(p, stream);

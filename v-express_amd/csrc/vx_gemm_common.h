@@ -1,0 +1,44 @@
+// Pieces shared by the GEMM kernels of libvexpress_hip.so (vx_gemm.hip, vx_gemm_ring.hip).
+#pragma once
+#include "vx_common.h"
+#include "../../include/vexpress_hip.h"
+
+constexpr int BK = 64;   // K-tile depth: one LDS row = 64 bf16 = 128 B = eight 16-B chunks
+
+// XOR swizzle of the 16-B chunks of an LDS row (conflict-free ds_read_b128 fragment reads)
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// Async 16-B global -> LDS copies (global_load_lds_dwordx4): LDS address = M0 (wave-uniform) + lane * 16.
+// Issued through inline asm ON PURPOSE: for the __builtin_amdgcn_global_load_lds form hipcc (ROCm 7.2) tracks the
+// copy as a pending LDS store and puts `s_waitcnt vmcnt(0)` in front of the next LDS read of ANY address, i.e. it
+// drains the prefetch of the next K-tile before the current one is multiplied (seen in the ISA: the "double
+// buffered" loop was serial).  The kernels order DMA -> ds_read themselves (counted s_waitcnt vmcnt + s_barrier),
+// so the compiler must not know about these copies.  Its own vmcnt arithmetic for ordinary loads stays correct:
+// vmcnt retires in order, so unknown older copies only make its waits conservative.
+__device__ __forceinline__ uint32_t lds_addr_of(const void* shared_ptr) {
+  return (uint32_t)(size_t)(__attribute__((address_space(3))) const char*)shared_ptr;
+}
+// wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset
+__device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, uint32_t lds_wave_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave_addr), "v"(voff),
+               "s"(sbase)
+               : "memory", "m0");
+}
+// per-lane 64-bit address
+__device__ __forceinline__ void glds16_v(const void* vaddr, uint32_t lds_wave_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_wave_addr), "v"(vaddr)
+               : "memory", "m0");
+}
+
+// XCD-aware block remap (8 XCDs, blocks are dealt round-robin): logical ids that are adjacent run on the same
+// XCD, so the column tiles of one A row-tile share that XCD's L2.  Bijective for any block count.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// FAST addressing eligibility (see gemm_kernel in vx_gemm.hip)
+bool vx_gemm_fast_ok(const vx_gemm_params& p);
+// persistent ring-staged kernel (vx_gemm_ring.hip)
+bool vx_gemm_ring_eligible(const vx_gemm_params& p);
+int vx_gemm_ring_launch(const vx_gemm_params& p, hipStream_t stream);

@@ -1,0 +1,497 @@
+// Persistent, ring-staged MFMA GEMM / implicit-GEMM convolution for gfx950: the 256 x 320 x 64 tile of vx_gemm.hip
+// re-scheduled so that the matrix pipe never waits for a whole K-tile to arrive.
+//
+//   * one 512-thread workgroup per CU walks a list of output tiles (persistent: tile = block + i * gridDim);
+//     8 waves as 2 (M) x 4 (N), wave tile 128 x 80 = 8 x 5 accumulator fragments (v_mfma_f32_16x16x32_bf16, C^T form);
+//   * a K-tile (256 + 320 rows of 128 B) is staged as nine 8-KiB *pieces* (one global_load_lds_dwordx4 per thread
+//     each): B0..B4 (64 weight rows each) and A0..A3, where A piece p holds the 2 x 32 activation rows that phase p
+//     of both wave rows consumes.  LDS holds two K-tile buffers (144 KiB);
+//   * a K-tile is multiplied in four phases (A rows 32p..32p+31 of the wave x all 80 columns = 20 MFMAs); the B
+//     fragments are read once per K-tile (phase 0) and stay in registers;
+//   * the two wave rows (waves 0-3 / 4-7 = the two waves of every SIMD) run the same slot sequence
+//        L(t,0) M(t,0) L(t,1) M(t,1) L(t,2) M(t,2) L(t,3) M(t,3) ...      (one s_barrier after every slot)
+//     staggered by one slot, so while one wave of a SIMD is in an M slot (20 back-to-back MFMAs at raised priority)
+//     its partner is in an L slot: LDS fragment reads for its next M slot, DMA issue, counted vmcnt wait;
+//   * DMA pieces are issued 1.4 .. 2 K-tiles ahead of their first use, into LDS slots whose last reader finished at
+//     least one slot earlier, across output-tile boundaries (the next tile's first two K-tiles stream in during the
+//     epilogue).  Issue schedule (u = K-tile sequence number of this block, groups g0 = {B0,B1,B2},
+//     g1 = {B3,B4,A0}, g2 = {A1,A2}, g3 = {A3}):
+//         L(t,0): g3 of u = t+1      L(t,1): g0 of t+2      L(t,2): g1 of t+2      L(t,3): g2 of t+2
+//     Waits (end of the L slot, before its barrier; in-order vmcnt, e1 = [t+1 exists], e2 = [t+2 exists]):
+//         L(t,0): A1(t) landed   -> vmcnt(2 + 9 e1)          L(t,1): A2(t)          -> vmcnt(1 + 9 e1 + 3 e2)
+//         L(t,2): A3(t)          -> vmcnt(9 e1 + 6 e2)       L(t,3): g0, g1 of t+1  -> vmcnt(3 e1 + 8 e2)
+//     A piece is read one L slot after the wait that retires it (wait -> barrier -> read), never in the same slot;
+//     an LDS slot is refilled at the earliest one L slot after its last read, and every L slot drains its own
+//     LDS reads (lgkmcnt(0)) before its barrier.  tools/ring_schedule_sim.cpp replays this schedule with random DMA
+//     latencies and checks every read / refill against these rules.
+//   * epilogue: both wave rows re-align (one extra barrier each), then every lane exchanges accumulator columns with
+//     its 16-lane neighbour (v_permlane16_swap) so that it owns 8 consecutive output columns: bias / residual loads
+//     and the output stores are 16 bytes per lane.
+//
+// Eligibility (vx_gemm_ring_eligible): STORE epilogue into bf16, the FAST addressing conditions of vx_gemm.hip
+// (pad 0, no upsample, channel counts multiples of 64, operands < 4 GiB), m % 256 == 0, n % 320 == 0, no split-K.
+#include "vx_common.h"
+#include "vx_gemm_common.h"
+#include "../../include/vexpress_hip.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+namespace {
+
+constexpr int R_BM = 256, R_BN = 320, R_NT = 512;
+constexpr int PIECE = 8192;                 // bytes: 64 rows x 128 B, one 16-B DMA per thread of the block
+constexpr int NB_PIECES = 5, NA_PIECES = 4;
+constexpr int BUF_BYTES = (NB_PIECES + NA_PIECES) * PIECE;   // 73,728
+constexpr int B_OFF = 0, A_OFF = NB_PIECES * PIECE;
+constexpr int R_LDS_BYTES = 2 * BUF_BYTES;  // 147,456
+
+// Compile-time ablation switches (tools/exp_ring_ablate.sh builds one library per mask with -DVX_RING_ABLATE=mask; the
+// product library is built without): 1 no MFMA, 2 no LDS reads (and no MFMA), 4 every tile gathers tile 0's
+// activation rows (all L2 hits), 8 no A copies, 16 no B copies, 32 no epilogue stores
+#ifdef VX_RING_ABLATE
+#define RABL(bit) (((VX_RING_ABLATE) & (bit)) != 0)
+#else
+#define RABL(bit) false
+#endif
+#ifdef VX_RING_TRACE
+// slot timing trace (tools/gemm_bench --trace): waves 0 and 4 of block 0 record s_memtime at every barrier
+__device__ unsigned long long* g_ring_trace = nullptr;
+#define RING_TRACE_MAX 512
+#define RING_STAMP()                                                                   \
+  do {                                                                                 \
+    if (trace != nullptr && trace_n < RING_TRACE_MAX) trace[trace_n++] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define RING_STAMP() do {} while (0)
+#endif
+#define RING_WAIT_VM(N) do { RING_STAMP(); ring_wait_vm<N>(); RING_STAMP(); } while (0)
+
+__device__ __forceinline__ void ring_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int N>
+__device__ __forceinline__ void ring_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void ring_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ float bits_f(uint32_t u) { return __uint_as_float(u); }
+
+// odd 16-lane rows of x <-> even 16-lane rows of y
+__device__ __forceinline__ void swap16(float& x, float& y) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+
+__global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wc = wave & 3;   // wave row (= stagger group) / wave column
+#ifdef VX_RING_TRACE
+  unsigned long long* trace = nullptr;
+  int trace_n = 0;
+  if (g_ring_trace != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4) && (tid & 63) == 0)
+    trace = g_ring_trace + (wave >> 2) * RING_TRACE_MAX;
+#endif
+
+  // ---- this block's output tiles: lb, lb + G, lb + 2G, ...   (column tile fastest, so co-running blocks of an XCD
+  // share activation row tiles through its L2)
+  const int n_tiles = p.n / R_BN;
+  const int total_tiles = (p.m / R_BM) * n_tiles;
+  const int G = gridDim.x;
+  const int lb = xcd_remap(blockIdx.x, G);
+  const int my_tiles = (total_tiles - lb + G - 1) / G;
+  const int nk = p.k >> 6;
+  const int S = my_tiles * nk;   // K-tile sequence length of this block
+
+  const char* __restrict__ A1 = (const char*)p.a;
+  const char* __restrict__ A2 = (const char*)p.a2;
+  const char* __restrict__ Wt = (const char*)p.w;
+  const int cin = p.c1 + p.c2, c1 = p.c1;
+  const int kw = p.kw, kh = p.kh, w_in = p.w_in;
+  const int hw_out = p.h_out * p.w_out;
+  const uint32_t lda1b = (uint32_t)p.lda1 * 2u, lda2b = (uint32_t)p.lda2 * 2u;
+  const bool is_conv = !(kh == 1 && kw == 1 && p.stride == 1 && p.h_in == p.h_out && p.w_in == p.w_out);
+
+  // ---- DMA coordinates: thread (r0, slot) of a piece; the LDS image is lane-linear, so the XOR swizzle is applied to
+  // the K-chunk this thread fetches (slot s of row r holds chunk s ^ ((r >> 1) & 7))
+  const int r0 = tid >> 3;
+  const int cc = (tid & 7) ^ ((r0 >> 1) & 7);
+  const uint32_t lds_wave = lds_addr_of(smem) + wave * 1024;
+  const uint32_t boff = (uint32_t)r0 * (uint32_t)p.k * 2u + (uint32_t)cc * 16u;   // + q * 64 rows (wave-uniform)
+  const long b_piece_stride = (long)p.k * 128;                                       // 64 weight rows
+  // Input pixel of this thread's row in A piece q, RELATIVE to the first row of the output tile.  The eligibility
+  // test guarantees that a 256-row tile is either a whole number of frames or a whole number of image rows of one
+  // frame, so the relative pixel is the same for every tile and only a wave-uniform base changes per tile.
+  uint32_t pixl[NA_PIECES];
+  const uint32_t cc16 = (uint32_t)cc * 16u;
+#pragma unroll
+  for (int q = 0; q < NA_PIECES; ++q) {
+    const int ml = (r0 >> 5) * 128 + 32 * q + (r0 & 31);   // A piece q: rows 32q.. of wave row 0, then of wave row 1
+    if (is_conv) {
+      const int fr = ml / hw_out;
+      const int rem = ml - fr * hw_out;
+      const int oy = rem / p.w_out;
+      const int ox = rem - oy * p.w_out;
+      pixl[q] = (uint32_t)(fr * p.h_in * p.w_in + oy * p.stride * w_in + ox * p.stride);
+    } else {
+      pixl[q] = (uint32_t)ml;
+    }
+  }
+
+  // issue-side position: output tile, K-tile within it, and the (channel chunk, tap) of that K-tile.  K-tiles are
+  // walked channel-chunk-major, taps innermost, so the nine shifted reads of an activation chunk are back to back
+  // (they hit the XCD's L2 instead of travelling from the Infinity Cache nine times).
+  int iss_lid = lb, iss_kt = 0;
+  int s_ci = 0, s_kx = 0, s_ky = 0;
+  const char* bbase_tile = nullptr;
+  long pix0 = 0;   // input pixel of the issue tile's first output row (wave-uniform)
+
+  auto setup_issue_tile = [&]() {
+    const int tile_m = iss_lid / n_tiles, tile_n = iss_lid - tile_m * n_tiles;
+    const int m0 = tile_m * R_BM;
+    bbase_tile = Wt + (long)(tile_n * R_BN) * p.k * 2;
+    if (is_conv) {
+      const int fr = m0 / hw_out;
+      const int rem = m0 - fr * hw_out;
+      const int oy = rem / p.w_out;   // rem % w_out == 0
+      pix0 = (long)fr * p.h_in * p.w_in + (long)oy * p.stride * w_in;
+    } else {
+      pix0 = m0;
+    }
+  };
+
+  // wave-uniform sources of the K-tile at the issue pointer, refreshed once per K-tile (not per copy: the scalar
+  // 64-bit arithmetic would otherwise dominate the L slots)
+  const char* a_cur = nullptr;   // source + channel chunk + (tile origin + tap) * row pitch
+  const char* b_cur = nullptr;   // weights + column tile + K offset
+  uint32_t a_ld = 0;             // row pitch (bytes) of the source that holds this channel chunk
+  auto refresh_issue_bases = [&]() {
+    const bool first = s_ci < c1;
+    a_ld = first ? lda1b : lda2b;
+    a_cur = (first ? A1 + (long)s_ci * 2 : A2 + (long)(s_ci - c1) * 2) +
+            ((RABL(4) ? 0 : pix0) + s_ky * w_in + s_kx) * (long)a_ld;
+    b_cur = bbase_tile + ((long)(s_ky * kw + s_kx) * cin + s_ci) * 2;
+  };
+  const uint32_t bq1 = (uint32_t)b_piece_stride, bq2 = 2u * bq1, bq3 = 3u * bq1, bq4 = 4u * bq1;   // < 4 GiB (fast_ok)
+
+  auto issue_b = [&](uint32_t buf, int q) {
+    const uint32_t qo = q == 0 ? 0u : (q == 1 ? bq1 : (q == 2 ? bq2 : (q == 3 ? bq3 : bq4)));
+    if (RABL(16)) return;
+    glds16_s(b_cur, boff + qo, buf + B_OFF + q * PIECE);
+  };
+  auto issue_a = [&](uint32_t buf, int q) {
+    // pixl < 2^24 and the row pitch < 2^24 bytes (eligibility): one v_mad_u32_u24
+    if (RABL(8)) return;
+    glds16_s(a_cur, __umul24(pixl[q], a_ld) + cc16, buf + A_OFF + q * PIECE);
+  };
+  // group g of the K-tile at the issue pointer, into that K-tile's buffer (sequence parity `par`)
+  auto issue_group = [&](int g, int par) {
+    const uint32_t buf = lds_wave + par * BUF_BYTES;
+    if (g == 0) {
+      issue_b(buf, 0); issue_b(buf, 1); issue_b(buf, 2);
+    } else if (g == 1) {
+      issue_b(buf, 3); issue_b(buf, 4); issue_a(buf, 0);
+    } else if (g == 2) {
+      issue_a(buf, 1); issue_a(buf, 2);
+    } else {
+      issue_a(buf, 3);
+    }
+  };
+  // step the issue pointer to the next K-tile of the sequence (`more`: that K-tile exists)
+  auto advance_issue = [&](bool more) {
+    ++iss_kt;
+    if (++s_kx == kw) {
+      s_kx = 0;
+      if (++s_ky == kh) { s_ky = 0; s_ci += BK; }
+    }
+    if (iss_kt == nk) {
+      iss_kt = 0; s_ci = 0; s_kx = 0; s_ky = 0;
+      iss_lid += G;
+      if (more) setup_issue_tile();
+    }
+    if (more) refresh_issue_bases();
+  };
+
+  // ---- fragment read offsets (bytes within a buffer).  (row >> 1) & 7 == (frow >> 1) & 7 for every fragment row
+  // (piece / wave / fragment bases are multiples of 16 rows), so the swizzle term is per-lane constant.
+  const int frow = lane & 15, fgrp = lane >> 4;
+  const int sw = (frow >> 1) & 7;
+  const int ck0 = ((fgrp ^ sw) << 4), ck1 = (((4 + fgrp) ^ sw) << 4);
+  const int a_rd = A_OFF + (32 * grp + frow) * 128;        // + p * PIECE + s * 2048 + ck
+  const int b_rd = B_OFF + (wc * 80 + frow) * 128;         // + j * 2048 + ck
+
+  f32x4_t acc[8][5];
+  uint4 bfr[5][2], af[2][2];
+
+  // ------------------------------------------------------------------ prologue: K-tiles 0 and 1 of the sequence
+  setup_issue_tile();
+  refresh_issue_bases();
+  issue_group(0, 0); issue_group(1, 0); issue_group(2, 0); issue_group(3, 0);
+  advance_issue(S > 1);
+  if (S > 1) {
+    issue_group(0, 1); issue_group(1, 1); issue_group(2, 1);
+    ring_wait_vm<11>();   // g0, g1 of K-tile 0 landed (younger: g2, g3 of 0 and g0..g2 of 1)
+  } else {
+    ring_wait_vm<3>();
+  }
+  ring_barrier();
+
+  int u = 0;                 // sequence number of the K-tile being multiplied
+  int cmp_lid = lb;          // its output tile
+
+  // one K-tile: four (L slot, barrier, M slot, barrier) phases.  e1 / e2: K-tiles u+1 / u+2 exist in this block's
+  // sequence (wave-uniform; false only for the last two K-tiles of the block)
+  auto ktile = [&](const bool e1, const bool e2) {
+    const int par = u & 1;
+    const char* buf = smem + par * BUF_BYTES;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      // ---------------- L slot
+      if (ph == 0 && !RABL(2)) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          bfr[j][0] = *reinterpret_cast<const uint4*>(buf + b_rd + j * 2048 + ck0);
+          bfr[j][1] = *reinterpret_cast<const uint4*>(buf + b_rd + j * 2048 + ck1);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2 && !RABL(2); ++s) {
+        af[s][0] = *reinterpret_cast<const uint4*>(buf + a_rd + ph * PIECE + s * 2048 + ck0);
+        af[s][1] = *reinterpret_cast<const uint4*>(buf + a_rd + ph * PIECE + s * 2048 + ck1);
+      }
+      RING_STAMP();
+      if (ph == 0) {
+        if (e1) {
+          issue_group(3, par ^ 1);          // A3 of u+1
+          advance_issue(e2);                // -> u+2
+          RING_WAIT_VM(11);
+        } else {
+          RING_WAIT_VM(2);
+        }
+      } else if (ph == 1) {
+        if (e2) {
+          issue_group(0, par);              // u+2 reuses this K-tile's buffer: its B slots were read in L(u,0)
+          RING_WAIT_VM(13);
+        } else if (e1) {
+          RING_WAIT_VM(10);
+        } else {
+          RING_WAIT_VM(1);
+        }
+      } else if (ph == 2) {
+        if (e2) {
+          issue_group(1, par);
+          RING_WAIT_VM(15);
+        } else if (e1) {
+          RING_WAIT_VM(9);
+        } else {
+          RING_WAIT_VM(0);
+        }
+      } else {
+        if (e2) {
+          issue_group(2, par);
+          RING_WAIT_VM(11);
+        } else if (e1) {
+          RING_WAIT_VM(3);
+        } else {
+          RING_WAIT_VM(0);
+        }
+      }
+      ring_wait_lgkm0();
+      RING_STAMP();
+      ring_barrier();
+      RING_STAMP();
+      // ---------------- M slot
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            if (RABL(3)) {
+              asm volatile("" ::"v"(bfr[j][kk].x), "v"(af[s][kk].x));
+              continue;
+            }
+            acc[2 * ph + s][j] = mfma16(bfr[j][kk], af[s][kk], acc[2 * ph + s][j]);
+          }
+      __builtin_amdgcn_s_setprio(0);
+      RING_STAMP();
+      ring_barrier();
+      RING_STAMP();
+    }
+    ++u;
+  };
+
+  const float* __restrict__ bias = p.bias;
+  const float* __restrict__ rowbias = p.rowbias;
+  const bf16_t* __restrict__ resid = (const bf16_t*)p.residual;
+  const bool do_silu = p.act == VX_ACT_SILU;
+  const float alpha = p.alpha;
+  const int lrow = lane & 15, lq = lane >> 4;
+
+  for (int ti = 0; ti < my_tiles; ++ti) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (grp == 1) ring_barrier();   // stagger: wave row 1 runs one slot behind wave row 0
+    for (int kt = 0; kt < nk; ++kt) {
+      ktile(u + 1 < S, u + 2 < S);
+    }
+    if (grp == 0) ring_barrier();   // re-align
+
+    // ---------------------------------------------------------------- epilogue (no barriers, no LDS)
+    // acc[i][j][r] = C[m0 + 128 grp + 16 i + lrow][n0 + 80 wc + 16 j + 4 lq + r].  Pairing fragments (j, j+1) and
+    // swapping the odd 16-lane rows of the first with the even rows of the second gives every lane 8 consecutive
+    // columns of one fragment: [x0..x3 y0..y3] = fragment j + (lq & 1), columns 8 (lq >> 1) .. + 7.  The unpaired
+    // fragment j = 4 is paired over rows instead (i, i+1).
+    {
+      const int tile_m = cmp_lid / n_tiles, tile_n = cmp_lid - tile_m * n_tiles;
+      const int row_base = tile_m * R_BM + 128 * grp + lrow;
+      const int col_base = tile_n * R_BN + 80 * wc + 8 * (lq >> 1);
+      auto finish = [&](float (&v)[8], int m, int n) {
+        // v: 8 consecutive columns n..n+7 of row m
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (bias != nullptr) {
+          b0 = *reinterpret_cast<const float4*>(bias + n);
+          b1 = *reinterpret_cast<const float4*>(bias + n + 4);
+        }
+        if (rowbias != nullptr) {
+          const float* rb = rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld + n;
+          const float4 r0_ = *reinterpret_cast<const float4*>(rb);
+          const float4 r1_ = *reinterpret_cast<const float4*>(rb + 4);
+          b0.x += r0_.x; b0.y += r0_.y; b0.z += r0_.z; b0.w += r0_.w;
+          b1.x += r1_.x; b1.y += r1_.y; b1.z += r1_.z; b1.w += r1_.w;
+        }
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        if (do_silu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= alpha;
+      };
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        // five 8-column items per row pair: (i, j=0|1), (i, j=2|3), (i+1, 0|1), (i+1, 2|3), (i|i+1, 4)
+        float v[5][8];
+        int mrow[5], ncol[5];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int ii = i + (t >> 1), jp = (t & 1) * 2;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[ii][jp][r], y = acc[ii][jp + 1][r];
+            swap16(x, y);
+            v[t][r] = x;
+            v[t][4 + r] = y;
+          }
+          mrow[t] = row_base + 16 * ii;
+          ncol[t] = col_base + 16 * (jp + (lq & 1));
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[i][4][r], y = acc[i + 1][4][r];
+          swap16(x, y);
+          v[4][r] = x;
+          v[4][4 + r] = y;
+        }
+        mrow[4] = row_base + 16 * (i + (lq & 1));
+        ncol[4] = col_base + 64;
+        uint4 rv[5];
+        if (resid != nullptr) {
+#pragma unroll
+          for (int t = 0; t < 5; ++t)
+            rv[t] = *reinterpret_cast<const uint4*>(resid + (size_t)mrow[t] * p.ldr + ncol[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          finish(v[t], mrow[t], ncol[t]);
+          if (resid != nullptr) {
+            float rf[8];
+            unpack_bf16x8(rv[t], rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[t][e] += rf[e];
+          }
+          if (RABL(32)) {
+            asm volatile("" ::"v"(v[t][0]), "v"(v[t][7]));
+            continue;
+          }
+          *reinterpret_cast<uint4*>((bf16_t*)p.out + (size_t)mrow[t] * p.ldc + ncol[t]) = pack_bf16x8(v[t]);
+        }
+      }
+    }
+    cmp_lid += G;
+  }
+}
+
+int g_cu_count = 0;
+
+}  // namespace
+
+#ifdef VX_RING_TRACE
+extern "C" int vx_gemm_ring_set_trace(void* dev_buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_ring_trace), &dev_buf, sizeof(void*)) == hipSuccess ? 0 : VX_ERR_HIP;
+}
+#endif
+
+bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
+  static int mode = -1;   // VX_GEMM_RING: 0 off, 1 short K only, 2 (default) every eligible shape
+  if (mode < 0) {
+    const char* e = getenv("VX_GEMM_RING");
+    mode = (e && !strcmp(e, "0")) ? 0 : ((e && !strcmp(e, "1")) ? 1 : 2);
+  }
+  if (!mode) return false;
+  if (p.epi != VX_EPI_STORE || p.out_f32 || p.splitk > 1) return false;
+  if ((p.m % R_BM) != 0 || (p.n % R_BN) != 0) return false;
+  if ((p.ldc % 8) != 0 || (p.residual != nullptr && (p.ldr % 8) != 0)) return false;
+  if (p.rowbias != nullptr && (p.rowbias_ld % 4) != 0) return false;
+  if (!vx_gemm_fast_ok(p)) return false;
+  if ((long)p.nb * p.h_in * p.w_in >= (1l << 24) || p.lda1 >= (1 << 23) || p.lda2 >= (1 << 23)) return false;   // umul24
+  const int hw_out = p.h_out * p.w_out;
+  // a 256-row tile = whole frames, or whole image rows of one frame (tile-invariant per-thread gather offsets)
+  if (!((R_BM % hw_out) == 0 || ((hw_out % R_BM) == 0 && (R_BM % p.w_out) == 0))) return false;
+  const long tiles = (long)(p.m / R_BM) * (p.n / R_BN);
+  if (tiles < 192) return false;   // fewer tiles than ~3/4 of the CUs: the 128-row tiles of vx_gemm.hip fill the chip better
+  // In isolation (tools/gemm_bench, operands warm in L2 / Infinity Cache) the plain two-stage loop is a few % faster on
+  // long K loops: an LDS-DMA copy issued beside the partner wave's MFMAs costs 2-3x one issued in a burst
+  // (profiles/r01d_ring_ablation.txt).  Inside the model the ring kernel wins on every eligible shape (tap-innermost
+  // K order: 89 % vs 57 % L2 hit rate, 6x less fabric traffic; next tile prefetched under the epilogue): 11.01 vs
+  // 10.64 frames/s.  VX_GEMM_RING=1 restricts it to K <= 1280, =0 disables it.
+  return mode == 2 || p.k <= 1280;
+}
+
+int vx_gemm_ring_launch(const vx_gemm_params& p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       R_LDS_BYTES);
+    if (e != hipSuccess) {
+      vx_set_error("vx_gemm(ring): hipFuncSetAttribute(%d B LDS) failed: %s", R_LDS_BYTES, hipGetErrorString(e));
+      return VX_ERR_HIP;
+    }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    g_cu_count = cus;
+    attr_set = true;
+  }
+  const long tiles = (long)(p.m / R_BM) * (p.n / R_BN);
+  const unsigned grid = (unsigned)(tiles < g_cu_count ? tiles : g_cu_count);
+  hipLaunchKernelGGL(gemm_ring_kernel, dim3(grid), dim3(R_NT), R_LDS_BYTES, stream, p);
+  return vx_check_launch("vx_gemm(ring)");
+}
