@@ -81,6 +81,85 @@ def test_gemm_split_k(ops):
     check(o2, a.float() @ w.float().t() + bias, "split-K linear f32", rel=1e-4, mx=1e-4)
 
 
+def _ring_used(prof):
+    return all("gemm_ring" in r[3] for r in prof.records) and len(prof.records) > 0
+
+
+@pytest.mark.parametrize("m,n,k", [(256 * 96, 640, 320), (256 * 192, 320, 64), (256 * 200, 320, 128),
+                                   (256 * 300, 320, 192), (256 * 64, 960, 1280)])
+def test_gemm_ring_linear(ops, m, n, k):
+    """Persistent ring-staged kernel (vx_gemm_ring.hip): plain linears incl. 1- and 2-K-tile problems and blocks that
+    walk more than one output tile; bias + alpha + in-place residual through the 16-byte permlane epilogue."""
+    a, w = rnd(m, k), rnd(n, k, scale=k ** -0.5, seed=1)
+    bias = rnd(n, seed=2, dtype=torch.float32)
+    res = rnd(m, n, seed=3)
+    h = res.clone()
+    with ops.GemmProfile() as prof:
+        ops.gemm(a, w, bias, residual=h, alpha=0.75, out=h)
+    assert _ring_used(prof), prof.records[0][3]
+    check(h, res.float() + 0.75 * (a.float() @ w.float().t() + bias), f"ring gemm {m}x{n}x{k}")
+    # a launch over the first half of the rows is bit-identical to the matching rows (K order is shape-independent)
+    if (m // 2) % 256 == 0 and (m // 2 // 256) * (n // 320) >= 192:
+        h2 = res[:m // 2].clone()
+        ops.gemm(a[:m // 2], w, bias, residual=h2, alpha=0.75, out=h2)
+        assert torch.equal(h2, h[:m // 2])
+
+
+@pytest.mark.parametrize("m,c", [(256 * 24, 320), (256 * 13, 640)])
+def test_gemm_ring_geglu(ops, m, c):
+    """GEGLU epilogue of the ring kernel (8-row value/gate interleave, permlane32 value/gate pairing, 16-byte stores)."""
+    from v_express_amd import weights as Wt
+    a = rnd(m, c)
+    w = rnd(8 * c, c, scale=c ** -0.5, seed=1)
+    b = rnd(8 * c, seed=2, dtype=torch.float32)
+    with ops.GemmProfile() as prof:
+        out = ops.geglu(a, Wt.geglu_interleave(w), Wt.geglu_interleave(b))
+    assert _ring_used(prof), prof.records[0][3]
+    hg = a.float() @ w.float().t() + b
+    hval, gate = hg.chunk(2, dim=-1)
+    check(out, hval * F.gelu(gate), f"ring geglu c={c}")
+
+
+def test_gemm_ring_store_no_residual(ops):
+    """STORE epilogue without a residual (separate kernel instantiation) + per-tile time-embedding row."""
+    m, n, k, grp = 256 * 96, 640, 192, 256 * 48
+    a, w = rnd(m, k), rnd(n, k, scale=k ** -0.5, seed=1)
+    bias = rnd(n, seed=2, dtype=torch.float32)
+    rowbias = rnd(2, n, seed=3, dtype=torch.float32)
+    with ops.GemmProfile() as prof:
+        out = ops.gemm(a, w, bias, rowbias=rowbias, rows_per_group=grp)
+    assert _ring_used(prof), prof.records[0][3]
+    check(out, a.float() @ w.float().t() + bias + rowbias.repeat_interleave(grp, 0), "ring gemm bias+rowbias")
+
+
+@pytest.mark.parametrize("nb,hh,ww,c1,c2,cout", [(48, 32, 32, 64, 0, 320), (24, 32, 32, 64, 128, 640),
+                                                 (768, 8, 8, 64, 0, 320), (192, 16, 16, 64, 64, 320)])
+def test_gemm_ring_conv(ops, nb, hh, ww, c1, c2, cout):
+    """3x3 convolution over a zero-bordered image (the resnet path) through the ring kernel: tap-innermost K order,
+    dual-source channel concat, time-embedding rows + SiLU; tiles spanning image rows (32x32), one frame (16x16) and
+    four frames (8x8)."""
+    from v_express_amd import lib as L
+    cin = c1 + c2
+    x = torch.zeros(nb, hh + 2, ww + 2, cin, device="cuda", dtype=BF)
+    x[:, 1:-1, 1:-1] = rnd(nb, hh, ww, cin)
+    wt = rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=1)
+    bias = rnd(cout, seed=2, dtype=torch.float32)
+    w2d = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    g = ops.ConvGeom(nb, hh + 2, ww + 2, 3, 3, 1, 0)
+    rows = hh * ww * (nb // 2)
+    rowbias = rnd(2, cout, seed=5, dtype=torch.float32)
+    if c2:
+        x1, x2 = x[..., :c1].contiguous(), x[..., c1:].contiguous()
+        a, a2 = x1.view(-1, c1), x2.view(-1, c2)
+    else:
+        a, a2 = x.view(-1, cin), None
+    with ops.GemmProfile() as prof:
+        out = ops.gemm(a, w2d, bias, geom=g, a2=a2, rowbias=rowbias, rows_per_group=rows, act=L.VX_ACT_SILU)
+    assert _ring_used(prof), prof.records[0][3]
+    ref = _conv_ref(x, wt, bias, 1, 0, 0).reshape(nb * hh * ww, cout) + rowbias.repeat_interleave(rows, 0)
+    check(out, F.silu(ref), f"ring conv {nb}x{hh}x{ww} {c1}+{c2}->{cout}")
+
+
 def test_gemm_epilogue_options(ops):
     from v_express_amd import lib as L
     m, n, k, grp = 384, 320, 256, 96

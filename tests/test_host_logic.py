@@ -114,7 +114,7 @@ def test_weight_relayouts():
     g = torch.Generator().manual_seed(0)
     w = torch.randn(64, 16, generator=g)
     wi = weights.geglu_interleave(w)
-    assert torch.equal(wi[0:16], w[0:16]) and torch.equal(wi[16:32], w[32:48]) and torch.equal(wi[32:48], w[16:32])
+    assert torch.equal(wi[0:8], w[0:8]) and torch.equal(wi[8:16], w[32:40]) and torch.equal(wi[16:24], w[8:16])
     sd = {"c.weight": torch.randn(6, 4, 3, 3, generator=g), "c.bias": torch.randn(6, generator=g)}
     pc = weights.prep_conv(sd, "c", "cpu")
     assert pc.w.shape == (8, 3 * 3 * 8) and pc.b.shape == (8,) and pc.cout == 6

@@ -6,6 +6,9 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-inline-asm -shared"
 for m in 0 1 2 4 6 10 18 26 32 34; do
   /opt/rocm/bin/hipcc $F -DVX_RING_ABLATE=$m vx_gemm.hip vx_gemm_ring.hip vx_norm.hip -x hip vx_api.cpp -o ../../tools/ringlibs/abl$m.so &
 done
+for m in 1 64 65; do
+  /opt/rocm/bin/hipcc $F -DVX_GEMM_ABLATE=$m vx_gemm.hip vx_gemm_ring.hip vx_norm.hip -x hip vx_api.cpp -o ../../tools/ringlibs/cabl$m.so &
+done
 /opt/rocm/bin/hipcc $F -DVX_RING_TRACE vx_gemm.hip vx_gemm_ring.hip vx_norm.hip -x hip vx_api.cpp -o ../../tools/ringlibs/trace.so &
 wait
 ls -la ../../tools/ringlibs

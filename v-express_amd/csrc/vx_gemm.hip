@@ -25,11 +25,12 @@
 
 namespace {
 
-// Ablation switches (tools/gemm_bench only; compiled in with -DVX_ABLATE, never in the product library):
+// Compile-time ablation switches (tools/build_ring_variants.sh builds one library per mask with
+// -DVX_GEMM_ABLATE=mask; never defined for the product library):
 //   1 no epilogue stores   2 no bias/rowbias/residual loads   4 no DMA inside the K loop   8 no MFMA   16 no LDS reads
-#ifdef VX_ABLATE
-__device__ int g_ablate = 0;
-#define ABL(bit) ((ablate & (bit)) != 0)
+//   64 GEGLU without the GELU (value * gate)
+#ifdef VX_GEMM_ABLATE
+#define ABL(bit) (((VX_GEMM_ABLATE) & (bit)) != 0)
 #else
 #define ABL(bit) false
 #endif
@@ -70,9 +71,6 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
   static_assert(NI % NJ == 0, "fragment grouping");
   static_assert(G * (STAGES - 2) < 64, "vmcnt is 6 bits");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef VX_ABLATE
-  const int ablate = __builtin_amdgcn_readfirstlane(g_ablate);
-#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -364,27 +362,37 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
       }
     }
   } else if constexpr (EPI == VX_EPI_GEGLU) {
-    // fragment pairs (2q, 2q+1) hold the value / gate columns of the same 16 output channels
+    // Weight rows are interleaved in blocks of 8 (weights.py: geglu_interleave): columns 0-7 of a 16-column fragment
+    // are the VALUES of 8 output channels, columns 8-15 their GATES, so lanes 0-31 hold values and lanes 32-63 the
+    // matching gates.  v_permlane32_swap over two row blocks (i, i+1) hands lanes 0-31 value and gate of block i and
+    // lanes 32-63 those of block i+1 (every lane works in the GELU); stores are 8 bytes (4 outputs) per lane.
+    static_assert(MI % 2 == 0, "GEGLU pairs row blocks");
     const int nout = p.n / 2;
+    const int orow0 = wrow0 + lrow + 16 * (lane >> 5);
 #pragma unroll
-    for (int j = 0; j < NI; j += 2) {
-      const int ncol = wcol0 + j * 16 + lq * 4;   // interleaved weight row of the first value column
-      if (ncol + 16 >= p.n) continue;
+    for (int j = 0; j < NI; ++j) {
+      const int nfrag = wcol0 + j * 16;            // interleaved weight row of the fragment's first value column
+      const int ocol = nfrag / 2 + 4 * (lq & 1);
+      const bool col_ok = nfrag + 16 <= p.n && ocol < nout;
       float bh[4] = {0.f, 0.f, 0.f, 0.f}, bg[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias != nullptr) {
-        const float4 h4 = *reinterpret_cast<const float4*>(bias + ncol);
-        const float4 g4 = *reinterpret_cast<const float4*>(bias + ncol + 16);
+      if (bias != nullptr && col_ok) {
+        const float4 h4 = *reinterpret_cast<const float4*>(bias + nfrag + 4 * (lq & 1));
+        const float4 g4 = *reinterpret_cast<const float4*>(bias + nfrag + 8 + 4 * (lq & 1));
         bh[0] = h4.x; bh[1] = h4.y; bh[2] = h4.z; bh[3] = h4.w;
         bg[0] = g4.x; bg[1] = g4.y; bg[2] = g4.z; bg[3] = g4.w;
       }
-      const int ocol = (wcol0 + j * 16) / 2 + lq * 4;
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int m = wrow0 + i * 16 + lrow;
-        if (m >= p.m || ocol >= nout) continue;
+      for (int i = 0; i < MI; i += 2) {
         float o[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (acc[i][j][r] + bh[r]) * gelu_f(acc[i][j + 1][r] + bg[r]);
+        for (int r = 0; r < 4; ++r) {
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][r]), __float_as_uint(acc[i + 1][j][r]),
+                                                     false, false);
+          const float val = __uint_as_float(sw[0]) + bh[r], gat = __uint_as_float(sw[1]) + bg[r];
+          o[r] = val * (ABL(64) ? gat : gelu_f(gat));
+        }
+        const int m = orow0 + 16 * i;
+        if (m >= p.m || !col_ok) continue;
         if (ABL(1)) {
           asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
           continue;
@@ -598,11 +606,6 @@ bool use_big(const vx_gemm_params& p) {
 }
 
 }  // namespace
-#ifdef VX_ABLATE
-extern "C" int vx_gemm_set_ablate(int flags) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &flags, sizeof(int)) == hipSuccess ? 0 : VX_ERR_HIP;
-}
-#endif
 
 extern "C" int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk) {
   return splitk > 1 ? (int64_t)splitk * m * n * (int64_t)sizeof(float) : 0;
@@ -613,7 +616,8 @@ extern "C" const char* vx_gemm_config_name(const vx_gemm_params* pp) {
   const bool fast = fast_ok(p);
   const char* epi = p.epi == VX_EPI_STORE ? "STORE" : (p.epi == VX_EPI_GEGLU ? "GEGLU" : "SPLIT");
   const char* tile;
-  if (vx_gemm_ring_eligible(p)) return "gemm_ring_kernel<256x320x64,8w,STORE,fast>";
+  if (vx_gemm_ring_eligible(p))
+    return p.epi == VX_EPI_GEGLU ? "gemm_ring_kernel<256x320x64,8w,GEGLU,fast>" : "gemm_ring_kernel<256x320x64,8w,STORE,fast>";
   if (p.epi == VX_EPI_STORE && p.n <= 32) tile = "256x32x64,4w";
   else if (use_big(p)) tile = "256x320x64,8w";
   else if (p.epi != VX_EPI_GEGLU && prefer160(p.n)) tile = "128x160x64,4w";
@@ -655,7 +659,8 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
     return launch<128, 128, 2, 2, 2, VX_EPI_STORE>(p, stream);
   } else if (p.epi == VX_EPI_GEGLU) {
     VX_REQUIRE(p.out != nullptr && (p.n % 32) == 0 && (p.ldc % 8) == 0,
-               "vx_gemm: GEGLU needs n%%32==0 (16-wide value/gate interleave)");
+               "vx_gemm: GEGLU needs n%%32==0 (value/gate rows interleaved in blocks of 8)");
+    if (vx_gemm_ring_eligible(p)) return vx_gemm_ring_launch(p, stream);
     if (use_big(p)) return launch<256, 320, 4, 2, 2, VX_EPI_GEGLU>(p, stream);
     return launch<128, 128, 2, 2, 2, VX_EPI_GEGLU>(p, stream);
   } else if (p.epi == VX_EPI_SPLIT) {

@@ -92,6 +92,7 @@ __device__ __forceinline__ void swap16(float& x, float& y) {
   y = __uint_as_float(r[1]);
 }
 
+template <int EPI, bool RES>   // RES: STORE epilogue with a residual addend
 __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -353,84 +354,174 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
     if (grp == 0) ring_barrier();   // re-align
 
     // ---------------------------------------------------------------- epilogue (no barriers, no LDS)
-    // acc[i][j][r] = C[m0 + 128 grp + 16 i + lrow][n0 + 80 wc + 16 j + 4 lq + r].  Pairing fragments (j, j+1) and
-    // swapping the odd 16-lane rows of the first with the even rows of the second gives every lane 8 consecutive
-    // columns of one fragment: [x0..x3 y0..y3] = fragment j + (lq & 1), columns 8 (lq >> 1) .. + 7.  The unpaired
-    // fragment j = 4 is paired over rows instead (i, i+1).
-    {
-      const int tile_m = cmp_lid / n_tiles, tile_n = cmp_lid - tile_m * n_tiles;
-      const int row_base = tile_m * R_BM + 128 * grp + lrow;
-      const int col_base = tile_n * R_BN + 80 * wc + 8 * (lq >> 1);
-      auto finish = [&](float (&v)[8], int m, int n) {
-        // v: 8 consecutive columns n..n+7 of row m
-        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-        if (bias != nullptr) {
-          b0 = *reinterpret_cast<const float4*>(bias + n);
-          b1 = *reinterpret_cast<const float4*>(bias + n + 4);
-        }
-        if (rowbias != nullptr) {
-          const float* rb = rowbias + (size_t)(m / p.rows_per_group) * p.rowbias_ld + n;
-          const float4 r0_ = *reinterpret_cast<const float4*>(rb);
-          const float4 r1_ = *reinterpret_cast<const float4*>(rb + 4);
-          b0.x += r0_.x; b0.y += r0_.y; b0.z += r0_.z; b0.w += r0_.w;
-          b1.x += r1_.x; b1.y += r1_.y; b1.z += r1_.z; b1.w += r1_.w;
-        }
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        if (do_silu) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= alpha;
+    // acc[i][j][r] = C[m0 + 128 grp + 16 i + lrow][n0 + 80 wc + 16 j + 4 lq + r].
+    const int tile_m = cmp_lid / n_tiles, tile_n = cmp_lid - tile_m * n_tiles;
+    const int row_base = tile_m * R_BM + 128 * grp + lrow;
+    if constexpr (EPI == VX_EPI_STORE) {
+      // Pairing fragments (j, j+1) and swapping the odd 16-lane rows of the first with the even rows of the second
+      // gives every lane 8 consecutive columns of one fragment: [x0..x3 y0..y3] = fragment j + (lq & 1), columns
+      // 8 (lq >> 1) .. + 7 -> 16-byte residual loads / output stores for fragments 0-3; fragment 4 keeps the native
+      // 4 columns per lane (8 bytes).  Items are walked row-block-major (i, then {01, 23, 4}) so that a wave finishes
+      // the 160 contiguous bytes of an output row within one step (partial lines meet in L2 right away), the lane's
+      // 20 bias values (+ the tile's time-embedding row) are loaded once per tile, and the residual loads run
+      // RES_DEPTH items ahead of their use: the epilogue of a short-K tile is a string of HBM round trips otherwise.
+      constexpr int N_ITEMS = 24, RES_DEPTH = 6;
+      const int col_p = tile_n * R_BN + 80 * wc + 8 * (lq >> 1) + 16 * (lq & 1);   // + 32 t  (pair t = 0, 1)
+      const int col_4 = tile_n * R_BN + 80 * wc + 64 + 4 * lq;
+      const float* rb_row = rowbias != nullptr ? rowbias + (size_t)((tile_m * R_BM) / p.rows_per_group) * p.rowbias_ld
+                                               : nullptr;   // rows_per_group % 256 == 0: one row per tile
+      // byte offsets (32-bit: eligibility bounds m * ld * 2 < 4 GiB) = per-lane base + wave-uniform item part
+      const uint32_t ldr2 = (uint32_t)p.ldr * 2u, ldc2 = (uint32_t)p.ldc * 2u;
+      const uint32_t res_p = (uint32_t)row_base * ldr2 + (uint32_t)col_p * 2u, res_4 = (uint32_t)row_base * ldr2 + (uint32_t)col_4 * 2u;
+      const uint32_t out_p = (uint32_t)row_base * ldc2 + (uint32_t)col_p * 2u, out_4 = (uint32_t)row_base * ldc2 + (uint32_t)col_4 * 2u;
+      // item k: row block i = k / 3, kind = k % 3 (0, 1: fragment pair; 2: fragment 4)
+      auto res_off = [&](int k) {
+        return (k % 3 == 2 ? res_4 : res_p + (uint32_t)(k % 3) * 64u) + (uint32_t)(k / 3) * (16u * ldr2);
       };
+      auto out_off = [&](int k) {
+        return (k % 3 == 2 ? out_4 : out_p + (uint32_t)(k % 3) * 64u) + (uint32_t)(k / 3) * (16u * ldc2);
+      };
+      const char* __restrict__ resb = (const char*)resid;
+      char* __restrict__ outb = (char*)p.out;
+      float bv[2][8], b4[4];
 #pragma unroll
-      for (int i = 0; i < 8; i += 2) {
-        // five 8-column items per row pair: (i, j=0|1), (i, j=2|3), (i+1, 0|1), (i+1, 2|3), (i|i+1, 4)
-        float v[5][8];
-        int mrow[5], ncol[5];
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int ii = i + (t >> 1), jp = (t & 1) * 2;
+        for (int e = 0; e < 8; ++e) bv[t][e] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b4[e] = 0.f;
+      auto add_bias = [&](const float* src) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float4 x0 = *reinterpret_cast<const float4*>(src + col_p + 32 * t);
+          const float4 x1 = *reinterpret_cast<const float4*>(src + col_p + 32 * t + 4);
+          bv[t][0] += x0.x; bv[t][1] += x0.y; bv[t][2] += x0.z; bv[t][3] += x0.w;
+          bv[t][4] += x1.x; bv[t][5] += x1.y; bv[t][6] += x1.z; bv[t][7] += x1.w;
+        }
+        const float4 x4 = *reinterpret_cast<const float4*>(src + col_4);
+        b4[0] += x4.x; b4[1] += x4.y; b4[2] += x4.z; b4[3] += x4.w;
+      };
+      if (bias != nullptr) add_bias(bias);
+      if (rb_row != nullptr) add_bias(rb_row);
+      uint4 rv[N_ITEMS];   // (.x, .y only for the 8-byte items)
+      auto load_res = [&](int k) {
+        if (k % 3 == 2) {
+          const uint2 t2 = *reinterpret_cast<const uint2*>(resb + res_off(k));
+          rv[k] = make_uint4(t2.x, t2.y, 0u, 0u);
+        } else {
+          rv[k] = *reinterpret_cast<const uint4*>(resb + res_off(k));
+        }
+      };
+      if (RES && !RABL(64)) {
+#pragma unroll
+        for (int k = 0; k < RES_DEPTH; ++k) load_res(k);
+      }
+#pragma unroll
+      for (int k = 0; k < N_ITEMS; ++k) {
+        if (RES && !RABL(64) && k + RES_DEPTH < N_ITEMS) load_res(k + RES_DEPTH);
+        const int i = k / 3, kind = k % 3;
+        if (kind == 2) {
+          float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float x = acc[ii][jp][r], y = acc[ii][jp + 1][r];
-            swap16(x, y);
-            v[t][r] = x;
-            v[t][4 + r] = y;
+            v[r] = acc[i][4][r] + b4[r];
+            if (do_silu) v[r] = silu_f(v[r]);
+            v[r] *= alpha;
           }
-          mrow[t] = row_base + 16 * ii;
-          ncol[t] = col_base + 16 * (jp + (lq & 1));
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x = acc[i][4][r], y = acc[i + 1][4][r];
-          swap16(x, y);
-          v[4][r] = x;
-          v[4][4 + r] = y;
-        }
-        mrow[4] = row_base + 16 * (i + (lq & 1));
-        ncol[4] = col_base + 64;
-        uint4 rv[5];
-        if (resid != nullptr) {
-#pragma unroll
-          for (int t = 0; t < 5; ++t)
-            rv[t] = *reinterpret_cast<const uint4*>(resid + (size_t)mrow[t] * p.ldr + ncol[t]);
-        }
-#pragma unroll
-        for (int t = 0; t < 5; ++t) {
-          finish(v[t], mrow[t], ncol[t]);
-          if (resid != nullptr) {
-            float rf[8];
-            unpack_bf16x8(rv[t], rf);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[t][e] += rf[e];
+          if (RES && !RABL(64)) {
+            v[0] += __uint_as_float(rv[k].x << 16); v[1] += __uint_as_float(rv[k].x & 0xffff0000u);
+            v[2] += __uint_as_float(rv[k].y << 16); v[3] += __uint_as_float(rv[k].y & 0xffff0000u);
           }
           if (RABL(32)) {
-            asm volatile("" ::"v"(v[t][0]), "v"(v[t][7]));
+            asm volatile("" ::"v"(v[0]), "v"(v[3]));
             continue;
           }
-          *reinterpret_cast<uint4*>((bf16_t*)p.out + (size_t)mrow[t] * p.ldc + ncol[t]) = pack_bf16x8(v[t]);
+          *reinterpret_cast<uint2*>(outb + out_off(k)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        } else {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[i][2 * kind][r], y = acc[i][2 * kind + 1][r];
+            swap16(x, y);
+            v[r] = x;
+            v[4 + r] = y;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bv[kind][e];
+          if (do_silu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= alpha;
+          if (RES && !RABL(64)) {
+            float rf[8];
+            unpack_bf16x8(rv[k], rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rf[e];
+          }
+          if (RABL(32)) {
+            asm volatile("" ::"v"(v[0]), "v"(v[7]));
+            continue;
+          }
+          *reinterpret_cast<uint4*>(outb + out_off(k)) = pack_bf16x8(v);
+        }
+      }
+    } else {   // VX_EPI_GEGLU
+      // Weight rows are interleaved in blocks of 8 (weights.py: geglu_interleave): columns 16j..16j+7 of a fragment
+      // are the VALUES of output channels 8j'..8j'+7 and columns 16j+8..16j+15 their GATES, i.e. lanes 0-31 hold
+      // values and lanes 32-63 the matching gates.  v_permlane32_swap on the fragments of two row blocks (i, i+1)
+      // gives lanes 0-31 value AND gate of block i, lanes 32-63 those of block i+1: no lane idles in the GELU.
+      // Then the packed results of fragments (j, j+1) are exchanged with v_permlane16_swap for 16-byte stores.
+      const int ocol_base = (tile_n * R_BN + 80 * wc) / 2 + 4 * (lq & 1);    // + 8 j (+ r)
+      const int bcol_base = tile_n * R_BN + 80 * wc + 4 * (lq & 1);         // value bias; gate bias at + 8
+      const int orow = row_base + 16 * (lane >> 5);                          // + 16 i  (i even)
+      bf16_t* __restrict__ outp = (bf16_t*)p.out;
+#pragma unroll
+      for (int jp = 0; jp < 5; jp += 2) {
+        const int nj = jp + 1 < 5 ? 2 : 1;
+        float bval[2][4], bgat[2][4];
+#pragma unroll
+        for (int jj = 0; jj < nj; ++jj) {
+          float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = v4;
+          if (bias != nullptr) {
+            v4 = *reinterpret_cast<const float4*>(bias + bcol_base + 16 * (jp + jj));
+            g4 = *reinterpret_cast<const float4*>(bias + bcol_base + 16 * (jp + jj) + 8);
+          }
+          bval[jj][0] = v4.x; bval[jj][1] = v4.y; bval[jj][2] = v4.z; bval[jj][3] = v4.w;
+          bgat[jj][0] = g4.x; bgat[jj][1] = g4.y; bgat[jj][2] = g4.z; bgat[jj][3] = g4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+          uint32_t pk[2][2];
+#pragma unroll
+          for (int jj = 0; jj < nj; ++jj) {
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][jp + jj][r]),
+                                                         __float_as_uint(acc[i + 1][jp + jj][r]), false, false);
+              const float val = __uint_as_float(sw[0]) + bval[jj][r];   // lanes 0-31: block i, lanes 32-63: block i+1
+              const float gat = __uint_as_float(sw[1]) + bgat[jj][r];
+              o[r] = val * (RABL(64) ? gat : gelu_f(gat));
+            }
+            pk[jj][0] = pack_bf16x2(o[0], o[1]);
+            pk[jj][1] = pack_bf16x2(o[2], o[3]);
+          }
+          const size_t rowoff = (size_t)(orow + 16 * i) * p.ldc;
+          if (RABL(32)) {
+            asm volatile("" ::"v"(pk[0][0]), "v"(pk[0][1]));
+            continue;
+          }
+          if (nj == 2) {
+            // lane (lq & 1) = 0 keeps fragment jp (columns 0-3 own, 4-7 from its odd neighbour), the odd lane takes jp+1
+            auto s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+            auto s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+            const int oc = (tile_n * R_BN + 80 * wc) / 2 + 8 * (jp + (lq & 1));
+            *reinterpret_cast<uint4*>(outp + rowoff + oc) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          } else {
+            *reinterpret_cast<uint2*>(outp + rowoff + ocol_base + 8 * jp) = make_uint2(pk[0][0], pk[0][1]);
+          }
         }
       }
     }
@@ -455,10 +546,14 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
     mode = (e && !strcmp(e, "0")) ? 0 : ((e && !strcmp(e, "1")) ? 1 : 2);
   }
   if (!mode) return false;
-  if (p.epi != VX_EPI_STORE || p.out_f32 || p.splitk > 1) return false;
+  if ((p.epi != VX_EPI_STORE && p.epi != VX_EPI_GEGLU) || p.out_f32 || p.splitk > 1) return false;
   if ((p.m % R_BM) != 0 || (p.n % R_BN) != 0) return false;
   if ((p.ldc % 8) != 0 || (p.residual != nullptr && (p.ldr % 8) != 0)) return false;
-  if (p.rowbias != nullptr && (p.rowbias_ld % 4) != 0) return false;
+  if ((unsigned long long)p.m * p.ldc * 2ull >= (1ull << 32) ||
+      (p.residual != nullptr && (unsigned long long)p.m * p.ldr * 2ull >= (1ull << 32)))
+    return false;   // 32-bit epilogue offsets
+  // the time-embedding row must be the same for all 256 rows of a tile (true whenever frames * hw is a multiple of 256)
+  if (p.rowbias != nullptr && ((p.rowbias_ld % 4) != 0 || (p.rows_per_group % R_BM) != 0)) return false;
   if (!vx_gemm_fast_ok(p)) return false;
   if ((long)p.nb * p.h_in * p.w_in >= (1l << 24) || p.lda1 >= (1 << 23) || p.lda2 >= (1 << 23)) return false;   // umul24
   const int hw_out = p.h_out * p.w_out;
@@ -474,11 +569,12 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
   return mode == 2 || p.k <= 1280;
 }
 
-int vx_gemm_ring_launch(const vx_gemm_params& p, hipStream_t stream) {
+template <int EPI, bool RES>
+static int ring_launch(const vx_gemm_params& p, hipStream_t stream) {
   static bool attr_set = false;
+  auto kern = gemm_ring_kernel<EPI, RES>;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       R_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
     if (e != hipSuccess) {
       vx_set_error("vx_gemm(ring): hipFuncSetAttribute(%d B LDS) failed: %s", R_LDS_BYTES, hipGetErrorString(e));
       return VX_ERR_HIP;
@@ -492,6 +588,11 @@ int vx_gemm_ring_launch(const vx_gemm_params& p, hipStream_t stream) {
   }
   const long tiles = (long)(p.m / R_BM) * (p.n / R_BN);
   const unsigned grid = (unsigned)(tiles < g_cu_count ? tiles : g_cu_count);
-  hipLaunchKernelGGL(gemm_ring_kernel, dim3(grid), dim3(R_NT), R_LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(R_NT), R_LDS_BYTES, stream, p);
   return vx_check_launch("vx_gemm(ring)");
+}
+
+int vx_gemm_ring_launch(const vx_gemm_params& p, hipStream_t stream) {
+  if (p.epi == VX_EPI_GEGLU) return ring_launch<VX_EPI_GEGLU, false>(p, stream);
+  return p.residual != nullptr ? ring_launch<VX_EPI_STORE, true>(p, stream) : ring_launch<VX_EPI_STORE, false>(p, stream);
 }

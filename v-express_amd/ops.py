@@ -203,7 +203,7 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
 
 
 def geglu(a, w_interleaved, bias_interleaved, out=None):
-    """FeedForward first half: h * gelu(g) with value/gate weight rows interleaved in blocks of 16."""
+    """FeedForward first half: h * gelu(g) with value/gate weight rows interleaved in blocks of 8."""
     p, geom = _base_params(a, w_interleaved, None)
     if out is None:
         out = torch.empty((geom.m, p.n // 2), device=a.device, dtype=BF16)

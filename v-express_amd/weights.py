@@ -5,7 +5,7 @@ diffusers AutoencoderKL — SURVEY.md Appendix C).  Re-layouts done once at load
   * conv weights [Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin] ((ky, kx, ci) K order, NHWC implicit GEMM), channel
     padding to multiples of 8 for the 4-channel latent convs;
   * attn1 / temporal to_q,to_k,to_v -> one fused [3C, C] matrix; cross-attention to_k,to_v -> [2C, ctx];
-  * GEGLU `ff.net.0.proj` [8C, C]: value rows and gate rows interleaved in blocks of 16 so that one MFMA
+  * GEGLU `ff.net.0.proj` [8C, C]: value rows and gate rows interleaved in blocks of 8 so that one MFMA
     accumulator fragment pair holds (value, gate) of the same channels;
   * every ResnetBlock3D.time_emb_proj concatenated into one [sum(Cout), 1280] matrix (one GEMM per timestep);
   * weights -> bf16; biases, norm affine parameters and the motion-module sinusoid tables -> fp32.
@@ -84,13 +84,16 @@ def prep_cross_attn(sd, p, device):
                     out=prep_linear(sd, p + ".to_out.0", device))
 
 
+GEGLU_BLOCK = 8   # one 16-column MFMA fragment = 8 value columns + their 8 gate columns (vx_gemm GEGLU epilogue)
+
+
 def geglu_interleave(t):
-    """[8C, ...] (value rows then gate rows) -> blocks of 16 value rows followed by their 16 gate rows."""
+    """[8C, ...] (value rows then gate rows) -> blocks of 8 value rows followed by their 8 gate rows."""
     half = t.shape[0] // 2
     if half % 16:
         raise ValueError(f"GEGLU inner width {half} is not a multiple of 16")
-    v = t[:half].reshape(half // 16, 16, *t.shape[1:])
-    g = t[half:].reshape(half // 16, 16, *t.shape[1:])
+    v = t[:half].reshape(half // GEGLU_BLOCK, GEGLU_BLOCK, *t.shape[1:])
+    g = t[half:].reshape(half // GEGLU_BLOCK, GEGLU_BLOCK, *t.shape[1:])
     return torch.stack([v, g], dim=1).reshape(t.shape).contiguous()
 
 
