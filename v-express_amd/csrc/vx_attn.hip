@@ -18,6 +18,10 @@
 #include "vx_common.h"
 #include "../../include/vexpress_hip.h"
 
+#include <stdlib.h>
+
+#include <type_traits>
+
 namespace {
 
 struct AttnParams {
@@ -260,6 +264,305 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
   return vx_check_launch("vx_attention");
 }
 
+// -------------------------------------------------------------------------------------------------------------
+// attn2_kernel: the same MFMA mapping, re-scheduled around the real bound of the small-head-dim levels.  At d = 40
+// (64x64 level: 4096 x 4096 scores per head) a 64-key tile costs a wave 28 MFMAs (448 cycles) but ~185 VALU
+// instructions for the online softmax (32 of them v_exp_f32): the kernel is VALU-bound, and the old body ran the two
+// streams back to back.  Changes:
+//   * the per-tile VALU overhead that is not softmax is gone: key masking only in a peeled last tile, staging
+//     addresses and validity precomputed (unconditional loads: predicated ones made hipcc serialise them);
+//   * row sums come out of the PV MFMA: row `d` of the V^T tile is all ones (head dims that are not multiples of 16
+//     have spare rows), so O^T[d][q] = sum_k P[q][k] of exactly the bf16 P values that multiply V; no VALU adds;
+//   * the accumulator rescale (and its multiplies) is skipped, wave-uniformly, whenever no running max of the wave
+//     grew in this tile (alpha == 1 for every lane): after the first few tiles that is the common case;
+//   * row max through v_max3_f32 (fmaxf nests fold to it).
+// LDS: single K / V^T buffers; the next tile waits in registers while this one is multiplied (T14 split).
+template <int KK, int DT, int QT, bool ONES>
+__global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
+  constexpr int NV = (DT + 1) / 2;   // V^T chunks per thread per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ks = smem;
+  char* vs = smem + KK * 4096;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  // 1-D grid, XCD-aware: blocks are dealt to the 8 XCDs round-robin, so logical ids that are adjacent (all query
+  // blocks of one (batch, head), then the next head) are mapped onto ONE XCD and its L2 serves the K / V^T re-reads.
+  const int nqb = (p.n_q + 64 * QT - 1) / (64 * QT);
+  int lid;
+  {
+    const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  }
+  const int bh = lid / nqb, qb = lid - bh * nqb;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int kvb = b / p.q_per_kv;
+  const int q0 = qb * (64 * QT) + wave * (16 * QT);
+  const bf16_t* __restrict__ kbase = p.k + (size_t)kvb * p.n_kv * p.ldk + h * p.d;
+  const bf16_t* __restrict__ vbase = p.vt + (size_t)(kvb * p.heads + h) * p.d * p.vt_pitch;
+
+  uint4 qf[QT][KK];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    int qrow = q0 + 16 * qt + i;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      int dcol = 32 * kk + 8 * g;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qrow < p.n_q && dcol < p.d)
+        v = *reinterpret_cast<const uint4*>(p.q + (size_t)(b * p.n_q + qrow) * p.ldq + h * p.d + dcol);
+      qf[qt][kk] = v;
+    }
+  }
+  f32x4_t o[DT][QT];
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = -INFINITY;
+    l_run[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- staging coordinates (loop-invariant): thread -> (key, 16-B channel chunk) of the K tile and (dim row, 8-key
+  // chunk) of the V^T tile.  Chunks beyond the head dim are zero-filled ONCE (the single LDS buffers are never
+  // overwritten there) and row d of V^T is set to ones once.  In the loop every thread loads unconditionally (threads
+  // of a padding chunk re-read chunk 0 / row 0 and just do not store): predicated loads would make hipcc wait for the
+  // previous tile's loads before issuing the next ones.
+  uint32_t kptr[KK];   // element offsets from kbase / vbase (the K / V^T of one (batch, head) span < 4 Gi elements)
+  char* klds[KK];
+  bool kval[KK];
+#pragma unroll
+  for (int s = 0; s < KK; ++s) {
+    const int idx = tid + 256 * s;
+    const int key = idx / (4 * KK), c = idx % (4 * KK);
+    kval[s] = c * 8 < p.d;
+    kptr[s] = (uint32_t)key * (uint32_t)p.ldk + (kval[s] ? c * 8 : 0);
+    klds[s] = ks + k_lds_off(c >> 2, key, c & 3);
+    if (!kval[s]) *reinterpret_cast<uint4*>(klds[s]) = make_uint4(0, 0, 0, 0);
+  }
+  uint32_t vptr[NV];
+  char* vlds[NV];
+  bool vval[NV];
+#pragma unroll
+  for (int s = 0; s < NV; ++s) {
+    const int idx = tid + 256 * s;
+    const int row = idx >> 3, j = idx & 7;
+    vval[s] = row < p.d;
+    vptr[s] = (uint32_t)(vval[s] ? row : 0) * (uint32_t)p.vt_pitch + j * 8;
+    vlds[s] = vs + v_lds_off(row, j);
+    if (!vval[s] && row < DT * 16)
+      *reinterpret_cast<uint4*>(vlds[s]) = (ONES && row == p.d)
+                                               ? make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u)
+                                               : make_uint4(0, 0, 0, 0);
+  }
+  const uint32_t kstep = 64u * (uint32_t)p.ldk;   // elements per key tile
+  const int n_tiles = (p.n_kv + 63) >> 6;
+  const bool ragged = (p.n_kv & 63) != 0;    // the last tile has keys beyond n_kv
+
+  uint4 rk[KK], rv[NV];
+  // tile `t` -> registers.  `edge`: the tile reaches beyond n_kv; those keys re-read the last valid key / the first
+  // key chunk instead (finite values: their scores are masked to -inf, so P = 0 exactly and 0 * V stays 0).
+  // (value-returning helpers + plain unrolled loops at the call sites: arrays written through a by-reference lambda
+  // ended up in scratch memory)
+  auto load_k1 = [&](int t, int s, bool edge) -> uint4 {
+    uint32_t off = kptr[s] + (uint32_t)t * kstep;
+    if (edge) {
+      const int key = (tid + 256 * s) / (4 * KK);
+      const int over = t * 64 + key - (p.n_kv - 1);
+      if (over > 0) off -= (uint32_t)over * (uint32_t)p.ldk;
+    }
+    return *reinterpret_cast<const uint4*>(kbase + off);
+  };
+  auto load_v1 = [&](int t, int s, bool edge) -> uint4 {
+    uint32_t off = vptr[s] + (uint32_t)t * 64u;
+    if (edge) {
+      const int j = (tid + 256 * s) & 7;
+      if (t * 64 + j * 8 >= p.n_kv) off = vptr[s] - j * 8;   // chunk 0 of the row
+    }
+    return *reinterpret_cast<const uint4*>(vbase + off);
+  };
+#define VX_ATTN2_LOAD(t_, edge_)                                      \
+  do {                                                                \
+    _Pragma("unroll") for (int s_ = 0; s_ < KK; ++s_) rk[s_] = load_k1((t_), s_, (edge_)); \
+    _Pragma("unroll") for (int s_ = 0; s_ < NV; ++s_) rv[s_] = load_v1((t_), s_, (edge_)); \
+  } while (0)
+#define VX_ATTN2_STORE()                                              \
+  do {                                                                \
+    _Pragma("unroll") for (int s_ = 0; s_ < KK; ++s_)                 \
+      if (kval[s_]) *reinterpret_cast<uint4*>(klds[s_]) = rk[s_];     \
+    _Pragma("unroll") for (int s_ = 0; s_ < NV; ++s_)                 \
+      if (vval[s_]) *reinterpret_cast<uint4*>(vlds[s_]) = rv[s_];     \
+  } while (0)
+  auto qk = [&](f32x4_t (&s_)[4][QT]) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) s_[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        uint4 kf = *reinterpret_cast<const uint4*>(ks + k_lds_off(kk, 16 * kt + i, g));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s_[kt][qt] = mfma16(kf, qf[qt][kk], s_[kt][qt]);
+      }
+    }
+  };
+
+  // prologue: K(0), V(0) -> LDS
+  VX_ATTN2_LOAD(0, n_tiles == 1 && ragged);
+  VX_ATTN2_STORE();
+  __syncthreads();
+
+  // one key tile.  MASK: tile t reaches beyond n_kv.
+  auto step = [&](auto mask_c, const int t) {
+    constexpr bool MASK = decltype(mask_c)::value;
+    // registers <- K(t+1), V(t+1)   (written to LDS after this tile's MFMAs: T14 issue-early / write-late)
+    if (t + 1 < n_tiles) {
+      const bool edge = ragged && t + 1 == n_tiles - 1;
+      VX_ATTN2_LOAD(t + 1, edge);
+    }
+    f32x4_t cur[4][QT];
+    qk(cur);
+    if (MASK) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (t * 64 + 16 * kt + 4 * g + r >= p.n_kv) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) cur[kt][qt][r] = -INFINITY;
+          }
+        }
+    }
+    float alpha[QT];
+    bool grew = false;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float mx = fmaxf(fmaxf(cur[0][qt][0], cur[0][qt][1]), cur[0][qt][2]);
+      mx = fmaxf(fmaxf(mx, cur[0][qt][3]), cur[1][qt][0]);
+      mx = fmaxf(fmaxf(mx, cur[1][qt][1]), cur[1][qt][2]);
+      mx = fmaxf(fmaxf(mx, cur[1][qt][3]), cur[2][qt][0]);
+      mx = fmaxf(fmaxf(mx, cur[2][qt][1]), cur[2][qt][2]);
+      mx = fmaxf(fmaxf(mx, cur[2][qt][3]), cur[3][qt][0]);
+      mx = fmaxf(fmaxf(mx, cur[3][qt][1]), cur[3][qt][2]);
+      mx = fmaxf(mx, cur[3][qt][3]);
+      mx = wave_xor_max(mx, 16);
+      mx = wave_xor_max(mx, 32);
+      const float mnew = fmaxf(m_run[qt], mx * p.c);
+      grew |= mnew > m_run[qt];
+      alpha[qt] = __builtin_amdgcn_exp2f(m_run[qt] - mnew);
+      m_run[qt] = mnew;
+      float rs = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pv = __builtin_amdgcn_exp2f(fmaf(cur[kt][qt][r], p.c, -mnew));
+          if (!ONES) rs += pv;
+          cur[kt][qt][r] = pv;
+        }
+      if (!ONES) l_run[qt] = l_run[qt] * alpha[qt] + rs;   // (partial over g; reduced at the end)
+    }
+    if (__any(grew)) {   // wave-uniform: some running max moved -> rescale the accumulators (and the sums in them)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          o[dt][qt][0] *= alpha[qt]; o[dt][qt][1] *= alpha[qt]; o[dt][qt][2] *= alpha[qt]; o[dt][qt][3] *= alpha[qt];
+        }
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int ks_ = 0; ks_ < 2; ++ks_) {
+      uint4 pb[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const f32x4_t& a = cur[2 * ks_][qt];
+        const f32x4_t& c2 = cur[2 * ks_ + 1][qt];
+        pb[qt] = make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(c2[0], c2[1]),
+                            pack_bf16x2(c2[2], c2[3]));
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        int row = 16 * dt + i;
+        int j1 = 4 * ks_ + (g >> 1);
+        const uint2 v1 = *reinterpret_cast<const uint2*>(vs + v_lds_off(row, j1) + (g & 1) * 8);
+        const uint2 v2 = *reinterpret_cast<const uint2*>(vs + v_lds_off(row, j1 + 2) + (g & 1) * 8);
+        uint4 vf = make_uint4(v1.x, v1.y, v2.x, v2.y);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[dt][qt] = mfma16(vf, pb[qt], o[dt][qt]);
+      }
+    }
+    // LDS <- K(t+1), V(t+1)
+    __syncthreads();
+    if (t + 1 < n_tiles) VX_ATTN2_STORE();
+    __syncthreads();
+  };
+
+  {
+    const int n_plain = ragged ? n_tiles - 1 : n_tiles;   // tiles that need no key masking
+    for (int t = 0; t < n_plain; ++t) step(std::false_type{}, t);
+    if (ragged) step(std::true_type{}, n_tiles - 1);
+  }
+
+  // ---- normalise and store: lane holds 4 consecutive d-columns of one query
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float l;
+    if (ONES) {
+      // O^T[d][query i] lives in fragment d / 16, lane group (d % 16) / 4, register d % 4
+      const int dd = p.d;
+      float mine = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * dt + r == dd - 4 * ((dd & 15) >> 2)) mine = o[dt][qt][r];
+      l = __shfl(mine, i + 16 * ((dd & 15) >> 2), 64);
+    } else {
+      l = l_run[qt];
+      l = wave_xor_sum(l, 16);
+      l = wave_xor_sum(l, 32);
+    }
+    float inv = 1.0f / l;
+    int qrow = q0 + 16 * qt + i;
+    if (qrow >= p.n_q) continue;
+    bf16_t* orow = p.out + (size_t)(b * p.n_q + qrow) * p.ldo + h * p.d;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      int dcol = 16 * dt + 4 * g;
+      if (dcol < p.d) {
+        uint2 w;
+        w.x = pack_bf16x2(o[dt][qt][0] * inv, o[dt][qt][1] * inv);
+        w.y = pack_bf16x2(o[dt][qt][2] * inv, o[dt][qt][3] * inv);
+        *reinterpret_cast<uint2*>(orow + dcol) = w;
+      }
+    }
+  }
+}
+
+#undef VX_ATTN2_LOAD
+#undef VX_ATTN2_STORE
+
+template <int KK, int DT, int QT, bool ONES>
+int launch_attn2(const AttnParams& p, hipStream_t stream) {
+  constexpr int smem = KK * 4096 + DT * 2048;
+  auto kern = attn2_kernel<KK, DT, QT, ONES>;
+  static bool attr_set = false;
+  if (!attr_set && smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      vx_set_error("vx_attention: hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e));
+      return VX_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((long)ceil_div(p.n_q, 64 * QT) * p.batch * p.heads));
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
+  return vx_check_launch("vx_attention");
+}
+
 // -------------------------------------------------------------------------------------------- temporal attention
 struct TemporalParams {
   const bf16_t* qkv; int ldqkv;
@@ -487,6 +790,11 @@ extern "C" int vx_attention(const void* q, int ldq, const void* k, int ldk, cons
   AttnParams p{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)vt, vt_pitch, (bf16_t*)out, ldo,
                batch, heads, n_q, n_kv, head_dim, q_per_kv, scale * 1.4426950408889634f};
   const int d = head_dim;
+  static int v1 = -1;
+  if (v1 < 0) v1 = getenv("VX_ATTN_V1") != nullptr;
+  // attn2: the software-pipelined kernel; instantiated for the head dims whose register budget fits two S tiles
+  // (d = 40: the 64x64 level, 85 % of the attention time).  Other head dims keep the plain kernel.
+  if (!v1 && d > 32 && d <= 48 && (d % 16) != 0) return launch_attn2<2, 3, 2, true>(p, stream);
   if (d <= 32) return launch_attn<1, 2, 4, true>(p, stream);
   if (d <= 48) return launch_attn<2, 3, 2, true>(p, stream);
   if (d <= 64) return launch_attn<2, 4, 2, true>(p, stream);
