@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 3
+#define VX_ABI_VERSION 4
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
@@ -37,7 +37,7 @@ int vx_device_info(int device, int* out4);
  */
 enum { VX_EPI_STORE = 0, VX_EPI_GEGLU = 1, VX_EPI_SPLIT = 2 };
 enum { VX_PART_ROWS = 0, VX_PART_VT = 1 };
-enum { VX_ACT_NONE = 0, VX_ACT_SILU = 1 };
+enum { VX_ACT_NONE = 0, VX_ACT_SILU = 1, VX_ACT_GELU = 2 };   /* GELU = erf form (nn.GELU default) */
 
 typedef struct {
   /* A operand: up to two channel-concatenated NHWC sources (a2 may be NULL) */
@@ -146,6 +146,11 @@ int vx_nhwc_to_ncfhw(const float* x, int ld, int b, int c, int f, int hw, float*
 /* VAE post-process: NHWC float32 [n, hw, ld] -> clamp(x/2+0.5, 0, 1) as [n, 3, hw] float32
  * (pipelines/v_express_pipeline.py:160). */
 int vx_vae_postprocess(const float* x, int ld, int n, int c, int hw, float* out, void* stream);
+/* 3x3x3 median over (frame, y, x) with reflect padding + optional uint8 packing of the result.
+ * Replaces pipelines/utils.py:46-61 (median_filter_3d, kernel_size 3) and the (video*255).astype(uint8) + HWC
+ * permute of save_video (:70-73).  video: float32 [c, f, h, w]; out_f32: float32 [c, f, h, w] or NULL;
+ * out_u8: uint8 [f, h, w, c] or NULL. */
+int vx_median3d(const float* video, int c, int f, int h, int w, float* out_f32, void* out_u8, void* stream);
 
 #ifdef __cplusplus
 }

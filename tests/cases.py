@@ -30,3 +30,23 @@ def unet_cfg(kw):
 def oracle_cfg(kw):
     import oracle
     return oracle.UNetConfig(**kw)
+
+
+# ---- once-per-clip prologue / post-processing: seeded inputs shared by make_golden.py,
+# the oracle tests and the GPU parity tests
+KPS_SMALL = dict(conditioning_embedding_channels=64, block_out_channels=(16, 32, 48, 64))
+AUDIO_SMALL = dict(dim=128, depth=2, dim_head=16, heads=8, num_queries=5, embedding_dim=96, output_dim=128,
+                   max_seq_len=10)
+
+
+def prologue_inputs(seed=11):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    return dict(
+        kps_images=torch.rand(1, 3, 3, 64, 48, generator=g),            # [b, 3, f, H, W] in [0, 1]
+        audio_windows_small=torch.randn(4, 10, 96, generator=g),       # [F, 2*(2*pad+1), d]
+        audio_windows_full=torch.randn(3, 10, 768, generator=g),
+        wav2vec_states=torch.randn(1, 37, 96, generator=g),            # [1, T, d] "last_hidden_state"
+        ref_image=torch.rand(1, 3, 64, 48, generator=g) * 2 - 1,        # [-1, 1]
+        video=torch.rand(3, 5, 12, 10, generator=g),                    # [C, F, H, W] in [0, 1]
+    )

@@ -15,10 +15,54 @@ import refharness as H  # noqa: E402
 from v_express_amd import synth  # noqa: E402
 
 
+def prologue(out):
+    """Reference outputs of the once-per-clip prologue and the median filter."""
+    import types
+    import ref_import as R
+    modules, _ = R.import_reference()
+    import diffusers   # the stand-in (on sys.path after import_reference)
+    U = R.import_reference_utils()
+    from pipelines.v_express_pipeline import VExpressPipeline
+    inp = cases.prologue_inputs()
+    g = {}
+    for tag, kw in (("small", cases.KPS_SMALL), ("full", {})):
+        kcfg = synth.KpsGuiderConfig(**kw)
+        ref = modules.VKpsGuider(kcfg.conditioning_embedding_channels, block_out_channels=kcfg.block_out_channels)
+        ref.load_state_dict(synth.kps_guider_state_dict(kcfg), strict=True)
+        with torch.no_grad():
+            g[f"kps_{tag}"] = ref(inp["kps_images"]).clone()
+    for tag, kw, key in (("small", cases.AUDIO_SMALL, "audio_windows_small"), ("full", {}, "audio_windows_full")):
+        acfg = synth.AudioProjectionConfig(**kw)
+        ref = modules.AudioProjection(dim=acfg.dim, depth=acfg.depth, dim_head=acfg.dim_head, heads=acfg.heads,
+                                      num_queries=acfg.num_queries, embedding_dim=acfg.embedding_dim,
+                                      output_dim=acfg.output_dim, ff_mult=acfg.ff_mult, max_seq_len=acfg.max_seq_len)
+        ref.load_state_dict(synth.audio_projection_state_dict(acfg), strict=True)
+        with torch.no_grad():
+            g[f"audio_{tag}"] = ref(inp[key]).clone()
+    vcfg = synth.VaeConfig(**cases.SMALL_VAE)
+    vae = diffusers.AutoencoderKL(block_out_channels=vcfg.block_out_channels, layers_per_block=vcfg.layers_per_block,
+                                  norm_num_groups=vcfg.norm_num_groups, latent_channels=vcfg.latent_channels)
+    vae.load_state_dict(synth.vae_encoder_state_dict(vcfg), strict=False)
+    with torch.no_grad():
+        g["vae_mean"] = vae.encode(inp["ref_image"]).latent_dist.mean.clone()
+    g["median"] = U.median_filter_3d(inp["video"], 3, "cpu").clone()
+    g["median_u8"] = torch.from_numpy((g["median"].permute(1, 2, 3, 0) * 255).numpy().astype("uint8"))
+    stub = types.SimpleNamespace(
+        audio_processor=lambda wav, return_tensors, sampling_rate: {"input_values": wav},
+        audio_encoder=lambda wav: types.SimpleNamespace(last_hidden_state=inp["wav2vec_states"]),
+        audio_projection=lambda x: x, device="cpu", dtype=torch.float32)
+    g["audio_windows_F7"] = VExpressPipeline.prepare_audio_embeddings(stub, torch.zeros(1, 16), 7, 2, False)[0].clone()
+    torch.save(g, os.path.join(out, "prologue.pt"))
+    print("prologue", {k: tuple(v.shape) for k, v in g.items()})
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     out = os.path.join(HERE, "golden")
     os.makedirs(out, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "prologue":
+        return prologue(out)
+    prologue(out)
     built = {}
     for name, (kw, F, h, w, t) in cases.FORWARD_CASES.items():
         key = tuple(kw["block_out_channels"])

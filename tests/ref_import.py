@@ -28,6 +28,23 @@ def import_reference():
     return modules, pipelines
 
 
+def import_reference_utils():
+    """pipelines/utils.py (median_filter_3d, save_video).  Its module-level imports of cv2 / imageio_ffmpeg (video
+    muxing only, not installed here) are satisfied with empty stand-in modules; median_filter_3d uses neither."""
+    import types
+    import_reference()
+    for name in ("cv2", "imageio_ffmpeg"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except ImportError:
+                m = types.ModuleType(name)
+                m.get_ffmpeg_exe = lambda: "ffmpeg"
+                sys.modules[name] = m
+    import pipelines.utils as U
+    return U
+
+
 SD15_UNET_CONFIG = dict(
     sample_size=64, in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True, freq_shift=0,
     down_block_types=["CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"],

@@ -21,7 +21,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for n in names:
         assert hasattr(so, n), n
-    assert lib.lib.vx_abi_version() == 3
+    assert lib.lib.vx_abi_version() == 4
     assert ctypes.sizeof(lib.GemmParams) % 8 == 0
     # argument validation happens before any launch, so it works without a GPU and never aborts the process
     p = lib.GemmParams()
@@ -162,3 +162,13 @@ def test_unit_partition_properties():
                     assert halves in ([0], [1], [0, 1])
     assert distributed.UnitSchedule(10, 8).rounds() == 3          # 124 frames on 8 GPUs: 20 units -> 3 rounds
     assert distributed.split_frames(124, 8)[0] == (0, 16) and distributed.split_frames(124, 8)[-1] == (112, 124)
+
+
+def test_audio_windows_match_reference_golden():
+    """prepare_audio_embeddings' window construction (pipelines/v_express_pipeline.py:381-401) vs the reference's own
+    output stored in tests/golden/prologue.pt."""
+    import os
+    import cases
+    from v_express_amd.prologue import audio_windows
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prologue.pt"), weights_only=False)
+    assert torch.equal(audio_windows(cases.prologue_inputs()["wav2vec_states"], 7, 2), g["audio_windows_F7"])

@@ -78,3 +78,27 @@ def test_ddim_constants_match_scheduler():
     assert d.set_timesteps(25) == g["timesteps"].tolist() == list(range(999, 0, -40))
     assert torch.allclose(d.alphas_cumprod, g["alphas_cumprod"], atol=1e-7)
     assert d.alphas_cumprod[999].item() == 0.0        # zero terminal SNR
+
+
+def test_prologue_oracle_matches_reference_golden():
+    """oracle/prologue.py against tests/golden/prologue.pt (reference outputs, tests/make_golden.py prologue)."""
+    from oracle import prologue as OP
+    g = _load("prologue.pt")
+    inp = cases.prologue_inputs()
+    b, c, f, H, W = inp["kps_images"].shape
+    frames = inp["kps_images"].permute(0, 2, 1, 3, 4).reshape(b * f, c, H, W)
+    for tag, kw in (("small", cases.KPS_SMALL), ("full", {})):
+        sd = synth.kps_guider_state_dict(synth.KpsGuiderConfig(**kw))
+        got = OP.kps_guider(sd, frames).reshape(b, f, -1, H // 8, W // 8).permute(0, 2, 1, 3, 4)
+        assert (got - g[f"kps_{tag}"]).abs().max().item() < TOL
+    for tag, kw, key in (("small", cases.AUDIO_SMALL, "audio_windows_small"), ("full", {}, "audio_windows_full")):
+        acfg = synth.AudioProjectionConfig(**kw)
+        got = OP.audio_projection(synth.audio_projection_state_dict(acfg), inp[key], acfg.depth, acfg.heads)
+        assert (got - g[f"audio_{tag}"]).abs().max().item() < 2 * TOL
+    vcfg = synth.VaeConfig(**cases.SMALL_VAE)
+    got = OP.vae_encode_mean(synth.vae_encoder_state_dict(vcfg), oracle.VaeConfig(**cases.SMALL_VAE), inp["ref_image"])
+    assert (got - g["vae_mean"]).abs().max().item() < 2 * TOL
+    med = OP.median_filter_3d(inp["video"], 3)
+    assert torch.equal(med, g["median"])
+    assert torch.equal(torch.from_numpy(OP.frames_uint8(med)), g["median_u8"])
+    assert torch.equal(OP.audio_windows(inp["wav2vec_states"], 7, 2), g["audio_windows_F7"])

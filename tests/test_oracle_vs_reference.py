@@ -39,3 +39,73 @@ def test_uncond_reference_attention_is_out_bias(reference):
     x = torch.randn(2, 16, 64, generator=g)
     o = L.attention(w, "a", x, torch.zeros(2, 16, 64), 8)
     assert torch.allclose(o, w["a.to_out.0.bias"].expand_as(o), atol=1e-6)
+
+
+def test_prologue_models_against_live_reference(reference):
+    """VKpsGuider / AudioProjection (reference modules, unmodified) and AutoencoderKL.encode (diffusers stand-in) vs
+    oracle/prologue.py on the same synthetic weights; strict state_dict loads pin the key schema."""
+    import ref_import as R
+    import diffusers
+    import oracle
+    from oracle import prologue as OP
+    modules, _ = R.import_reference()
+    inp = cases.prologue_inputs()
+    # --- VKpsGuider
+    for kw in (cases.KPS_SMALL, {}):
+        kcfg = synth.KpsGuiderConfig(**kw)
+        sd = synth.kps_guider_state_dict(kcfg)
+        ref = modules.VKpsGuider(kcfg.conditioning_embedding_channels, block_out_channels=kcfg.block_out_channels)
+        ref.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            want = ref(inp["kps_images"])                                          # [1, C, f, h/8, w/8]
+        b, c, f, H, W = inp["kps_images"].shape
+        got = OP.kps_guider(sd, inp["kps_images"].permute(0, 2, 1, 3, 4).reshape(b * f, c, H, W))
+        got = got.reshape(b, f, -1, H // 8, W // 8).permute(0, 2, 1, 3, 4)
+        assert (got - want).abs().max().item() < 1e-5
+    # --- AudioProjection
+    for kw, key in ((cases.AUDIO_SMALL, "audio_windows_small"), ({}, "audio_windows_full")):
+        acfg = synth.AudioProjectionConfig(**kw)
+        sd = synth.audio_projection_state_dict(acfg)
+        ref = modules.AudioProjection(dim=acfg.dim, depth=acfg.depth, dim_head=acfg.dim_head, heads=acfg.heads,
+                                      num_queries=acfg.num_queries, embedding_dim=acfg.embedding_dim,
+                                      output_dim=acfg.output_dim, ff_mult=acfg.ff_mult, max_seq_len=acfg.max_seq_len)
+        ref.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            want = ref(inp[key])
+        got = OP.audio_projection(sd, inp[key], acfg.depth, acfg.heads)
+        assert (got - want).abs().max().item() < 2e-5
+    # --- VAE encode (mean)
+    vcfg = synth.VaeConfig(**cases.SMALL_VAE)
+    sdv = synth.vae_encoder_state_dict(vcfg)
+    vae = diffusers.AutoencoderKL(block_out_channels=vcfg.block_out_channels, layers_per_block=vcfg.layers_per_block,
+                                  norm_num_groups=vcfg.norm_num_groups, latent_channels=vcfg.latent_channels)
+    missing = vae.load_state_dict(sdv, strict=False)
+    assert all(k.startswith(("decoder.", "post_quant_conv.")) for k in missing.missing_keys) and not missing.unexpected_keys
+    with torch.no_grad():
+        want = vae.encode(inp["ref_image"]).latent_dist.mean
+    got = OP.vae_encode_mean(sdv, oracle.VaeConfig(**cases.SMALL_VAE), inp["ref_image"])
+    assert (got - want).abs().max().item() < 2e-5
+
+
+def test_audio_windows_and_median_against_live_reference(reference):
+    """The audio-window construction of prepare_audio_embeddings (executed from the reference pipeline's own source
+    lines) and pipelines/utils.py:median_filter_3d vs the oracle restatements: bit-exact."""
+    import ref_import as R
+    from oracle import prologue as OP
+    U = R.import_reference_utils()
+    inp = cases.prologue_inputs()
+    want = U.median_filter_3d(inp["video"], 3, "cpu")
+    got = OP.median_filter_3d(inp["video"], 3)
+    assert torch.equal(got, want)
+    # window construction: run the reference method body on a stand-in `self`
+    import types
+    _, pipelines = R.import_reference()
+    from pipelines.v_express_pipeline import VExpressPipeline
+    F_, pad = 7, 2
+    stub = types.SimpleNamespace(
+        audio_processor=lambda wav, return_tensors, sampling_rate: {"input_values": wav},
+        audio_encoder=lambda wav: types.SimpleNamespace(last_hidden_state=inp["wav2vec_states"]),
+        audio_projection=lambda x: x, device="cpu", dtype=torch.float32)
+    want = VExpressPipeline.prepare_audio_embeddings(stub, torch.zeros(1, 16), F_, pad, False)[0]
+    got = OP.audio_windows(inp["wav2vec_states"], F_, pad)
+    assert torch.equal(got, want)

@@ -11,8 +11,9 @@ from .scheduler import DDIMScheduler  # noqa: F401
 
 _LAZY = {
     "UNet3DConditionModel": "unet_3d", "UNet3DConditionOutput": "unet_3d", "UNet2DConditionModel": "unet_2d",
-    "AutoencoderKLDecoder": "vae", "ReferenceAttentionControl": "mutual_self_attention",
-    "VExpressPipeline": "pipeline",
+    "AutoencoderKLDecoder": "vae", "AutoencoderKL": "vae", "ReferenceAttentionControl": "mutual_self_attention",
+    "VExpressPipeline": "pipeline", "VKpsGuider": "prologue", "AudioProjection": "prologue",
+    "median_filter_3d": "postprocess", "video_frames_uint8": "postprocess",
 }
 
 

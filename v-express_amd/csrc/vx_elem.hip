@@ -124,6 +124,49 @@ inline dim3 grid1d(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) /
 
 }  // namespace
 
+// 3x3x3 median over (frame, y, x) with reflect padding in all three axes (pipelines/utils.py:46-61: func.pad(...,
+// mode='reflect') + unfold + torch.median over the 27 window values).  One thread per output pixel and channel; the 27
+// values are partially selection-sorted in registers with min/max exchanges (the median is the 14th smallest: a pure
+// selection, so the result is bit-identical to the reference for any input without NaNs).
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__global__ __launch_bounds__(256) void median3d_kernel(const float* __restrict__ x, int c, int f, int h, int w,
+                                                       float* __restrict__ out_f32, uint8_t* __restrict__ out_u8) {
+  const long total = (long)c * f * h * w;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int xx = (int)(idx % w);
+  const int yy = (int)((idx / w) % h);
+  const int ff = (int)((idx / ((long)w * h)) % f);
+  const int cc = (int)(idx / ((long)w * h * f));
+  const float* xc = x + (size_t)cc * f * h * w;
+  float v[27];
+#pragma unroll
+  for (int dt = 0; dt < 3; ++dt) {
+    const float* xf = xc + (size_t)reflect_idx(ff + dt - 1, f) * h * w;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const float* xr = xf + (size_t)reflect_idx(yy + dy - 1, h) * w;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) v[(dt * 3 + dy) * 3 + dx] = xr[reflect_idx(xx + dx - 1, w)];
+    }
+  }
+  // selection: after pass i, v[i] is the (i+1)-th smallest
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+#pragma unroll
+    for (int j = i + 1; j < 27; ++j) {
+      const float lo = fminf(v[i], v[j]), hi = fmaxf(v[i], v[j]);
+      v[i] = lo;
+      v[j] = hi;
+    }
+  }
+  const float med = v[13];
+  if (out_f32 != nullptr) out_f32[idx] = med;
+  if (out_u8 != nullptr)   // (video * 255).astype(uint8): fp32 product, truncation (pipelines/utils.py:72-73)
+    out_u8[(((size_t)ff * h + yy) * w + xx) * c + cc] = (uint8_t)(unsigned)(med * 255.0f);
+}
+
 extern "C" int vx_add_row_bias(void* x, int ldx, int rows, int c, const float* bias, float alpha, void* stream) {
   VX_REQUIRE(x && bias && rows > 0 && (c % 8) == 0 && (ldx % 8) == 0, "vx_add_row_bias: bad arguments");
   hipLaunchKernelGGL(add_row_bias_kernel, grid1d((long)rows * (c / 8)), dim3(256), 0, (hipStream_t)stream,
@@ -179,4 +222,12 @@ extern "C" int vx_vae_postprocess(const float* x, int ld, int n, int c, int hw, 
   VX_REQUIRE(x && out && ld >= c, "vx_vae_postprocess: bad arguments");
   hipLaunchKernelGGL(vae_post_kernel, grid1d((long)n * hw), dim3(256), 0, (hipStream_t)stream, x, ld, n, c, hw, out);
   return vx_check_launch("vx_vae_postprocess");
+}
+
+extern "C" int vx_median3d(const float* video, int c, int f, int h, int w, float* out_f32, void* out_u8, void* stream) {
+  VX_REQUIRE(video && (out_f32 || out_u8), "vx_median3d: null pointer");
+  VX_REQUIRE(c >= 1 && f >= 2 && h >= 2 && w >= 2, "vx_median3d: reflect padding needs f, h, w >= 2 (got %d %d %d)", f, h, w);
+  hipLaunchKernelGGL(median3d_kernel, grid1d((long)c * f * h * w), dim3(256), 0, (hipStream_t)stream, video, c, f, h, w,
+                     out_f32, (uint8_t*)out_u8);
+  return vx_check_launch("vx_median3d");
 }

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
     // out-of-range rows / columns), so the loads of a row group are in flight together; only stores are predicated.
     const float* __restrict__ rowbias = p.rowbias;
     const bf16_t* __restrict__ resid = (const bf16_t*)p.residual;
-    const bool do_silu = p.act == VX_ACT_SILU;
+    const bool do_silu = p.act == VX_ACT_SILU, do_gelu = p.act == VX_ACT_GELU;
     const bool out_is_f32 = p.out_f32 != 0;
     const float alpha = p.alpha;
 #pragma unroll
@@ -342,6 +342,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
           if (do_silu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+          } else if (do_gelu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= alpha;
@@ -510,6 +513,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vx_gemm_params
     if (p.act == VX_ACT_SILU) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+    } else if (p.act == VX_ACT_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] *= p.alpha;

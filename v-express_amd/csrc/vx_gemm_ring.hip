@@ -546,7 +546,7 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
     mode = (e && !strcmp(e, "0")) ? 0 : ((e && !strcmp(e, "1")) ? 1 : 2);
   }
   if (!mode) return false;
-  if ((p.epi != VX_EPI_STORE && p.epi != VX_EPI_GEGLU) || p.out_f32 || p.splitk > 1) return false;
+  if ((p.epi != VX_EPI_STORE && p.epi != VX_EPI_GEGLU) || p.out_f32 || p.splitk > 1 || p.act == VX_ACT_GELU) return false;
   if ((p.m % R_BM) != 0 || (p.n % R_BN) != 0) return false;
   if ((p.ldc % 8) != 0 || (p.residual != nullptr && (p.ldr % 8) != 0)) return false;
   if ((unsigned long long)p.m * p.ldc * 2ull >= (1ull << 32) ||

@@ -16,7 +16,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "vexpress_hip.h")
 
 VX_EPI_STORE, VX_EPI_GEGLU, VX_EPI_SPLIT = 0, 1, 2
 VX_PART_ROWS, VX_PART_VT = 0, 1
-VX_ACT_NONE, VX_ACT_SILU = 0, 1
+VX_ACT_NONE, VX_ACT_SILU, VX_ACT_GELU = 0, 1, 2
 
 
 class GemmParams(C.Structure):
@@ -93,12 +93,13 @@ def _load():
     lib.vx_ncfhw_to_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     lib.vx_nhwc_to_ncfhw.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     lib.vx_vae_postprocess.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.vx_median3d.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
     for name in declared_symbols():
         fn = getattr(lib, name)
         if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name",
                         "vx_gemm_splitk_ws_bytes"):
             fn.restype = i32
-    if lib.vx_abi_version() != 3:
+    if lib.vx_abi_version() != 4:
         raise ImportError("libvexpress_hip.so ABI version mismatch")
     return lib
 

@@ -94,12 +94,16 @@ def _row_stride(t):
 class ConvGeom:
     """Geometry of an implicit-GEMM convolution over NHWC frames."""
 
-    def __init__(self, nb, h_in, w_in, kh=1, kw=1, stride=1, pad=0, upsample=0):
+    def __init__(self, nb, h_in, w_in, kh=1, kw=1, stride=1, pad=0, upsample=0, pad_end=0):
+        """pad: zero padding before AND after each spatial axis; pad_end: extra zero padding after only
+        (diffusers Downsample2D(padding=0): F.pad(x, (0, 1, 0, 1)) + conv stride 2 -> pad=0, pad_end=1).  The
+        kernel's gather zero-fills every tap that falls outside the stored image, so pad_end only changes the
+        output size."""
         self.nb, self.h_in, self.w_in = nb, h_in, w_in
         self.kh, self.kw, self.stride, self.pad, self.upsample = kh, kw, stride, pad, upsample
         he, we = h_in << upsample, w_in << upsample
-        self.h_out = (he + 2 * pad - kh) // stride + 1
-        self.w_out = (we + 2 * pad - kw) // stride + 1
+        self.h_out = (he + 2 * pad + pad_end - kh) // stride + 1
+        self.w_out = (we + 2 * pad + pad_end - kw) // stride + 1
 
     @property
     def m(self):
@@ -394,6 +398,17 @@ def nhwc_to_ncfhw(x, b, c, f, h, w):
     out = torch.empty((b, c, f, h, w), device=x.device, dtype=torch.float32)
     L.check(_lib.vx_nhwc_to_ncfhw(_ptr(x), x.stride(0), b, c, f, h * w, _ptr(out), _stream()), "vx_nhwc_to_ncfhw")
     return out
+
+
+def median3d(video, want_f32=True, want_u8=False):
+    """video fp32 [C, F, H, W] (device) -> (filtered fp32 [C, F, H, W] or None, uint8 [F, H, W, C] or None)."""
+    if video.dtype != torch.float32 or not video.is_cuda or not video.is_contiguous():
+        raise TypeError("median3d: expected a contiguous CUDA float32 [C, F, H, W] tensor")
+    c, f, h, w = video.shape
+    out = torch.empty_like(video) if want_f32 else None
+    u8 = torch.empty((f, h, w, c), device=video.device, dtype=torch.uint8) if want_u8 else None
+    L.check(_lib.vx_median3d(_ptr(video), c, f, h, w, _ptr(out), _ptr(u8), _stream()), "vx_median3d")
+    return out, u8
 
 
 def vae_postprocess(x, n, c, h, w):

@@ -12,10 +12,10 @@ step are fused; the VAE decodes frames in batches.  With `torch.distributed` ini
 units of a timestep are sharded over the ranks (distributed.py) — the reference's
 `do_multi_devices_inference` flag is accepted and, as in the reference, changes nothing by itself.
 
-Out of scope: the once-per-clip prologue models (VKpsGuider, wav2vec2,
-AudioProjection, VAE encoder).  They are called through the reference's own hooks when provided as torch
-modules; the benchmark and the parity tests pass their outputs in directly (`reference_latents=`,
-`kps_features=`, `audio_embeddings=`, `latents=` keyword arguments).
+Once-per-clip prologue: VKpsGuider, AudioProjection and the VAE encoder run on the HIP
+kernels when the v_express_amd classes are passed (prologue.py, vae.AutoencoderKL); wav2vec2 stays a user-provided
+transformers module.  The benchmark and the loop parity tests pass the prologue outputs in directly
+(`reference_latents=`, `kps_features=`, `audio_embeddings=`, `latents=` keyword arguments).
 """
 import math
 from typing import Callable, List, Optional, Union
@@ -59,21 +59,54 @@ class VExpressPipeline:
         return self
 
     # ------------------------------------------------------------------ once-per-clip prologue (reference hooks)
+    @staticmethod
+    def _preprocess_image(image, height, width, normalize):
+        """diffusers VaeImageProcessor.preprocess as configured at pipelines/v_express_pipeline.py:112-119
+        (do_convert_rgb, resize with LANCZOS, [0,1]; `normalize`: 2x-1 for the reference image only)."""
+        import numpy as np
+        from PIL import Image
+        if isinstance(image, torch.Tensor):
+            t = image if image.ndim == 4 else image[None]
+        else:
+            arr = np.asarray(image.convert("RGB").resize((width, height), resample=Image.LANCZOS), dtype=np.float32)
+            t = torch.from_numpy(arr / 255.0).permute(2, 0, 1)[None]
+        return 2.0 * t - 1.0 if normalize else t
+
     def prepare_reference_latent(self, reference_image, height, width):
-        """pipelines/v_express_pipeline.py:343-348 (needs a VAE *encoder*, out of scope: pass reference_latents=)."""
-        raise NotImplementedError("VAE-encoding the reference image is out of the hot-path scope; "
-                                  "pass reference_latents=[1,4,h/8,w/8] (already scaled by 0.18215)")
+        """pipelines/v_express_pipeline.py:343-348: VAE-encode the reference image (posterior mean) * 0.18215.  Runs on
+        the HIP VAE encoder when `vae` is a v_express_amd.AutoencoderKL (encoder weights loaded)."""
+        if not hasattr(self.vae, "encode"):
+            raise NotImplementedError("this VAE has no encoder half (AutoencoderKLDecoder): construct "
+                                      "v_express_amd.AutoencoderKL and load encoder.* / quant_conv.*, or pass "
+                                      "reference_latents=[1,4,h/8,w/8] (already scaled by 0.18215)")
+        x = self._preprocess_image(reference_image, height, width, normalize=True)
+        return self.vae.encode(x).latent_dist.mean * 0.18215
+
+    def prepare_kps_tokens(self, kps_images, height, width, do_classifier_free_guidance):
+        """prepare_kps_feature (:350-372) on the device, returning the token layout the loop consumes:
+        bf16 `[2, F, hw, C0]` (row 0 = the all-zero unconditional half).  Needs a v_express_amd.VKpsGuider."""
+        frames = [self._preprocess_image(img, height, width, normalize=False).unsqueeze(2) for img in kps_images]
+        x = torch.cat(frames, dim=2)                                          # [1, 3, F, H, W]
+        toks = []
+        for i in range(0, x.shape[2], 16):                                    # :359-366 (chunks of 16 frames)
+            t, h, w = self.v_kps_guider.forward_tokens(x[:, :, i:i + 16])
+            toks.append(t)
+        tok = torch.cat(toks, dim=0).view(1, x.shape[2], h * w, -1)
+        if do_classifier_free_guidance:
+            tok = torch.cat([torch.zeros_like(tok), tok], dim=0)
+        return tok
 
     def prepare_kps_feature(self, kps_images, height, width, do_classifier_free_guidance):
-        """pipelines/v_express_pipeline.py:350-372 through a user-provided torch VKpsGuider."""
+        """pipelines/v_express_pipeline.py:350-372 with the reference's return layout `[2, C, F, h, w]` float32."""
         if self.v_kps_guider is None:
             raise NotImplementedError("no v_kps_guider given; pass kps_features=[2,320,F,h/8,w/8]")
-        import numpy as np
-        frames = []
-        for img in kps_images:
-            arr = np.asarray(img.convert("RGB").resize((width, height)), dtype=np.float32) / 255.0
-            frames.append(torch.from_numpy(arr).permute(2, 0, 1)[None, :, None])
-        x = torch.cat(frames, dim=2).to(self.device)
+        if hasattr(self.v_kps_guider, "forward_tokens"):
+            tok = self.prepare_kps_tokens(kps_images, height, width, do_classifier_free_guidance)
+            b2, F_, hw, c = tok.shape
+            h = height // self.vae_scale_factor
+            return tok.float().view(b2, F_, h, hw // h, c).permute(0, 4, 1, 2, 3).contiguous()
+        frames = [self._preprocess_image(img, height, width, normalize=False).unsqueeze(2) for img in kps_images]
+        x = torch.cat(frames, dim=2).to(self.device)                          # a user-provided torch module
         feats = [self.v_kps_guider(x[:, :, i:i + 16].to(next(self.v_kps_guider.parameters()).dtype)).float()
                  for i in range(0, x.shape[2], 16)]
         feat = torch.cat(feats, dim=2)
@@ -83,17 +116,16 @@ class VExpressPipeline:
 
     def prepare_audio_embeddings(self, audio_waveform, video_length, num_pad_audio_frames,
                                  do_classifier_free_guidance):
-        """pipelines/v_express_pipeline.py:374-407 through user-provided wav2vec2 + AudioProjection modules."""
+        """pipelines/v_express_pipeline.py:374-407.  wav2vec2 (`audio_processor` + `audio_encoder`) is a user-provided
+        transformers module (out of scope); the window construction and the AudioProjection run here
+        (v_express_amd.AudioProjection on the HIP kernels, or any callable with the reference's signature)."""
         if self.audio_encoder is None or self.audio_projection is None or self.audio_processor is None:
             raise NotImplementedError("no audio modules given; pass audio_embeddings=[2,F,5,768]")
+        from .prologue import audio_windows
         wav = self.audio_processor(audio_waveform, return_tensors="pt", sampling_rate=16000)["input_values"]
         enc_dtype = next(self.audio_encoder.parameters()).dtype
         emb = self.audio_encoder(wav.to(self.device, enc_dtype)).last_hidden_state
-        emb = torch.nn.functional.interpolate(emb.float().permute(0, 2, 1), size=2 * video_length,
-                                              mode="linear")[0].permute(1, 0).to(enc_dtype)
-        pad = torch.zeros_like(emb)[:2 * num_pad_audio_frames]
-        emb = torch.cat([pad, emb, pad], dim=0)
-        per_frame = torch.stack([emb[2 * i:2 * (i + 2 * num_pad_audio_frames + 1)] for i in range(video_length)])
+        per_frame = audio_windows(emb, video_length, num_pad_audio_frames).to(enc_dtype)
         out = self.audio_projection(per_frame).unsqueeze(0)
         if do_classifier_free_guidance:
             out = torch.cat([torch.zeros_like(out), out], dim=0)
@@ -219,8 +251,12 @@ class VExpressPipeline:
                                            audio_attention_weight=audio_attention_weight)
         if reference_latents is None:
             reference_latents = self.prepare_reference_latent(reference_image, height, width)
+        kps_tokens = None
         if kps_features is None:
-            kps_features = self.prepare_kps_feature(kps_images, height, width, do_cfg)
+            if hasattr(self.v_kps_guider, "forward_tokens"):
+                kps_tokens = self.prepare_kps_tokens(kps_images, height, width, do_cfg)   # stays in the token layout
+            else:
+                kps_features = self.prepare_kps_feature(kps_images, height, width, do_cfg)
         if audio_embeddings is None:
             audio_embeddings = self.prepare_audio_embeddings(audio_waveform, video_length, num_pad_audio_frames,
                                                              do_cfg)
@@ -233,8 +269,9 @@ class VExpressPipeline:
         reader.update(writer, do_cfg, dtype=self.dtype)
         lat = self.prepare_latents(num_images_per_prompt, self.denoising_unet.in_channels, width, height,
                                    video_length, self.dtype, dev, generator, latents)
-        b2, c0, F, h, w = kps_features.shape
-        kps_tokens = ops.ncfhw_to_nhwc(kps_features.to(dev), c0).view(b2, F, h * w, c0)
+        if kps_tokens is None:
+            b2, c0, F, h, w = kps_features.shape
+            kps_tokens = ops.ncfhw_to_nhwc(kps_features.to(dev), c0).view(b2, F, h * w, c0)
         audio = audio_embeddings.to(device=dev, dtype=ops.BF16).contiguous()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record()

@@ -290,3 +290,89 @@ def synthetic_inputs(cfg: UNetConfig, num_frames, latent_h, latent_w, seed=42, d
     to = dict(device=device, dtype=dtype)
     return dict(latents=latents.to(**to), ref_latents=ref_latents.to(**to), kps_features=kps.to(**to),
                 audio_embeddings=audio.to(**to))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Once-per-clip prologue models: VKpsGuider, AudioProjection, VAE encoder.
+@dataclass
+class KpsGuiderConfig:
+    """modules/v_kps_guider.py:11-16 as instantiated by inference.py:100."""
+    conditioning_embedding_channels: int = 320
+    conditioning_channels: int = 3
+    block_out_channels: Tuple[int, ...] = (16, 32, 96, 256)
+
+
+@dataclass
+class AudioProjectionConfig:
+    """modules/audio_projection.py:98-110 as instantiated by inference.py:116-126 (num_pad_audio_frames = 2)."""
+    dim: int = 768
+    depth: int = 4
+    dim_head: int = 64
+    heads: int = 12
+    num_queries: int = 5
+    embedding_dim: int = 768
+    output_dim: int = 768
+    ff_mult: int = 4
+    max_seq_len: int = 10
+
+
+def kps_guider_state_dict(cfg: KpsGuiderConfig = None, seed=45, device="cpu", dtype=torch.float32):
+    """VKpsGuider state_dict (modules/v_kps_guider.py:18-33).  conv_out is zero-initialised in the reference
+    (zero_module); here it is drawn N(0, 0.02^2) so the path is numerically live."""
+    cfg = cfg or KpsGuiderConfig()
+    g = _gen(seed, device, dtype, False)
+    ch = list(cfg.block_out_channels)
+    g.conv("conv_in", cfg.conditioning_channels, ch[0], 3)
+    for i in range(len(ch) - 1):
+        g.conv(f"blocks.{2 * i}", ch[i], ch[i], 3)
+        g.conv(f"blocks.{2 * i + 1}", ch[i], ch[i + 1], 3)
+    g.sd["conv_out.weight"] = g.normal((cfg.conditioning_embedding_channels, ch[-1], 3, 3), 0.02)
+    g.sd["conv_out.bias"] = g.normal((cfg.conditioning_embedding_channels,), 0.02)
+    return g.sd
+
+
+def audio_projection_state_dict(cfg: AudioProjectionConfig = None, seed=46, device="cpu", dtype=torch.float32):
+    """AudioProjection state_dict (modules/audio_projection.py:112-136)."""
+    cfg = cfg or AudioProjectionConfig()
+    g = _gen(seed, device, dtype, False)
+    inner = cfg.dim_head * cfg.heads
+    g.sd["pos_emb.weight"] = g.normal((cfg.max_seq_len, cfg.embedding_dim), 1.0)
+    g.sd["latents"] = g.normal((1, cfg.num_queries, cfg.dim), cfg.dim ** -0.5)
+    g.linear("proj_in", cfg.embedding_dim, cfg.dim)
+    g.linear("proj_out", cfg.dim, cfg.output_dim)
+    g.norm("norm_out", cfg.output_dim)
+    for i in range(cfg.depth):
+        a, f = f"layers.{i}.0", f"layers.{i}.1"
+        g.norm(a + ".norm1", cfg.dim)
+        g.norm(a + ".norm2", cfg.dim)
+        g.linear(a + ".to_q", cfg.dim, inner, bias=False)
+        g.linear(a + ".to_kv", cfg.dim, 2 * inner, bias=False)
+        g.linear(a + ".to_out", inner, cfg.dim, bias=False)
+        g.norm(f + ".0", cfg.dim)
+        g.linear(f + ".1", cfg.dim, cfg.dim * cfg.ff_mult, bias=False)
+        g.linear(f + ".3", cfg.dim * cfg.ff_mult, cfg.dim, bias=False)
+    return g.sd
+
+
+def vae_encoder_state_dict(cfg: VaeConfig = None, seed=47, device="cpu", dtype=torch.float32):
+    """sd-vae-ft-mse encoder half of diffusers AutoencoderKL (encoder.* + quant_conv)."""
+    cfg = cfg or VaeConfig()
+    g = _gen(seed, device, dtype, False)
+    ch = list(cfg.block_out_channels)
+    g.conv("encoder.conv_in", 3, ch[0], 3)
+    prev = ch[0]
+    for i, c in enumerate(ch):
+        for j in range(cfg.layers_per_block):
+            g.resnet(f"encoder.down_blocks.{i}.resnets.{j}", prev if j == 0 else c, c, None)
+        if i != len(ch) - 1:
+            g.conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", c, c, 3)
+        prev = c
+    for j in range(2):
+        g.resnet(f"encoder.mid_block.resnets.{j}", ch[-1], ch[-1], None)
+    a = "encoder.mid_block.attentions.0"
+    g.norm(a + ".group_norm", ch[-1])
+    g.attn(a, ch[-1], qkv_bias=True)
+    g.norm("encoder.conv_norm_out", ch[-1])
+    g.conv("encoder.conv_out", ch[-1], 2 * cfg.latent_channels, 3)
+    g.conv("quant_conv", 2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
+    return g.sd

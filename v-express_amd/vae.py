@@ -29,6 +29,7 @@ class AutoencoderKLDecoder:
         self._dtype = torch.bfloat16
         self._raw = {}
         self._P = None
+        self._PE = None
 
     @property
     def device(self):
@@ -50,10 +51,13 @@ class AutoencoderKLDecoder:
     def eval(self):
         return self
 
+    _PREFIXES = ("decoder.", "post_quant_conv.")
+
     def load_state_dict(self, sd, strict=False):
-        keep = {k: v.detach() for k, v in sd.items() if k.startswith(("decoder.", "post_quant_conv."))}
+        keep = {k: v.detach() for k, v in sd.items() if k.startswith(self._PREFIXES)}
         self._raw.update(keep)
         self._P = None
+        self._PE = None
         return SimpleNamespace(missing_keys=[], unexpected_keys=[k for k in sd if k not in keep])
 
     def init_random(self, seed=44):
@@ -137,3 +141,70 @@ class AutoencoderKLDecoder:
             frames.append(ops.vae_postprocess(out, n, self.cfg.out_channels, H, W))
         video = torch.cat(frames)                                    # [(b F), 3, H, W]
         return video.view(b, F, self.cfg.out_channels, video.shape[-2], video.shape[-1]).permute(0, 2, 1, 3, 4)
+
+
+class AutoencoderKL(AutoencoderKLDecoder):
+    """Decoder + ENCODER halves: `vae.encode(x).latent_dist.mean` as called by
+    VExpressPipeline.prepare_reference_latent (pipelines/v_express_pipeline.py:343-348).  diffusers AutoencoderKL
+    encoder, restated: conv_in -> 4 down blocks of 2 resnets (Downsample2D(padding=0): F.pad (0,1,0,1) + conv3x3
+    stride 2 after the first three) -> mid (resnet, single-head attention, resnet) -> GroupNorm(eps 1e-6) -> SiLU ->
+    conv_out (2 x latent channels) -> quant_conv 1x1; the posterior mean is the first half of the channels."""
+    _PREFIXES = ("decoder.", "post_quant_conv.", "encoder.", "quant_conv.")
+
+    def _prepared_encoder(self):
+        if self._PE is not None:
+            return self._PE
+        if self._device.type != "cuda":
+            raise RuntimeError("v_express_amd models run on an MI355X only: call .to('cuda')")
+        sd, dev, cfg = self._raw, self._device, self.cfg
+        P = Wt.Prepared()
+        P["conv_in"] = Wt.prep_conv(sd, "encoder.conv_in", dev)
+        n = len(cfg.block_out_channels)
+        for i in range(n):
+            for j in range(cfg.layers_per_block):
+                P[f"down.{i}.resnets.{j}"] = Wt.prep_resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}", dev)
+            if i != n - 1:
+                P[f"down.{i}.downsampler"] = Wt.prep_conv(sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", dev)
+        for j in range(2):
+            P[f"mid.resnets.{j}"] = Wt.prep_resnet(sd, f"encoder.mid_block.resnets.{j}", dev)
+        a = "encoder.mid_block.attentions.0"
+        P["mid.attn"] = Wt.Prepared(norm=Wt.prep_norm(sd, a + ".group_norm", dev), attn=Wt.prep_self_attn(sd, a, dev))
+        P["norm_out"] = Wt.prep_norm(sd, "encoder.conv_norm_out", dev)
+        P["conv_out"] = Wt.prep_conv(sd, "encoder.conv_out", dev)
+        P["quant"] = Wt.prep_conv(sd, "quant_conv", dev)
+        self._PE = P
+        return P
+
+    def encode(self, x):
+        """x: [n, 3, H, W] in [-1, 1] -> SimpleNamespace(latent_dist=SimpleNamespace(mean=[n, 4, H/8, W/8] fp32))."""
+        P, cfg = self._prepared_encoder(), self.cfg
+        g = cfg.norm_num_groups
+        n, c, H, W = x.shape
+        t = ops.ncfhw_to_nhwc(x.to(self._device).float().unsqueeze(2).contiguous(), 8)
+        t = ops.gemm(t.view(n * H * W, 8), P.conv_in.w, P.conv_in.b, geom=ops.ConvGeom(n, H, W, 3, 3, 1, 1))
+        t = t.view(n, H * W, -1)
+        nb = len(cfg.block_out_channels)
+        for i in range(nb):
+            for j in range(cfg.layers_per_block):
+                t = B.resnet_block(P[f"down.{i}.resnets.{j}"], t, n, H, W, groups=g, eps=1e-6)
+            if i != nb - 1:
+                d = P[f"down.{i}.downsampler"]
+                geom = ops.ConvGeom(n, H, W, 3, 3, 2, 0, pad_end=1)
+                t = ops.gemm(t.view(n * H * W, -1), d.w, d.b, geom=geom)
+                H, W = geom.h_out, geom.w_out
+                t = t.view(n, H * W, -1)
+        hw = H * W
+        t = B.resnet_block(P["mid.resnets.0"], t, n, H, W, groups=g, eps=1e-6)
+        cch = t.shape[-1]
+        A = P["mid.attn"]
+        nrm = ops.groupnorm(t, A.norm.g, A.norm.b, frames=n, hw=hw, groups=g, eps=1e-6, silu=False)
+        h = t.reshape(n * hw, cch).clone()
+        B._self_attention(A.attn, nrm.view(n * hw, cch), h, seqs=n, n_tok=hw, heads=1)
+        t = B.resnet_block(P["mid.resnets.1"], h.view(n, hw, cch), n, H, W, groups=g, eps=1e-6)
+        nrm = ops.groupnorm(t, P.norm_out.g, P.norm_out.b, frames=n, hw=hw, groups=g, eps=1e-6, silu=True,
+                            pad_hw=(H, W))
+        m = ops.gemm(nrm.view(n * (H + 2) * (W + 2), -1), P.conv_out.w, P.conv_out.b,
+                     geom=ops.ConvGeom(n, H + 2, W + 2, 3, 3, 1, 0))
+        m = ops.gemm(m, P.quant.w, P.quant.b, out_f32=True)                     # [n*hw, 8] fp32: mean | logvar
+        mean = ops.nhwc_to_ncfhw(m, n, cfg.latent_channels, 1, H, W)[:, :, 0]
+        return SimpleNamespace(latent_dist=SimpleNamespace(mean=mean))
