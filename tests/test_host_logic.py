@@ -172,3 +172,60 @@ def test_audio_windows_match_reference_golden():
     from v_express_amd.prologue import audio_windows
     g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prologue.pt"), weights_only=False)
     assert torch.equal(audio_windows(cases.prologue_inputs()["wav2vec_states"], 7, 2), g["audio_windows_F7"])
+
+
+def test_checkpoint_ingestion_order_and_legacy_key_remaps(tmp_path):
+    """checkpoints.py: (1) the legacy remaps equal the reference's own train.py:122-161 function (executed from the
+    reference source when it is available, otherwise against the hand-written expectation); (2) the two-file load
+    order of inference.py:84-96 (denoising UNet, then motion module on top, both strict=False) fills every key; (3)
+    file formats (.bin through torch.load, .safetensors) and the VAE's deprecated attention key names."""
+    import ast
+    import copy
+    from v_express_amd import checkpoints as CK
+    sd = {"down.attentions.0.attn1.to_q.weight": torch.ones(2), "down.norm1.weight": torch.full((2,), 2.0),
+          "down.attentions.0.attn2.to_q.weight": torch.zeros(2),
+          "down.attentions.0.attn2.processor.to_q_aud.weight": torch.full((2,), 5.0),
+          "down.attentions.0.attn2.to_out.0.bias": torch.zeros(2),
+          "down.attentions.0.attn2.processor.to_out_aud.0.bias": torch.full((2,), 7.0)}
+    ref_path = "/root/reference/train.py"
+    ref_fn = None
+    if os.path.exists(ref_path):
+        tree = ast.parse(open(ref_path).read())
+        node = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "get_denoising_unet_state_dict"][0]
+        ns = {"copy": copy}
+        exec(compile(ast.Module(body=[node], type_ignores=[]), ref_path, "exec"), ns)
+        ref_fn = ns["get_denoising_unet_state_dict"]
+    for kind in ("old_attn", "moore_pretrained", "new_attn"):
+        got = CK.get_denoising_unet_state_dict(sd, kind)
+        if ref_fn is not None:
+            want = ref_fn(sd, kind)
+            assert set(got) == set(want) and all(torch.equal(got[k], want[k]) for k in want), kind
+    got = CK.get_denoising_unet_state_dict(sd, "old_attn")
+    assert torch.equal(got["down.attentions.0.attn1_5.to_q.weight"], torch.ones(2))
+    assert torch.equal(got["down.norm1_5.weight"], torch.full((2,), 2.0))
+    assert torch.equal(got["down.attentions.0.attn2.to_q.weight"], torch.full((2,), 5.0))
+    assert torch.equal(got["down.attentions.0.attn2.to_out.0.bias"], torch.full((2,), 7.0))
+    assert "down.attentions.0.attn1_5.to_q.weight" not in CK.get_denoising_unet_state_dict(sd, "new_attn")
+    with pytest.raises(ValueError):
+        CK.get_denoising_unet_state_dict(sd, "nope")
+    # two-file load order: spatial weights first, motion-module weights second, both partial
+    from v_express_amd import UNet3DConditionModel
+    cfg = synth.UNetConfig(block_out_channels=(64, 128, 256, 256))
+    full = synth.unet3d_state_dict(cfg)
+    motion = {k: v for k, v in full.items() if "motion_modules" in k}
+    spatial = {k: v for k, v in full.items() if "motion_modules" not in k}
+    assert motion and spatial
+    torch.save(spatial, tmp_path / "denoising_unet.bin")
+    from safetensors.torch import save_file
+    save_file({k: v.contiguous() for k, v in motion.items()}, str(tmp_path / "motion_module.safetensors"))
+    unet = UNet3DConditionModel(cfg)
+    r1 = unet.load_state_dict(CK._load_file(str(tmp_path / "denoising_unet.bin")), strict=False)
+    assert set(r1.missing_keys) == set(motion)
+    r2 = unet.load_state_dict(CK._load_file(str(tmp_path / "motion_module.safetensors")), strict=False)
+    assert set(r2.missing_keys) == set(spatial) and not r2.unexpected_keys
+    assert set(unet._raw) == set(full) and all(torch.equal(unet._raw[k], full[k]) for k in full)
+    assert CK.convert_vae_attention_key("decoder.mid_block.attentions.0.proj_attn.weight") == \
+        "decoder.mid_block.attentions.0.to_out.0.weight"
+    assert CK.convert_vae_attention_key("encoder.mid_block.attentions.0.query.bias") == \
+        "encoder.mid_block.attentions.0.to_q.bias"
+    assert CK.convert_vae_attention_key("decoder.conv_in.weight") == "decoder.conv_in.weight"
