@@ -44,6 +44,27 @@ def flop_per_frame(num_frames, windows, steps, scale):
     return (unet + VAE_TFLOP_PER_FRAME) * scale
 
 
+def _pmc_traffic(kernel_key):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/exp_pmc_bench.sh:
+    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; the
+    counter sits on the L2's fabric side, so Infinity-Cache hits are included).  None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    want = "gemm_ring_kernel<0," if "STORE" in kernel_key else ("gemm_ring_kernel<1," if "GEGLU" in kernel_key else None)
+    if want is None or "gemm_ring" not in kernel_key:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    n = b = 0.0
+    for k, v in d.items():
+        if want in k:
+            n += v["launches"]
+            b += v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
+    return (b / n, os.path.relpath(files[-1], ROOT)) if n else (None, None)
+
+
 def _pick_threads():
     """Thread count for the CPU leg: the fastest of a few candidates on a 1-second conv probe (a 256-thread box
     runs the fp32 oracle several times SLOWER with all hardware threads than with one thread per few cores)."""
@@ -246,9 +267,11 @@ def main():
         tot_f = sum(v["flops"] for v in summ.values())
         dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
         ach = dom[1]["flops"] / dom[1]["seconds"] / 1e12
+        traffic, traffic_src = _pmc_traffic(dom[0])
         result["roofline"] = {
             "bound": "mfma", "kernel": dom[0], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+            "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": dom[1].get("bytes", 0.0) / max(dom[1]["launches"], 1),
             "avg_launch_us": 1e6 * dom[1]["seconds"] / dom[1]["launches"], "launches": dom[1]["launches"],
             "all_gemm_tflops": tot_f / tot_s / 1e12,
             "per_kernel": {k: {"launches": v["launches"], "avg_us": 1e6 * v["seconds"] / v["launches"],

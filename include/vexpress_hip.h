@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 4
+#define VX_ABI_VERSION 5
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
@@ -76,10 +76,19 @@ typedef struct {
    * (the 8x8 level: M = 2048) that would otherwise fill half of the 256 CUs.  0 / 1 = off. */
   int32_t splitk;
   void* splitk_ws;
+  /* Kernel-selection hint for the persistent ring-staged kernel (its conv K order differs from the classic tiles', so
+   * callers that need bit-identical results for any sub-batch must make the choice from batch-independent facts):
+   * 0 = automatic (ring when eligible and the launch has >= 192 tiles), 1 = ring whenever structurally eligible,
+   * -1 = never. */
+  int32_t ring_hint;
 } vx_gemm_params;
 
 int vx_gemm(const vx_gemm_params* p, void* stream);
 int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk);
+/* Kernel-selection knob (process-wide; default 2, or the VX_GEMM_RING environment variable): 0 = never use the
+ * persistent ring-staged 256x320 kernel, 1 = only for K <= 1280, 2 = for every eligible problem.  Results differ only by
+ * fp32 summation order (the ring kernel walks conv taps innermost).  For A/B measurements and cross-checking tests. */
+int vx_gemm_set_ring_mode(int mode);
 /* name of the tile configuration vx_gemm would launch for p (profiling / roofline reports); thread-local storage */
 const char* vx_gemm_config_name(const vx_gemm_params* p);
 

@@ -21,7 +21,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for n in names:
         assert hasattr(so, n), n
-    assert lib.lib.vx_abi_version() == 4
+    assert lib.lib.vx_abi_version() == 5
     assert ctypes.sizeof(lib.GemmParams) % 8 == 0
     # argument validation happens before any launch, so it works without a GPU and never aborts the process
     p = lib.GemmParams()
@@ -40,9 +40,9 @@ def test_gemm_params_struct_matches_header_layout():
 #include <stdio.h>
 #include <stddef.h>
 #include "vexpress_hip.h"
-int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(vx_gemm_params), offsetof(vx_gemm_params, w),
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(vx_gemm_params), offsetof(vx_gemm_params, w),
   offsetof(vx_gemm_params, alpha), offsetof(vx_gemm_params, residual), offsetof(vx_gemm_params, part_out),
-  offsetof(vx_gemm_params, vt_pitch)); return 0; }'''
+  offsetof(vx_gemm_params, vt_pitch), offsetof(vx_gemm_params, ring_hint)); return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "p.c"), "w").write(src)
         inc = os.path.join(os.path.dirname(lib.HEADER))
@@ -50,7 +50,7 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(vx_gemm_params), offs
         got = list(map(int, subprocess.check_output([os.path.join(d, "p")]).split()))
     G = lib.GemmParams
     assert got == [ctypes.sizeof(G), G.w.offset, G.alpha.offset, G.residual.offset, G.part_out.offset,
-                   G.vt_pitch.offset]
+                   G.vt_pitch.offset, G.ring_hint.offset]
 
 
 def test_windows_and_alignment_match_reference_context_py():

@@ -13,7 +13,13 @@ from . import ops
 from .ops import ConvGeom
 
 
-def resnet_block(P, x, frames, H, W, *, groups, eps, temb=None, rows_per_group=0, skip=None):
+def resnet_block(P, x, frames, H, W, *, groups, eps, temb=None, rows_per_group=0, skip=None, items=None):
+    with ops.frame_rows(H * W, items=items):
+        return _resnet_block(P, x, frames, H, W, groups=groups, eps=eps, temb=temb, rows_per_group=rows_per_group,
+                             skip=skip)
+
+
+def _resnet_block(P, x, frames, H, W, *, groups, eps, temb=None, rows_per_group=0, skip=None):
     """ResnetBlock3D.forward (modules/resnet.py:217-251) / diffusers ResnetBlock2D.
     x: [frames, HW, C1]; skip: optional [frames, HW, C2] consumed as the channel concat
     torch.cat([x, skip], dim=1) (modules/unet_3d_blocks.py:694,831) without materialising it;
@@ -76,7 +82,7 @@ def _feed_forward(P, h):
 
 
 def spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_ref, w_aud):
-    with ops.frame_rows(H * W):
+    with ops.frame_rows(H * W, items=b):
         return _spatial_transformer_read(P, x, b=b, f=f, H=H, W=W, heads=heads, groups=groups, ehs=ehs, bank=bank,
                                          w_ref=w_ref, w_aud=w_aud)
 
@@ -104,10 +110,11 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
         else:
             kref, vtref = bank[bi]
             ln = ops.layernorm(hb, P.norm1_5.g, P.norm1_5.b)
-            q = ops.gemm(ln, P.attn1_5.wq)
-            a = ops.attention(q, kref, vtref, batch=f, heads=heads, n_q=hw, n_kv=kref.shape[0], head_dim=d,
-                              q_per_kv=f)
-            ops.gemm(a, P.attn1_5.out.w, P.attn1_5.out.b, residual=hb, alpha=w_ref, out=hb)
+            with ops.frame_rows(hw, items=1):          # these launches cover ONE batch item
+                q = ops.gemm(ln, P.attn1_5.wq)
+                a = ops.attention(q, kref, vtref, batch=f, heads=heads, n_q=hw, n_kv=kref.shape[0], head_dim=d,
+                                  q_per_kv=f)
+                ops.gemm(a, P.attn1_5.out.w, P.attn1_5.out.b, residual=hb, alpha=w_ref, out=hb)
     # 2. audio cross-attention (:227-244)
     n_ctx = ehs.shape[0] // frames
     ln = ops.layernorm(h, P.norm2.g, P.norm2.b)
@@ -149,7 +156,7 @@ def _spatial_transformer_write(P, x, *, frames, H, W, heads, groups, ehs):
 
 
 def motion_module(P, x, *, b, f, H, W, heads, groups):
-    with ops.frame_rows(H * W):
+    with ops.frame_rows(H * W, items=b):
         return _motion_module(P, x, b=b, f=f, H=H, W=W, heads=heads, groups=groups)
 
 

@@ -539,13 +539,24 @@ extern "C" int vx_gemm_ring_set_trace(void* dev_buf) {
 }
 #endif
 
+static int g_ring_mode = -1;   // VX_GEMM_RING: 0 off, 1 short K only, 2 (default) every eligible shape
+
+extern "C" int vx_gemm_set_ring_mode(int mode) {
+  if (mode < 0 || mode > 2) {
+    vx_set_error("vx_gemm_set_ring_mode: mode %d outside [0, 2]", mode);
+    return VX_ERR_INVALID;
+  }
+  g_ring_mode = mode;
+  return VX_OK;
+}
+
 bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
-  static int mode = -1;   // VX_GEMM_RING: 0 off, 1 short K only, 2 (default) every eligible shape
+  int& mode = g_ring_mode;
   if (mode < 0) {
     const char* e = getenv("VX_GEMM_RING");
     mode = (e && !strcmp(e, "0")) ? 0 : ((e && !strcmp(e, "1")) ? 1 : 2);
   }
-  if (!mode) return false;
+  if (!mode || p.ring_hint < 0) return false;
   if ((p.epi != VX_EPI_STORE && p.epi != VX_EPI_GEGLU) || p.out_f32 || p.splitk > 1 || p.act == VX_ACT_GELU) return false;
   if ((p.m % R_BM) != 0 || (p.n % R_BN) != 0) return false;
   if ((p.ldc % 8) != 0 || (p.residual != nullptr && (p.ldr % 8) != 0)) return false;
@@ -560,7 +571,9 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
   // a 256-row tile = whole frames, or whole image rows of one frame (tile-invariant per-thread gather offsets)
   if (!((R_BM % hw_out) == 0 || ((hw_out % R_BM) == 0 && (R_BM % p.w_out) == 0))) return false;
   const long tiles = (long)(p.m / R_BM) * (p.n / R_BN);
-  if (tiles < 192) return false;   // fewer tiles than ~3/4 of the CUs: the 128-row tiles of vx_gemm.hip fill the chip better
+  // fewer tiles than ~3/4 of the CUs: the 128-row tiles of vx_gemm.hip fill the chip better (ring_hint = 1: the caller
+  // made that call from batch-independent facts, e.g. v_express_amd.ops for the CFG-pair launch shape)
+  if (p.ring_hint == 0 && tiles < 192) return false;
   // In isolation (tools/gemm_bench, operands warm in L2 / Infinity Cache) the plain two-stage loop is a few % faster on
   // long K loops: an LDS-DMA copy issued beside the partner wave's MFMAs costs 2-3x one issued in a burst
   // (profiles/r01d_ring_ablation.txt).  Inside the model the ring kernel wins on every eligible shape (tap-innermost

@@ -41,6 +41,7 @@ class GemmParams(C.Structure):
         ("part_out", C.c_void_p * 3), ("part_kind", C.c_int32 * 3), ("part_ld", C.c_int32 * 3),
         ("seq_len", C.c_int32), ("head_dim", C.c_int32), ("vt_pitch", C.c_int32),
         ("splitk", C.c_int32), ("splitk_ws", C.c_void_p),
+        ("ring_hint", C.c_int32),
     ]
 
 
@@ -93,13 +94,14 @@ def _load():
     lib.vx_ncfhw_to_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     lib.vx_nhwc_to_ncfhw.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     lib.vx_vae_postprocess.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.vx_gemm_set_ring_mode.argtypes = [i32]
     lib.vx_median3d.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
     for name in declared_symbols():
         fn = getattr(lib, name)
         if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name",
                         "vx_gemm_splitk_ws_bytes"):
             fn.restype = i32
-    if lib.vx_abi_version() != 4:
+    if lib.vx_abi_version() != 5:
         raise ImportError("libvexpress_hip.so ABI version mismatch")
     return lib
 

@@ -26,6 +26,7 @@ class GemmProfile:
 
     def __init__(self):
         self.records = []          # (start_event, end_event, flops, tile_key, shape)
+        self.bytes_of = {}         # id(start_event) -> algorithmic bytes of that launch (operands read once + output)
 
     def __enter__(self):
         GemmProfile.active = self
@@ -38,11 +39,12 @@ class GemmProfile:
         torch.cuda.synchronize()
         by = {}
         for s, e, fl, key, _ in self.records:
-            d = by.setdefault(key, [0, 0.0, 0.0])
+            d = by.setdefault(key, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += s.elapsed_time(e) * 1e-3
             d[2] += fl
-        return {k: dict(launches=v[0], seconds=v[1], flops=v[2]) for k, v in by.items()}
+            d[3] += self.bytes_of.get(id(s), 0.0)
+        return {k: dict(launches=v[0], seconds=v[1], flops=v[2], bytes=v[3]) for k, v in by.items()}
 
     def by_shape(self):
         """{(m, n, k, kernel): [launches, seconds, flops]} sorted by time (tools / tuning)."""
@@ -70,6 +72,11 @@ def _launch_gemm(p, what):
     L.check(_lib.vx_gemm(C.byref(p), _stream()), what)
     e.record()
     prof.records.append((s, e, 2.0 * p.m * p.n * p.k, _tile_key(p), (p.m, p.n, p.k)))
+    # algorithmic bytes: every input row once (c1 + c2 channels), the weights once, the output once, residual once
+    rows_in = p.nb * p.h_in * p.w_in
+    n_out = p.n // 2 if p.epi == L.VX_EPI_GEGLU else p.n
+    prof.bytes_of[id(s)] = 2.0 * (rows_in * (p.c1 + p.c2) + p.n * p.k + p.m * n_out * (2 if p.out_f32 else 1) +
+                                  (p.m * p.n if p.residual else 0))
 
 
 def _ptr(t):
@@ -143,19 +150,37 @@ _SPLITK_WS = {}
 _FRAME_ROWS = [None]
 
 
-class frame_rows:
-    """`with ops.frame_rows(hw):` tells plain (geometry-less) GEMMs how many token rows one frame holds; only the
-    split-K policy reads it (convolutions carry their own geometry)."""
+_ITEMS = [None]
 
-    def __init__(self, hw):
-        self.hw = hw
+
+class frame_rows:
+    """`with ops.frame_rows(hw, items=b):` tells the GEMM wrappers how many token rows one frame holds and how many
+    independent batch items (CFG halves) share the launch.  Only the kernel-selection policies read it (split-K factor,
+    ring-kernel hint): they must be functions of per-item facts, never of how many items are batched, so that a CFG
+    half computed alone (on another GPU) is bit-identical to its rows in the batched call."""
+
+    def __init__(self, hw, items=None):
+        self.hw, self.items = hw, items
 
     def __enter__(self):
-        self.prev = _FRAME_ROWS[0]
-        _FRAME_ROWS[0] = self.hw
+        self.prev = (_FRAME_ROWS[0], _ITEMS[0])
+        _FRAME_ROWS[0], _ITEMS[0] = self.hw, self.items
 
     def __exit__(self, *a):
-        _FRAME_ROWS[0] = self.prev
+        _FRAME_ROWS[0], _ITEMS[0] = self.prev
+
+
+def _ring_hint(p):
+    """vx_gemm_params.ring_hint from batch-independent facts: rows of ONE batch item (a 16-frame CFG half) and N.
+    The ring kernel is chosen when a nominal CFG-pair launch (2 items) would have >= 192 tiles of 256 x 320 and an
+    item is a whole number of 256-row tiles; without the frame_rows context the library decides by the launch size."""
+    items = _ITEMS[0]
+    if items is None or items <= 0 or p.m % items:
+        return 0
+    rows_item = p.m // items
+    if rows_item % 256 or p.n % 320:
+        return -1
+    return 1 if (2 * rows_item // 256) * (p.n // 320) >= 192 else -1
 
 
 def _splitk(p, geom, device, plain):
@@ -202,6 +227,7 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be float32")
     _splitk(p, geom, a.device, plain)
+    p.ring_hint = _ring_hint(p)
     _launch_gemm(p, "vx_gemm")
     return out
 
@@ -214,6 +240,7 @@ def geglu(a, w_interleaved, bias_interleaved, out=None):
     p.epi = L.VX_EPI_GEGLU
     p.bias = bias_interleaved.data_ptr() if bias_interleaved is not None else None
     p.out, p.ldc = out.data_ptr(), _row_stride(out)[0]
+    p.ring_hint = _ring_hint(p)
     _launch_gemm(p, "vx_gemm(geglu)")
     return out
 

@@ -275,7 +275,7 @@ class UNet3DConditionModel(_UNetBase):
         def layer(p, j, attn, x, skip):
             x = B.resnet_block(P[f"{p}.resnets.{j}"], x, frames, h_, w_, groups=g, eps=eps,
                                temb=self._temb(rows, f"{p}.resnets.{j}"), rows_per_group=rpg_scale * h_ * w_,
-                               skip=skip)
+                               skip=skip, items=b)
             if attn:
                 ap = f"{p}.attentions.{j}"
                 x = B.spatial_transformer_read(P[ap], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g, ehs=ehs,
@@ -292,13 +292,13 @@ class UNet3DConditionModel(_UNetBase):
                 skips.append((x, h_, w_))
         # mid (unet_3d_blocks.py:269-293)
         x = B.resnet_block(P["mid_block.resnets.0"], x, frames, h_, w_, groups=g, eps=eps,
-                           temb=self._temb(rows, "mid_block.resnets.0"), rows_per_group=rpg_scale * h_ * w_)
+                           temb=self._temb(rows, "mid_block.resnets.0"), rows_per_group=rpg_scale * h_ * w_, items=b)
         x = B.spatial_transformer_read(P["mid_block.attentions.0"], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g,
                                        ehs=ehs, bank=[banks["mid_block.attentions.0"][r] for r in rowsel],
                                        w_ref=w_ref, w_aud=w_aud)
         x = B.motion_module(P["mid_block.motion_modules.0"], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g)
         x = B.resnet_block(P["mid_block.resnets.1"], x, frames, h_, w_, groups=g, eps=eps,
-                           temb=self._temb(rows, "mid_block.resnets.1"), rows_per_group=rpg_scale * h_ * w_)
+                           temb=self._temb(rows, "mid_block.resnets.1"), rows_per_group=rpg_scale * h_ * w_, items=b)
         for blk in plan["up"]:
             p = blk["prefix"]
             for j, _ in enumerate(blk["layers"]):
