@@ -212,10 +212,18 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
   // step the issue pointer to the next K-tile of the sequence (`more`: that K-tile exists)
   auto advance_issue = [&](bool more) {
     ++iss_kt;
+#ifdef VX_RING_TAP_OUTER
+    s_ci += BK;
+    if (s_ci >= cin) {
+      s_ci = 0;
+      if (++s_kx == kw) { s_kx = 0; ++s_ky; }
+    }
+#else
     if (++s_kx == kw) {
       s_kx = 0;
       if (++s_ky == kh) { s_ky = 0; s_ci += BK; }
     }
+#endif
     if (iss_kt == nk) {
       iss_kt = 0; s_ci = 0; s_kx = 0; s_ky = 0;
       iss_lid += G;
