@@ -191,3 +191,31 @@ def test_full_size_forward_ring_vs_classic_and_batch_invariance():
     cond = fwd(x[1:].contiguous(), ehs[F:].contiguous(), kps[1:].contiguous(), rows=[1])
     unc = fwd(x[:1].contiguous(), ehs[:F].contiguous(), kps[:1].contiguous(), rows=[0])
     assert torch.equal(cond[0], ring[1]) and torch.equal(unc[0], ring[0])
+
+
+def test_zero_audio_rows_reduce_to_output_bias():
+    """The unconditional CFG half carries all-zero audio tokens (pipelines/v_express_pipeline.py:403-405): K = V = 0,
+    uniform softmax, weighted sum exactly 0 -> attn2 contributes exactly w_aud * to_out.bias.  The shortcut path
+    (audio_zero=[True, False], precomputed audio K|V) must reproduce the fully computed forward: the cond half
+    bit-for-bit, the uncond half up to one fp32 rounding of alpha * bias before the bf16 store."""
+    _need_gpu()
+    from v_express_amd import ReferenceAttentionControl, ops, synth
+    kw, F, h, w, t = cases.FORWARD_CASES["small_f8_16x8"]
+    cfg = cases.unet_cfg(kw)
+    sd3, sd2 = synth.unet3d_state_dict(cfg), synth.refnet_state_dict(cfg)
+    inp = synth.synthetic_inputs(cfg, F, h, w)
+    unet, refnet = build_models(kw, sd3, sd2)
+    writer = ReferenceAttentionControl(refnet, do_classifier_free_guidance=True, mode="write", fusion_blocks="full")
+    reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", fusion_blocks="full",
+                                       reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD)
+    refnet(inp["ref_latents"], timestep=0, encoder_hidden_states=torch.zeros(1, 1, 768), return_dict=False)
+    reader.update(writer, True)
+    x = ops.ncfhw_to_nhwc(inp["latents"].repeat(2, 1, 1, 1, 1).cuda(), 8)
+    ehs = inp["audio_embeddings"].reshape(-1, 768).cuda().to(torch.bfloat16).contiguous()
+    assert (ehs[:F * 5] == 0).all()
+    kps = ops.ncfhw_to_nhwc(inp["kps_features"].cuda(), cfg.block_out_channels[0])
+    full = unet.forward_tokens(x, t, ehs, kps, b=2, f=F, H=h, W=w).view(2, F * h * w, -1)
+    fast = unet.forward_tokens(x, t, ehs, kps, b=2, f=F, H=h, W=w, audio_kv=unet.precompute_audio_kv(ehs),
+                               audio_zero=[True, False]).view(2, F * h * w, -1)
+    assert torch.equal(fast[1], full[1])
+    assert rel_l2(fast[0], full[0]) <= 2e-3

@@ -81,13 +81,20 @@ def _feed_forward(P, h):
     ops.gemm(g, P.ff.out.w, P.ff.out.b, residual=h, out=h)
 
 
-def spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_ref, w_aud):
+def audio_kv(P, ehs):
+    """K | V of the audio cross-attention (attn2) of one transformer block: ehs [b*f*n_ctx, 768] -> [b*f*n_ctx, 2C].
+    Depends on the audio tokens and the weights only, so the denoising loop computes it once per clip and window
+    (UNet3DConditionModel.precompute_audio_kv) instead of once per block per DDIM step."""
+    return ops.gemm(ehs, P.attn2.wkv)
+
+
+def spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_ref, w_aud, kv=None, audio_zero=None):
     with ops.frame_rows(H * W, items=b):
         return _spatial_transformer_read(P, x, b=b, f=f, H=H, W=W, heads=heads, groups=groups, ehs=ehs, bank=bank,
-                                         w_ref=w_ref, w_aud=w_aud)
+                                         w_ref=w_ref, w_aud=w_aud, kv=kv, audio_zero=audio_zero)
 
 
-def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_ref, w_aud):
+def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_ref, w_aud, kv=None, audio_zero=None):
     """Transformer3DModel.forward (modules/transformer_3d.py:103-169) with the block forward patched by
     ReferenceAttentionControl in *read* mode (modules/mutual_self_attention.py:176-267).
     x: [b*f, HW, C]; ehs: bf16 [b*f*n_ctx, 768] audio tokens; bank: list over the b batch rows of
@@ -115,13 +122,31 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
                 a = ops.attention(q, kref, vtref, batch=f, heads=heads, n_q=hw, n_kv=kref.shape[0], head_dim=d,
                                   q_per_kv=f)
                 ops.gemm(a, P.attn1_5.out.w, P.attn1_5.out.b, residual=hb, alpha=w_ref, out=hb)
-    # 2. audio cross-attention (:227-244)
+    # 2. audio cross-attention (:227-244).  A batch row whose audio tokens are ALL ZERO (the unconditional CFG half:
+    # torch.zeros_like, pipelines/v_express_pipeline.py:403-405) has K = V = 0 (to_k / to_v carry no bias): every
+    # score is 0, the softmax is uniform, the weighted sum of V is exactly 0 and the block adds exactly
+    # audio_attention_weight * to_out.bias - the same argument as the all-zero bank of 1.5.
     n_ctx = ehs.shape[0] // frames
-    ln = ops.layernorm(h, P.norm2.g, P.norm2.b)
-    q = ops.gemm(ln, P.attn2.wq)
-    kv = ops.gemm(ehs, P.attn2.wkv)
-    a = ops.small_kv_attention(q, kv, batch=frames, n_q=hw, n_kv=n_ctx, heads=heads, head_dim=d)
-    ops.gemm(a, P.attn2.out.w, P.attn2.out.b, residual=h, alpha=w_aud, out=h)
+    if kv is None:
+        kv = audio_kv(P, ehs)
+    if audio_zero is None or not any(audio_zero):
+        ln = ops.layernorm(h, P.norm2.g, P.norm2.b)
+        q = ops.gemm(ln, P.attn2.wq)
+        a = ops.small_kv_attention(q, kv, batch=frames, n_q=hw, n_kv=n_ctx, heads=heads, head_dim=d)
+        ops.gemm(a, P.attn2.out.w, P.attn2.out.b, residual=h, alpha=w_aud, out=h)
+    else:
+        kvr = f * n_ctx
+        for bi in range(b):
+            hb = h[bi * rows:(bi + 1) * rows]
+            if audio_zero[bi]:
+                ops.add_row_bias(hb, P.attn2.out.b, w_aud)
+                continue
+            ln = ops.layernorm(hb, P.norm2.g, P.norm2.b)
+            with ops.frame_rows(hw, items=1):
+                q = ops.gemm(ln, P.attn2.wq)
+                a = ops.small_kv_attention(q, kv[bi * kvr:(bi + 1) * kvr], batch=f, n_q=hw, n_kv=n_ctx, heads=heads,
+                                           head_dim=d)
+                ops.gemm(a, P.attn2.out.w, P.attn2.out.b, residual=hb, alpha=w_aud, out=hb)
     # 3. feed-forward (:247)
     _feed_forward(P, h)
     out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x2d)

@@ -180,17 +180,22 @@ class VExpressPipeline:
             raise NotImplementedError("guidance_scale <= 1 (no CFG) is not wired; V-Express defaults to 3.5")
         # per-call constants (window ids, conditioning slices) do not depend on the timestep: build them once so
         # the timestep loop issues kernels only (no host->device copies, no syncs)
+        # which CFG halves carry all-zero audio tokens (the unconditional half, :403-405): one device reduction per clip
+        audio_is_zero = [bool((audio[hh] == 0).all().item()) for hh in range(audio.shape[0])]
         calls = []
         for wi, halves in my_calls:
             hsel = torch.tensor(halves, device=dev)
             kps = kps_tokens.index_select(0, hsel).index_select(1, win_ids_long[wi]).reshape(len(halves) * f, hw, -1)
             ehs = audio.index_select(0, hsel).index_select(1, win_ids_long[wi])
-            calls.append((wi, halves, win_ids[wi], kps.contiguous(), ehs.reshape(-1, ehs.shape[-1]).contiguous()))
+            ehs = ehs.reshape(-1, ehs.shape[-1]).contiguous()
+            # the audio K | V of all 16 transformer blocks is step-invariant: once per clip and window
+            calls.append((wi, halves, win_ids[wi], kps.contiguous(), ehs, unet.precompute_audio_kv(ehs)))
         for i, t in enumerate(timesteps):
             t = int(t)
-            for wi, halves, ids, kps, ehs in calls:
+            for wi, halves, ids, kps, ehs, akv in calls:
                 x_in = ops.gather_latents(latents, ids, reps=len(halves))
-                out = unet.forward_tokens(x_in, t, ehs, kps, b=len(halves), f=f, H=H, W=W, batch_rows=halves)
+                out = unet.forward_tokens(x_in, t, ehs, kps, b=len(halves), f=f, H=H, W=W, batch_rows=halves,
+                                          audio_kv=akv, audio_zero=[audio_is_zero[hh] for hh in halves])
                 for j, hlf in enumerate(halves):
                     local[unit_slot[(wi, hlf)][1]].copy_(out[j * f * hw:(j + 1) * f * hw])
             gathered = dc.all_gather_units(local, max_units)          # [world, max_units, f*hw, 8]

@@ -245,11 +245,28 @@ class UNet3DConditionModel(_UNetBase):
     from_config = from_config_2d
 
     # ---- hot path on resident token tensors (used by the pipeline; no layout changes inside)
-    def forward_tokens(self, x_in, timestep, ehs, kps, *, b, f, H, W, batch_rows=None):
+    def precompute_audio_kv(self, ehs):
+        """Audio cross-attention K | V of every spatial transformer block for one batch of audio tokens
+        (`ehs` bf16 [b*f*n_ctx, 768]) -> {block prefix: [b*f*n_ctx, 2C]}.  Step-invariant (like the reference-attention
+        banks): the loop passes the result to `forward_tokens(audio_kv=...)` for all DDIM steps of a window."""
+        P = self._prepared()
+        plan = block_plan(self.cfg)
+        out = {}
+        for blk in plan["down"] + plan["up"]:
+            if blk["attn"]:
+                for j, _ in enumerate(blk["layers"]):
+                    ap = f"{blk['prefix']}.attentions.{j}"
+                    out[ap] = B.audio_kv(P[ap], ehs)
+        out["mid_block.attentions.0"] = B.audio_kv(P["mid_block.attentions.0"], ehs)
+        return out
+
+    def forward_tokens(self, x_in, timestep, ehs, kps, *, b, f, H, W, batch_rows=None, audio_kv=None,
+                       audio_zero=None):
         """x_in: bf16 [b*f, HW, 8] (latent channels zero-padded), ehs: bf16 [b*f*n_ctx, 768],
         kps: bf16 [b*f, HW, C0] or None -> fp32 [b*f*HW, 8] (columns >= out_channels are zero).
         batch_rows: which rows of the installed banks the b batch rows use (default 0..b-1; a lone CFG half
-        running on another GPU passes [0] or [1])."""
+        running on another GPU passes [0] or [1]).  audio_kv: `precompute_audio_kv(ehs)`; audio_zero: per batch row,
+        True when that row's audio tokens are all zero (its audio cross-attention then reduces to the output bias)."""
         P, cfg = self._prepared(), self.cfg
         g, eps, heads = cfg.norm_num_groups, cfg.norm_eps, cfg.heads
         frames = b * f
@@ -279,7 +296,8 @@ class UNet3DConditionModel(_UNetBase):
             if attn:
                 ap = f"{p}.attentions.{j}"
                 x = B.spatial_transformer_read(P[ap], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g, ehs=ehs,
-                                               bank=[banks[ap][r] for r in rowsel], w_ref=w_ref, w_aud=w_aud)
+                                               bank=[banks[ap][r] for r in rowsel], w_ref=w_ref, w_aud=w_aud,
+                                               kv=None if audio_kv is None else audio_kv[ap], audio_zero=audio_zero)
             return B.motion_module(P[f"{p}.motion_modules.{j}"], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g)
 
         for blk in plan["down"]:
@@ -295,7 +313,9 @@ class UNet3DConditionModel(_UNetBase):
                            temb=self._temb(rows, "mid_block.resnets.0"), rows_per_group=rpg_scale * h_ * w_, items=b)
         x = B.spatial_transformer_read(P["mid_block.attentions.0"], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g,
                                        ehs=ehs, bank=[banks["mid_block.attentions.0"][r] for r in rowsel],
-                                       w_ref=w_ref, w_aud=w_aud)
+                                       w_ref=w_ref, w_aud=w_aud,
+                                       kv=None if audio_kv is None else audio_kv["mid_block.attentions.0"],
+                                       audio_zero=audio_zero)
         x = B.motion_module(P["mid_block.motion_modules.0"], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g)
         x = B.resnet_block(P["mid_block.resnets.1"], x, frames, h_, w_, groups=g, eps=eps,
                            temb=self._temb(rows, "mid_block.resnets.1"), rows_per_group=rpg_scale * h_ * w_, items=b)
