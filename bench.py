@@ -157,10 +157,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VX_DIST_BACKEND=gloo (+ ranks folded onto the visible GPUs) exists only to exercise the multi-rank control flow on
+    # a single-GPU box; the measured configuration is one rank per GPU over RCCL ("nccl").
+    backend = os.environ.get("VX_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -251,12 +258,18 @@ def main():
         "prologue_ms": 1e3 * prologue_s, "model_build_s": t_build,
     }
 
-    if rank == 0 and not args.no_roofline:
-        # one instrumented DDIM step (all of this rank's UNet calls) + the decode of its frames
-        with ops.GemmProfile() as prof:
+    if not args.no_roofline:
+        # one instrumented DDIM step (all of this rank's UNet calls) + the decode of 4 frames.  EVERY rank runs the step
+        # (denoise contains the per-timestep all-gather); only rank 0 records and reports.
+        import contextlib
+        prof = ops.GemmProfile() if rank == 0 else None
+        with (prof if prof is not None else contextlib.nullcontext()):
             lat = inp["latents"].clone()
             pipe.denoise(lat, kps_tokens, audio, timesteps[:1], windows, 3.5)
-            pipe.vae.decode_video(lat[:, :, :min(F, 4)].contiguous(), chunk=4)
+            if rank == 0:
+                pipe.vae.decode_video(lat[:, :, :min(F, 4)].contiguous(), chunk=4)
+        torch.cuda.synchronize()
+    if rank == 0 and not args.no_roofline:
         summ = prof.summary()
         if args.gemm_shapes:
             with open(args.gemm_shapes, "w") as fsh:

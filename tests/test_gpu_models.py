@@ -219,3 +219,26 @@ def test_zero_audio_rows_reduce_to_output_bias():
                                audio_zero=[True, False]).view(2, F * h * w, -1)
     assert torch.equal(fast[1], full[1])
     assert rel_l2(fast[0], full[0]) <= 2e-3
+
+
+def test_bench_two_rank_control_flow_on_one_gpu():
+    """bench.py under torchrun with 2 ranks folded onto this GPU (VX_DIST_BACKEND=gloo: collectives staged through the
+    host) - exercises exactly the multi-rank control flow the driver launches with RCCL: unit sharding, the per-step
+    all-gather, the decode split + frame gather, the max-over-ranks timing and the rank-0-only roofline leg (which must
+    not leave rank 0 alone inside a collective).  Checks that it terminates and prints one well-formed JSON line."""
+    _need_gpu()
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "0", "--ddim-steps", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["windows"] == 2 and d["config"]["frames"] == 28
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["roofline"]["achieved"] > 0

@@ -77,20 +77,27 @@ class DistContext:
             return DistContext(dist.get_rank(), dist.get_world_size(), None)
         return DistContext()
 
+    def _all_gather(self, local: torch.Tensor) -> torch.Tensor:
+        out = torch.empty((self.world_size,) + tuple(local.shape), device=local.device, dtype=local.dtype)
+        if local.is_cuda and dist.get_backend(self.group) != "nccl":
+            # control-flow testing on a single-GPU box (gloo): stage through the host; never the measured path
+            host = torch.empty(out.shape, dtype=local.dtype)
+            dist.all_gather_into_tensor(host.view(-1), local.detach().cpu().contiguous().view(-1), group=self.group)
+            out.copy_(host)
+            return out
+        dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1), group=self.group)
+        return out
+
     def all_gather_units(self, local: torch.Tensor, max_units: int) -> torch.Tensor:
         """local: [max_units, ...] (this rank's unit outputs, zero-padded) -> [world, max_units, ...]."""
         if not self.enabled:
             return local.unsqueeze(0)
-        out = torch.empty((self.world_size,) + tuple(local.shape), device=local.device, dtype=local.dtype)
-        dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1), group=self.group)
-        return out
+        return self._all_gather(local)
 
     def all_gather_frames(self, local: torch.Tensor) -> torch.Tensor:
         if not self.enabled:
             return local.unsqueeze(0)
-        out = torch.empty((self.world_size,) + tuple(local.shape), device=local.device, dtype=local.dtype)
-        dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1), group=self.group)
-        return out
+        return self._all_gather(local)
 
 
 def split_frames(num_frames: int, world_size: int) -> List[Tuple[int, int]]:
