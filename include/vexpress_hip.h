@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 5
+#define VX_ABI_VERSION 6
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
@@ -98,7 +98,9 @@ const char* vx_gemm_config_name(const vx_gemm_params* p);
  * (modules/unet_3d.py:571-572).  ws: float32 workspace of vx_groupnorm_ws_floats() elements.
  * out_pad = 0: out is [frames, hw, C].  out_pad = p > 0: out is the interior of a zero-bordered
  * [frames, H + 2p, W + 2p, C] image (W = width, H = hw / width) whose border the caller keeps zero, so that the
- * following 3x3 convolution runs as a pad-0 ("valid") conv without bounds checks (vx_gemm fast addressing). */
+ * following 3x3 convolution runs as a pad-0 ("valid") conv without bounds checks (vx_gemm fast addressing).
+ * silu: activation code applied after the affine (VX_ACT_*: 0 none, 1 SiLU, 2 erf-GELU - the wav2vec2 feature
+ * encoder's GroupNorm(C groups) + GELU over the time axis: frames = 1, hw = time steps, groups = C). */
 int64_t vx_groupnorm_ws_floats(int frames, int slices, int groups);
 int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int frames, int hw, int groups, float eps,
                  const float* gamma, const float* beta, int silu, void* out, float* ws, int slices, int width,
@@ -160,6 +162,14 @@ int vx_vae_postprocess(const float* x, int ld, int n, int c, int hw, float* out,
  * permute of save_video (:70-73).  video: float32 [c, f, h, w]; out_f32: float32 [c, f, h, w] or NULL;
  * out_u8: uint8 [f, h, w, c] or NULL. */
 int vx_median3d(const float* video, int c, int f, int h, int w, float* out_f32, void* out_u8, void* stream);
+/* First wav2vec2 feature-encoder convolution on the raw waveform: out[t, co] = sum_j wt[j, co] * wave[t*stride + j]
+ * (1 input channel, no padding, no bias; t < (samples - taps) / stride + 1).  Replaces the first nn.Conv1d of
+ * transformers' Wav2Vec2FeatureEncoder reached from pipelines/v_express_pipeline.py:377 (self.audio_encoder(...)).
+ * wave: float32 [samples]; wt: float32 [taps, c] (the Conv1d weight [c, 1, taps] transposed), taps <= 16, c % 8 == 0;
+ * out: bf16 [t_out, c].  The remaining conv1d layers run on vx_gemm: in the time-major layout a k-tap stride-s window
+ * is k*C contiguous elements, i.e. a plain GEMM over overlapping rows (lda1 = s*C < c1 = k*C). */
+int vx_wave_conv1d(const float* wave, int samples, const float* wt, int c, int taps, int stride, void* out,
+                   void* stream);
 
 #ifdef __cplusplus
 }

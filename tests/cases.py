@@ -50,3 +50,26 @@ def prologue_inputs(seed=11):
         ref_image=torch.rand(1, 3, 64, 48, generator=g) * 2 - 1,        # [-1, 1]
         video=torch.rand(3, 5, 12, 10, generator=g),                    # [C, F, H, W] in [0, 1]
     )
+
+
+# ---- wav2vec2 audio encoder: configs + seeded waveform shared by make_golden.py (transformers'
+# own Wav2Vec2Model), the oracle tests and the GPU parity tests
+W2V_SMALL = dict(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, conv_dim=(32,) * 7,
+                 num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+W2V_CASES = {"small": (W2V_SMALL, 4000), "base": ({}, 6000)}          # name -> (config kwargs, samples @ 16 kHz)
+
+
+def waveform(samples, seed=3):
+    """Seeded raw audio, already through the processor's zero-mean / unit-variance normalisation: [1, samples]."""
+    import torch
+    wav = torch.randn(1, samples, generator=torch.Generator().manual_seed(seed)) * 0.1
+    return (wav - wav.mean()) / torch.sqrt(wav.var(unbiased=False) + 1e-7)
+
+
+def hf_wav2vec2(cfg, sd):
+    """transformers' own Wav2Vec2Model with the synthetic weights loaded strictly (pins the key schema)."""
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    hf = Wav2Vec2Model(Wav2Vec2Config(**{k: (list(v) if isinstance(v, tuple) else v)
+                                         for k, v in cfg.__dict__.items()})).eval()
+    hf.load_state_dict(sd, strict=True)
+    return hf

@@ -56,13 +56,31 @@ def prologue(out):
     print("prologue", {k: tuple(v.shape) for k, v in g.items()})
 
 
+def wav2vec2(out):
+    """Outputs of the installed transformers Wav2Vec2Model (the third-party module the reference calls at
+    pipelines/v_express_pipeline.py:377) on the seeded synthetic weights and waveform."""
+    g = {}
+    for tag, (kw, samples) in cases.W2V_CASES.items():
+        cfg = synth.Wav2Vec2Config(**kw)
+        hf = cases.hf_wav2vec2(cfg, synth.wav2vec2_state_dict(cfg))
+        with torch.no_grad():
+            g[tag] = hf(cases.waveform(samples)).last_hidden_state.clone()
+    import transformers
+    g["transformers_version"] = transformers.__version__
+    torch.save(g, os.path.join(out, "wav2vec2.pt"))
+    print("wav2vec2", {k: (tuple(v.shape) if hasattr(v, "shape") else v) for k, v in g.items()})
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     out = os.path.join(HERE, "golden")
     os.makedirs(out, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "prologue":
         return prologue(out)
+    if len(sys.argv) > 1 and sys.argv[1] == "wav2vec2":
+        return wav2vec2(out)
     prologue(out)
+    wav2vec2(out)
     built = {}
     for name, (kw, F, h, w, t) in cases.FORWARD_CASES.items():
         key = tuple(kw["block_out_channels"])

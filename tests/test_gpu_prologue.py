@@ -168,3 +168,135 @@ def test_pipeline_call_runs_prologue_on_device():
     aud = torch.cat([torch.zeros_like(aud), aud], dim=0)
     b = pipe(None, None, None, reference_latents=ref_lat, kps_features=feat, audio_embeddings=aud, **kw)
     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------- wav2vec2 audio encoder (§8f rank 2)
+def test_wave_conv1d_and_time_axis_groupnorm_gelu():
+    """vx_wave_conv1d (first feature-encoder conv on the raw fp32 waveform) and vx_groupnorm with one group per channel
+    over the time axis + fused erf-GELU, against plain fp32 torch."""
+    _need_gpu()
+    import torch.nn.functional as F
+    from v_express_amd import lib as L
+    from v_express_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for samples, c, taps, stride in ((4000, 32, 10, 5), (16001, 512, 10, 5), (57, 8, 16, 3), (10, 64, 10, 5)):
+        wave = torch.randn(samples, generator=g)
+        wt = torch.randn(taps, c, generator=g) * taps ** -0.5
+        got = ops.wave_conv1d(wave.cuda(), wt.cuda(), stride)
+        ref = wave.unfold(0, taps, stride) @ wt
+        _close(got, ref, f"wave_conv1d {samples}x{c}", rel=4e-3, mx=2 ** -8)
+        T = ref.shape[0]
+        gamma, beta = torch.randn(c, generator=g) * 0.1 + 1, torch.randn(c, generator=g) * 0.1
+        x = got.view(1, T, c)
+        y = ops.groupnorm(x, gamma.cuda(), beta.cuda(), frames=1, hw=T, groups=c, eps=1e-5, silu=L.VX_ACT_GELU)
+        if T > 1:
+            yref = F.gelu(F.group_norm(x.float().cpu().transpose(1, 2), c, gamma, beta, 1e-5)).transpose(1, 2)
+        else:                                     # one time step: zero variance, the output is GELU(beta)
+            yref = F.gelu(beta).expand(1, 1, c)
+        _close(y, yref, f"groupnorm(C groups)+gelu T={T}", rel=6e-3, mx=2 ** -7)
+    with pytest.raises(L.VxError):
+        ops.groupnorm(x, gamma.cuda(), beta.cuda(), frames=1, hw=T, groups=c, eps=1e-5, silu=3)
+
+
+@pytest.mark.parametrize("T,c,k,s,n", [(799, 512, 3, 2, 512), (199, 512, 2, 2, 512), (799, 32, 3, 2, 32),
+                                       (50, 64, 2, 2, 64), (3, 512, 3, 2, 512)])
+def test_conv1d_as_gemm_over_overlapping_rows(T, c, k, s, n):
+    """conv1d in the time-major layout == vx_gemm whose A rows overlap (row stride s*C < row length k*C): fast (K % 64
+    == 0) and gather addressing paths, ragged M, GELU epilogue - against F.conv1d."""
+    _need_gpu()
+    import torch.nn.functional as F
+    from v_express_amd import lib as L
+    from v_express_amd import ops
+    g = torch.Generator().manual_seed(T + c)
+    h = torch.randn(T, c, generator=g).to(torch.bfloat16)
+    w = (torch.randn(n, c, k, generator=g) * (2.0 / (c * k)) ** 0.5).to(torch.bfloat16)
+    t_out = (T - k) // s + 1
+    hd = h.cuda()
+    win = torch.as_strided(hd, (t_out, k * c), (s * c, 1))
+    got = ops.gemm(win, w.permute(0, 2, 1).reshape(n, k * c).contiguous().cuda(), act=L.VX_ACT_GELU)
+    ref = F.gelu(F.conv1d(h.float().t()[None], w.float(), stride=s))[0].t()
+    _close(got, ref, f"conv1d-as-gemm T={T} c={c} k={k}", rel=6e-3, mx=2 ** -7)
+
+
+@pytest.mark.parametrize("T,H,G,kp", [(18, 768, 16, 128), (249, 768, 16, 128), (12, 64, 4, 16)])
+def test_grouped_positional_conv_as_per_group_gemms(T, H, G, kp):
+    """Wav2Vec2PositionalConvEmbedding: x + GELU(conv1d(x, k, padding k/2, groups)[..., :-1]) through the group-major
+    padded buffer + one overlapping-row GEMM per group writing a column slice with the residual fused."""
+    _need_gpu()
+    import torch.nn.functional as F
+    from v_express_amd import synth
+    from v_express_amd.wav2vec2 import Wav2Vec2Model
+    g = torch.Generator().manual_seed(T)
+    cfg = synth.Wav2Vec2Config(hidden_size=H, num_hidden_layers=0, num_attention_heads=4, conv_dim=(32,) * 7,
+                               num_conv_pos_embeddings=kp, num_conv_pos_embedding_groups=G)
+    sd = synth.wav2vec2_state_dict(cfg)
+    m = Wav2Vec2Model(cfg).to("cuda")
+    m.load_state_dict(sd)
+    m._prepared()
+    x = torch.randn(T, H, generator=g).to(torch.bfloat16)
+    got = m._positional(x.cuda())
+    from oracle import wav2vec2 as OW
+    wp = OW.pos_conv_weight(sd).to(torch.bfloat16).float()
+    pos = F.conv1d(x.float().t()[None], wp, sd["encoder.pos_conv_embed.conv.bias"], padding=kp // 2, groups=G)
+    ref = x.float() + F.gelu(pos[0, :, :T]).t()
+    _close(got, ref, f"positional conv T={T} H={H}", rel=6e-3, mx=2 ** -7)
+
+
+@pytest.mark.parametrize("tag", ["small", "base"])
+def test_wav2vec2_vs_oracle_and_transformers_golden(tag):
+    _need_gpu()
+    from oracle import wav2vec2 as OW
+    from v_express_amd import Wav2Vec2Model, synth
+    kw, samples = cases.W2V_CASES[tag]
+    cfg = synth.Wav2Vec2Config(**kw)
+    sd = synth.wav2vec2_state_dict(cfg)
+    m = Wav2Vec2Model(cfg).to("cuda")
+    m.load_state_dict(sd)
+    wav = cases.waveform(samples)
+    got = m(wav).last_hidden_state
+    assert got.dtype == torch.float32 and got.shape == (1, cfg.num_frames(samples), cfg.hidden_size)
+    ref = OW.forward(sd, wav, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.num_conv_pos_embedding_groups,
+                     cfg.conv_stride, cfg.layer_norm_eps)
+    _close(got, ref, f"Wav2Vec2Model[{tag}] vs oracle", rel=3e-2, mx=2 ** -4)
+    gold = torch.load(os.path.join(GOLD, "wav2vec2.pt"), weights_only=False)[tag]
+    _close(got, gold, f"Wav2Vec2Model[{tag}] vs transformers golden", rel=3e-2, mx=2 ** -4)
+    feats = m.extract_features(wav[0].cuda())
+    _close(feats, OW.feature_encoder(sd, wav, cfg.conv_stride)[0], f"feature encoder[{tag}]", rel=2e-2, mx=2 ** -4)
+    if tag == "base":                                    # a second, longer clip: ragged T = 124 (2.5 s of audio)
+        wav2 = cases.waveform(40000, seed=4)
+        ref2 = OW.forward(sd, wav2, cfg.num_hidden_layers, cfg.num_attention_heads,
+                          cfg.num_conv_pos_embedding_groups, cfg.conv_stride, cfg.layer_norm_eps)
+        _close(m(wav2).last_hidden_state, ref2, "Wav2Vec2Model[base, 2.5 s] vs oracle", rel=3e-2, mx=2 ** -4)
+
+
+def test_audio_path_waveform_to_audio_tokens_on_device():
+    """prepare_audio_embeddings end to end on the HIP kernels: WaveformProcessor -> Wav2Vec2Model -> interpolation +
+    windows -> AudioProjection, against the oracle chain (pipelines/v_express_pipeline.py:374-407)."""
+    _need_gpu()
+    import types
+    import v_express_amd as vx
+    from oracle import prologue as OP
+    from oracle import wav2vec2 as OW
+    from v_express_amd import synth
+    wcfg = synth.Wav2Vec2Config(**cases.W2V_SMALL)
+    wsd = synth.wav2vec2_state_dict(wcfg)
+    enc = vx.Wav2Vec2Model(wcfg).to("cuda")
+    enc.load_state_dict(wsd)
+    acfg = synth.AudioProjectionConfig(dim=128, depth=2, dim_head=16, heads=8, num_queries=5,
+                                       embedding_dim=wcfg.hidden_size, output_dim=128, max_seq_len=10)
+    asd = synth.audio_projection_state_dict(acfg)
+    proj = vx.AudioProjection(dim=acfg.dim, depth=acfg.depth, dim_head=acfg.dim_head, heads=acfg.heads,
+                              num_queries=acfg.num_queries, embedding_dim=acfg.embedding_dim,
+                              output_dim=acfg.output_dim, max_seq_len=acfg.max_seq_len).to("cuda")
+    proj.load_state_dict(asd)
+    raw = torch.randn(9600, generator=torch.Generator().manual_seed(8)) * 0.2 + 0.05         # 0.6 s @ 16 kHz
+    F_, pad = 7, 2
+    stub = types.SimpleNamespace(audio_processor=vx.WaveformProcessor(), audio_encoder=enc, audio_projection=proj,
+                                 device=torch.device("cuda"))
+    got = vx.VExpressPipeline.prepare_audio_embeddings(stub, raw, F_, pad, True)
+    assert got.shape == (2, F_, 5, 128) and (got[0] == 0).all()
+    wav = OW.normalize_waveform(raw)[None]
+    states = OW.forward(wsd, wav, wcfg.num_hidden_layers, wcfg.num_attention_heads,
+                        wcfg.num_conv_pos_embedding_groups, wcfg.conv_stride, wcfg.layer_norm_eps)
+    ref = OP.audio_projection(asd, OP.audio_windows(states, F_, pad), acfg.depth, acfg.heads)
+    _close(got[1], ref, "waveform -> audio tokens", rel=3e-2, mx=2 ** -4)

@@ -21,7 +21,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for n in names:
         assert hasattr(so, n), n
-    assert lib.lib.vx_abi_version() == 5
+    assert lib.lib.vx_abi_version() == 6
     assert ctypes.sizeof(lib.GemmParams) % 8 == 0
     # argument validation happens before any launch, so it works without a GPU and never aborts the process
     p = lib.GemmParams()
@@ -229,3 +229,41 @@ def test_checkpoint_ingestion_order_and_legacy_key_remaps(tmp_path):
     assert CK.convert_vae_attention_key("encoder.mid_block.attentions.0.query.bias") == \
         "encoder.mid_block.attentions.0.to_q.bias"
     assert CK.convert_vae_attention_key("decoder.conv_in.weight") == "decoder.conv_in.weight"
+
+
+@pytest.mark.parametrize("tag", ["small", "base"])
+def test_wav2vec2_host_composition_with_emulated_kernels(tag, monkeypatch):
+    """The host side of v_express_amd.Wav2Vec2Model - weight re-layouts (tap-major conv matrices, weight-norm, per-group
+    positional-conv matrices, fused QKV), the overlapping-row window views that turn conv1d into plain GEMMs, the
+    group-major zero-padded positional-conv buffer, call order - run here with tests/fake_ops.py standing in for the
+    HIP wrappers (fp32 math, bf16 rounding at each kernel boundary) and compared with the fp32 oracle.  The GPU suite
+    runs the same code on the real kernels (tests/test_gpu_prologue.py)."""
+    import cases
+    import fake_ops
+    from oracle import wav2vec2 as OW
+    from v_express_amd import ops
+    from v_express_amd.wav2vec2 import Wav2Vec2Model, WaveformProcessor
+    fake_ops.install(monkeypatch, ops)
+    monkeypatch.setattr(Wav2Vec2Model, "_need_gpu", lambda self: None)
+    kw, samples = cases.W2V_CASES[tag]
+    cfg = synth.Wav2Vec2Config(**kw)
+    sd = synth.wav2vec2_state_dict(cfg)
+    m = Wav2Vec2Model(cfg).to("cpu")
+    m.load_state_dict({("wav2vec2." + k): v for k, v in sd.items()} | {"lm_head.weight": torch.zeros(2, 2)})  # CTC ckpt
+    wav = cases.waveform(samples)
+    got = m(wav).last_hidden_state
+    want = OW.forward(sd, wav, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.num_conv_pos_embedding_groups,
+                      cfg.conv_stride, cfg.layer_norm_eps)
+    assert got.shape == want.shape == (1, cfg.num_frames(samples), cfg.hidden_size)
+    assert ((got - want).norm() / want.norm()).item() < 2e-2
+    feats = m.extract_features(wav[0]).float()
+    fw = OW.feature_encoder(sd, wav, cfg.conv_stride)[0]
+    assert ((feats - fw).norm() / fw.norm()).item() < 1.5e-2
+    # the processor stand-in == Wav2Vec2FeatureExtractor(do_normalize=True)
+    raw = torch.randn(samples, generator=torch.Generator().manual_seed(5)) * 0.3 + 0.1
+    pv = WaveformProcessor()(raw, return_tensors="pt", sampling_rate=16000)["input_values"]
+    assert pv.shape == (1, samples) and torch.allclose(pv, OW.normalize_waveform(raw)[None], atol=1e-6)
+    with pytest.raises(ValueError):
+        WaveformProcessor()(raw, sampling_rate=8000)
+    with pytest.raises(NotImplementedError):
+        Wav2Vec2Model(synth.Wav2Vec2Config(do_stable_layer_norm=True))

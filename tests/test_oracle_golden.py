@@ -102,3 +102,32 @@ def test_prologue_oracle_matches_reference_golden():
     assert torch.equal(med, g["median"])
     assert torch.equal(torch.from_numpy(OP.frames_uint8(med)), g["median_u8"])
     assert torch.equal(OP.audio_windows(inp["wav2vec_states"], 7, 2), g["audio_windows_F7"])
+
+
+@pytest.mark.parametrize("tag", ["small", "base"])
+def test_wav2vec2_oracle_matches_transformers_golden_and_live(tag):
+    """oracle/wav2vec2.py against tests/golden/wav2vec2.pt (outputs of transformers' Wav2Vec2Model, the third-party
+    module the reference calls; tests/make_golden.py wav2vec2) and, where transformers is importable, against the
+    library itself on the same weights (strict state_dict load == key-schema check)."""
+    from oracle import wav2vec2 as OW
+    g = _load("wav2vec2.pt")
+    kw, samples = cases.W2V_CASES[tag]
+    cfg = synth.Wav2Vec2Config(**kw)
+    sd = synth.wav2vec2_state_dict(cfg)
+    wav = cases.waveform(samples)
+    got = OW.forward(sd, wav, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.num_conv_pos_embedding_groups,
+                     cfg.conv_stride, cfg.layer_norm_eps)
+    assert got.shape == g[tag].shape and (got - g[tag]).abs().max().item() < 2 * TOL
+    try:
+        hf = cases.hf_wav2vec2(cfg, sd)
+    except ImportError:
+        return
+    with torch.no_grad():
+        live = hf(wav).last_hidden_state
+    assert (got - live).abs().max().item() < 2 * TOL
+    # legacy weight_norm key names (checkpoints saved before torch's parametrization API) give the same weight
+    p = "encoder.pos_conv_embed.conv."
+    legacy = {k: v for k, v in sd.items() if "parametrizations" not in k}
+    legacy[p + "weight_g"] = sd[p + "parametrizations.weight.original0"]
+    legacy[p + "weight_v"] = sd[p + "parametrizations.weight.original1"]
+    assert torch.equal(OW.pos_conv_weight(legacy), OW.pos_conv_weight(sd))

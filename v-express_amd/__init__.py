@@ -14,6 +14,7 @@ _LAZY = {
     "AutoencoderKLDecoder": "vae", "AutoencoderKL": "vae", "ReferenceAttentionControl": "mutual_self_attention",
     "VExpressPipeline": "pipeline", "VKpsGuider": "prologue", "AudioProjection": "prologue",
     "median_filter_3d": "postprocess", "video_frames_uint8": "postprocess",
+    "Wav2Vec2Model": "wav2vec2", "WaveformProcessor": "wav2vec2",
 }
 
 

@@ -95,6 +95,19 @@ def load_audio_projection(audio_projection_path, dtype=torch.bfloat16, device="c
     return m
 
 
+def load_audio_encoder(audio_encoder_path, dtype=torch.bfloat16, device="cuda"):
+    """inference.py:109-110: `Wav2Vec2Model.from_pretrained(path)` + `Wav2Vec2Processor.from_pretrained(path)` ->
+    (encoder on the HIP kernels, waveform processor)."""
+    from .wav2vec2 import Wav2Vec2Model, WaveformProcessor
+    proc = WaveformProcessor()
+    pc = os.path.join(audio_encoder_path, "preprocessor_config.json")
+    if os.path.exists(pc):
+        with open(pc) as f:
+            cd = json.load(f)
+        proc = WaveformProcessor(cd.get("sampling_rate", 16000), cd.get("do_normalize", True))
+    return Wav2Vec2Model.from_pretrained(audio_encoder_path, dtype=dtype, device=device), proc
+
+
 def load_vae(vae_dir, dtype=torch.bfloat16, device="cuda"):
     """AutoencoderKL.from_pretrained(vae_path) (inference.py:162) for the diffusers directory layout:
     `config.json` + `diffusion_pytorch_model.safetensors` (or `.bin`)."""

@@ -167,6 +167,35 @@ __global__ __launch_bounds__(256) void median3d_kernel(const float* __restrict__
     out_u8[(((size_t)ff * h + yy) * w + xx) * c + cc] = (uint8_t)(unsigned)(med * 255.0f);
 }
 
+// First layer of the wav2vec2 feature encoder: conv1d over the raw float32 waveform (1 input channel, `taps` taps,
+// stride `stride`, no padding, no bias) -> bf16 time-major tokens [t_out, c].  One thread = one time step x 8 output
+// channels: the <= 16 waveform samples of the step are held in registers (every thread of a step reads the same ones:
+// a broadcast from L1), the 8 x taps weights come from the transposed weight table wt[taps][c] so that a wave's loads
+// are contiguous, fp32 FMA chain in tap order, one 16-B store.
+constexpr int WAVE_CONV_MAX_TAPS = 16;
+__global__ __launch_bounds__(256) void wave_conv1d_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                          bf16_t* __restrict__ out, int t_out, int c, int taps,
+                                                          int stride) {
+  const int chunks = c >> 3;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)t_out * chunks) return;
+  const int t = (int)(idx / chunks), ch = (int)(idx % chunks) * 8;
+  const float* xs = x + (size_t)t * stride;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int j = 0; j < taps; ++j) {
+    const float xv = xs[j];
+    const float4 w0 = *reinterpret_cast<const float4*>(wt + (size_t)j * c + ch);
+    const float4 w1 = *reinterpret_cast<const float4*>(wt + (size_t)j * c + ch + 4);
+    acc[0] = fmaf(w0.x, xv, acc[0]); acc[1] = fmaf(w0.y, xv, acc[1]);
+    acc[2] = fmaf(w0.z, xv, acc[2]); acc[3] = fmaf(w0.w, xv, acc[3]);
+    acc[4] = fmaf(w1.x, xv, acc[4]); acc[5] = fmaf(w1.y, xv, acc[5]);
+    acc[6] = fmaf(w1.z, xv, acc[6]); acc[7] = fmaf(w1.w, xv, acc[7]);
+  }
+  *reinterpret_cast<uint4*>(out + (size_t)t * c + ch) = pack_bf16x8(acc);
+}
+
 extern "C" int vx_add_row_bias(void* x, int ldx, int rows, int c, const float* bias, float alpha, void* stream) {
   VX_REQUIRE(x && bias && rows > 0 && (c % 8) == 0 && (ldx % 8) == 0, "vx_add_row_bias: bad arguments");
   hipLaunchKernelGGL(add_row_bias_kernel, grid1d((long)rows * (c / 8)), dim3(256), 0, (hipStream_t)stream,
@@ -230,4 +259,15 @@ extern "C" int vx_median3d(const float* video, int c, int f, int h, int w, float
   hipLaunchKernelGGL(median3d_kernel, grid1d((long)c * f * h * w), dim3(256), 0, (hipStream_t)stream, video, c, f, h, w,
                      out_f32, (uint8_t*)out_u8);
   return vx_check_launch("vx_median3d");
+}
+
+extern "C" int vx_wave_conv1d(const float* wave, int samples, const float* wt, int c, int taps, int stride, void* out,
+                              void* stream) {
+  VX_REQUIRE(wave && wt && out, "vx_wave_conv1d: null pointer");
+  VX_REQUIRE(c > 0 && (c % 8) == 0 && taps >= 1 && taps <= WAVE_CONV_MAX_TAPS && stride >= 1 && samples >= taps,
+             "vx_wave_conv1d: bad geometry (c=%d taps=%d stride=%d samples=%d)", c, taps, stride, samples);
+  const int t_out = (samples - taps) / stride + 1;
+  hipLaunchKernelGGL(wave_conv1d_kernel, grid1d((long)t_out * (c / 8)), dim3(256), 0, (hipStream_t)stream, wave, wt,
+                     (bf16_t*)out, t_out, c, taps, stride);
+  return vx_check_launch("vx_wave_conv1d");
 }

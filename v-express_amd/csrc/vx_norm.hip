@@ -234,9 +234,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
       unpack_bf16x8(raw, f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = f[e] * sc[e] + sh[e];
-      if (silu) {
+      if (silu == 1) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+      } else if (silu == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = gelu_f(f[e]);
       }
       *reinterpret_cast<uint4*>(oframe + (size_t)opix(px) * C + ch) = pack_bf16x8(f);
     };
@@ -381,6 +384,7 @@ extern "C" int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int 
   VX_REQUIRE(groups > 0 && (C % groups) == 0, "vx_groupnorm: C=%d not divisible by groups=%d", C, groups);
   VX_REQUIRE(C <= 8 * GN_THREADS * GN_MAX_SETS, "vx_groupnorm: C=%d too large", C);
   VX_REQUIRE(frames > 0 && hw > 0 && slices > 0 && slices <= hw, "vx_groupnorm: bad geometry");
+  VX_REQUIRE(silu >= 0 && silu <= 2, "vx_groupnorm: activation code %d (0 none, 1 SiLU, 2 erf-GELU)", silu);
   VX_REQUIRE(out_pad >= 0 && (out_pad == 0 || (width > 0 && hw % width == 0)),
              "vx_groupnorm: padded output needs the image width (hw=%d width=%d)", hw, width);
   if (out_pad == 0) width = hw;

@@ -96,12 +96,13 @@ def _load():
     lib.vx_vae_postprocess.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     lib.vx_gemm_set_ring_mode.argtypes = [i32]
     lib.vx_median3d.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.vx_wave_conv1d.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp]
     for name in declared_symbols():
         fn = getattr(lib, name)
         if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name",
                         "vx_gemm_splitk_ws_bytes"):
             fn.restype = i32
-    if lib.vx_abi_version() != 5:
+    if lib.vx_abi_version() != 6:
         raise ImportError("libvexpress_hip.so ABI version mismatch")
     return lib
 

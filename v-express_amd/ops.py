@@ -438,6 +438,20 @@ def median3d(video, want_f32=True, want_u8=False):
     return out, u8
 
 
+def wave_conv1d(wave, wt, stride):
+    """First wav2vec2 feature-encoder conv: wave float32 [samples], wt float32 [taps, C] -> bf16 [t_out, C]."""
+    if wave.dtype != torch.float32 or wt.dtype != torch.float32 or not wave.is_contiguous() or not wt.is_contiguous():
+        raise TypeError("wave_conv1d: contiguous float32 tensors expected")
+    taps, c = wt.shape
+    t_out = (wave.numel() - taps) // stride + 1
+    if t_out < 1:
+        raise ValueError(f"wave_conv1d: {wave.numel()} samples are shorter than one {taps}-tap window")
+    out = torch.empty((t_out, c), device=wave.device, dtype=BF16)
+    L.check(_lib.vx_wave_conv1d(_ptr(wave), wave.numel(), _ptr(wt), c, taps, stride, _ptr(out), _stream()),
+            "vx_wave_conv1d")
+    return out
+
+
 def vae_postprocess(x, n, c, h, w):
     """fp32 [n*hw, ld] -> fp32 [n, c, h, w] = clamp(x/2 + 0.5, 0, 1)."""
     out = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)

@@ -116,14 +116,17 @@ class VExpressPipeline:
 
     def prepare_audio_embeddings(self, audio_waveform, video_length, num_pad_audio_frames,
                                  do_classifier_free_guidance):
-        """pipelines/v_express_pipeline.py:374-407.  wav2vec2 (`audio_processor` + `audio_encoder`) is a user-provided
-        transformers module (out of scope); the window construction and the AudioProjection run here
-        (v_express_amd.AudioProjection on the HIP kernels, or any callable with the reference's signature)."""
+        """pipelines/v_express_pipeline.py:374-407.  `audio_processor` / `audio_encoder` are v_express_amd's
+        WaveformProcessor / Wav2Vec2Model (HIP kernels) or the transformers objects the reference uses - anything with
+        the same call signature; the window construction and the AudioProjection run here."""
         if self.audio_encoder is None or self.audio_projection is None or self.audio_processor is None:
             raise NotImplementedError("no audio modules given; pass audio_embeddings=[2,F,5,768]")
         from .prologue import audio_windows
         wav = self.audio_processor(audio_waveform, return_tensors="pt", sampling_rate=16000)["input_values"]
-        enc_dtype = next(self.audio_encoder.parameters()).dtype
+        if getattr(self.audio_encoder, "wants_fp32_input", False):
+            enc_dtype = torch.float32            # the HIP encoder reads the raw waveform in float32
+        else:
+            enc_dtype = next(self.audio_encoder.parameters()).dtype
         emb = self.audio_encoder(wav.to(self.device, enc_dtype)).last_hidden_state
         per_frame = audio_windows(emb, video_length, num_pad_audio_frames).to(enc_dtype)
         out = self.audio_projection(per_frame).unsqueeze(0)

@@ -316,6 +316,66 @@ class AudioProjectionConfig:
     max_seq_len: int = 10
 
 
+@dataclass
+class Wav2Vec2Config:
+    """facebook/wav2vec2-base-960h (the audio encoder inference.py:109-110 loads): transformers Wav2Vec2Config fields
+    that shape the eval-mode forward.  Only the group-norm / post-LayerNorm variant is supported."""
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    conv_dim: Tuple[int, ...] = (512, 512, 512, 512, 512, 512, 512)
+    conv_kernel: Tuple[int, ...] = (10, 3, 3, 3, 3, 2, 2)
+    conv_stride: Tuple[int, ...] = (5, 2, 2, 2, 2, 2, 2)
+    num_conv_pos_embeddings: int = 128
+    num_conv_pos_embedding_groups: int = 16
+    layer_norm_eps: float = 1e-5
+    feat_extract_norm: str = "group"
+    do_stable_layer_norm: bool = False
+    conv_bias: bool = False
+
+    def num_frames(self, samples):
+        """time steps the feature encoder produces for `samples` waveform samples"""
+        for k, s in zip(self.conv_kernel, self.conv_stride):
+            samples = (samples - k) // s + 1
+        return samples
+
+
+def wav2vec2_state_dict(cfg: Wav2Vec2Config = None, seed=48, device="cpu", dtype=torch.float32):
+    """transformers Wav2Vec2Model state_dict (key names of transformers >= 4.3x with torch parametrized weight_norm).
+    Convolutions are drawn Kaiming-normal like the library's own init so that seven GELU layers keep a live signal."""
+    cfg = cfg or Wav2Vec2Config()
+    g = _gen(seed, device, dtype, False)
+    cin = 1
+    for i, (c, k) in enumerate(zip(cfg.conv_dim, cfg.conv_kernel)):
+        p = f"feature_extractor.conv_layers.{i}"
+        g.sd[p + ".conv.weight"] = g.normal((c, cin, k), math.sqrt(2.0 / (cin * k)))
+        if i == 0:
+            g.norm(p + ".layer_norm", c)
+        cin = c
+    h = cfg.hidden_size
+    g.sd["masked_spec_embed"] = g.uniform((h,), 1.0)
+    g.norm("feature_projection.layer_norm", cin)
+    g.linear("feature_projection.projection", cin, h)
+    kp, gp = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
+    p = "encoder.pos_conv_embed.conv"
+    g.sd[p + ".bias"] = g.normal((h,), 0.02)
+    v = g.normal((h, h // gp, kp), 2.0 * math.sqrt(1.0 / (kp * h)))
+    g.sd[p + ".parametrizations.weight.original0"] = (v.float().norm(dim=(0, 1), keepdim=True) *
+                                                      (1.0 + 0.1 * g.normal((1, 1, kp), 1.0).float())).to(v.dtype)
+    g.sd[p + ".parametrizations.weight.original1"] = v
+    g.norm("encoder.layer_norm", h)
+    for i in range(cfg.num_hidden_layers):
+        lp = f"encoder.layers.{i}"
+        for n in ("k", "v", "q", "out"):
+            g.linear(f"{lp}.attention.{n}_proj", h, h)
+        g.norm(lp + ".layer_norm", h)
+        g.linear(lp + ".feed_forward.intermediate_dense", h, cfg.intermediate_size)
+        g.linear(lp + ".feed_forward.output_dense", cfg.intermediate_size, h)
+        g.norm(lp + ".final_layer_norm", h)
+    return g.sd
+
+
 def kps_guider_state_dict(cfg: KpsGuiderConfig = None, seed=45, device="cpu", dtype=torch.float32):
     """VKpsGuider state_dict (modules/v_kps_guider.py:18-33).  conv_out is zero-initialised in the reference
     (zero_module); here it is drawn N(0, 0.02^2) so the path is numerically live."""
