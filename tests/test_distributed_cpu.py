@@ -22,27 +22,49 @@ def fake_unit(latents, window, half, t):
     return torch.tanh(x * (1.0 + 0.25 * half) + 0.001 * t + x.roll(1, dims=1) * 0.3)
 
 
-def run_loop(rank, world, F, cs, co, steps, dc):
+def fake_unit_sharded(latents, window, lo, f_loc, half, t, shard):
+    """fake_unit on this rank's f_loc frames of the window; the frame roll (the stand-in for temporal attention)
+    runs in the pixel-shard layout between the two all-to-alls, like the motion modules do."""
+    x = latents[0][:, window[lo:lo + f_loc]]                    # [4, f_loc, h, w]
+    c, _, h, w = x.shape
+    tok = x.permute(1, 2, 3, 0).reshape(f_loc, h * w, c)       # [b*f_loc, hw, C] with b = 1
+    pix = shard.to_pixel_shard(tok, 1, f_loc)                   # [f, hw/S, C]
+    rolled = shard.to_frame_shard(pix.roll(1, dims=0), 1, f_loc)
+    rolled = rolled.reshape(f_loc, h, w, c).permute(3, 0, 1, 2)
+    return torch.tanh(x * (1.0 + 0.25 * half) + 0.001 * t + rolled * 0.3)
+
+
+def run_loop(rank, world, F, cs, co, steps, dc, S=1):
     windows = OL.uniform_windows(F, cs, co)
     plan = context.overlap_plan(windows, F)
     f = len(windows[0])
-    sch = distributed.UnitSchedule(len(windows), world)
+    sch = distributed.UnitSchedule(len(windows), world, S)
+    shard = dc.frame_shard(S)
+    f_loc, lo = f // S, (rank % S) * (f // S)
     s = DDIMScheduler(**SCHED_KW)
     s.set_timesteps(steps)
     lat = torch.randn(1, 4, F, 4, 4, generator=torch.Generator().manual_seed(0))
     for t in s.timesteps.tolist():
-        local = torch.zeros(sch.max_units, 4, f, 4, 4)
+        local = torch.zeros(sch.max_units, 4, f_loc, 4, 4)
         for w, halves in sch.calls(rank):
             for hlf in halves:
-                local[sch.slot[(w, hlf)][1]] = fake_unit(lat, windows[w], hlf, t)
+                if shard is None:
+                    local[sch.slot[(w, hlf)][1]] = fake_unit(lat, windows[w], hlf, t)
+                else:
+                    local[sch.slot[(w, hlf)][1]] = fake_unit_sharded(lat, windows[w], lo, f_loc, hlf, t, shard)
         gathered = dc.all_gather_units(local, sch.max_units)
+        full = {}
+        for wi in range(len(windows)):
+            for hlf in range(2):
+                ranks, slot = sch.unit_ranks((wi, hlf))
+                full[(wi, hlf)] = torch.cat([gathered[r, slot] for r in ranks], dim=1)      # frame shards in order
         sa, s1a, sap, s1ap = s.step_coefficients(t)
         new = lat.clone()
         for fr in plan["step_frames"]:
             v = None
             for (wi, li) in plan["terms"][fr]:
-                u = gathered[sch.slot[(wi, 0)]][:, li]
-                c = gathered[sch.slot[(wi, 1)]][:, li]
+                u = full[(wi, 0)][:, li]
+                c = full[(wi, 1)][:, li]
                 term = (u + 3.5 * (c - u)) / float(plan["counts"][fr])
                 v = term if v is None else v + term
             x = lat[0, :, fr]
@@ -51,12 +73,12 @@ def run_loop(rank, world, F, cs, co, steps, dc):
     return lat
 
 
-def _worker(rank, world, port, F, cs, co, steps, q):
+def _worker(rank, world, port, F, cs, co, steps, q, S=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dc = distributed.DistContext.from_env()
     assert dc.enabled and dc.world_size == world and dc.rank == rank
-    out = run_loop(rank, world, F, cs, co, steps, dc)
+    out = run_loop(rank, world, F, cs, co, steps, dc, S)
     lo, hi = distributed.split_frames(F, world)[rank]
     frames = torch.zeros(distributed.split_frames(F, world)[0][1], 3)
     frames[:hi - lo] = float(rank + 1)
@@ -86,3 +108,45 @@ def test_sharded_loop_is_bit_identical_to_single_process(F, cs, co):
         assert torch.equal(out, ref), f"rank {rank} diverged from the single-process loop"
         lo, hi = distributed.split_frames(F, world)[0]
         assert (owner[:hi] == 1).all() and (owner[hi:] == 2).all()
+
+
+def _spawn(world, F, cs, co, steps, S):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, F, cs, co, steps, q, S)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.parametrize("world,S,F,cs,co", [(2, 2, 8, 8, 2), (4, 2, 8, 8, 2), (4, 2, 14, 8, 2), (4, 4, 8, 8, 2)])
+def test_frame_sharded_units_are_bit_identical_to_single_process(world, S, F, cs, co):
+    """S ranks share each (window, CFG-half) unit, each holding f/S frames; the temporal mixing
+    runs in the pixel-shard layout between two all-to-alls inside the unit's process group (world/S groups work on
+    different units concurrently).  Data movement only => bit-identical to the single-process loop."""
+    ref = run_loop(0, 1, F, cs, co, 2, distributed.DistContext())
+    for rank, out, _ in _spawn(world, F, cs, co, 2, S):
+        assert torch.equal(out, ref), f"rank {rank} diverged from the single-process loop"
+
+
+def test_frame_shard_schedule_and_auto_policy():
+    D = distributed
+    # a 16-frame clip (1 window = 2 units) on 8 ranks: 4 ranks per unit; long clips keep S = 1
+    assert D.choose_frame_shards(1, 8, 16, 64) == 4 and D.choose_frame_shards(10, 8, 16, 64) == 1
+    assert D.choose_frame_shards(1, 2, 16, 64) == 1 and D.choose_frame_shards(2, 8, 16, 64) == 2
+    assert D.choose_frame_shards(1, 8, 12, 64) == 4 and D.choose_frame_shards(1, 8, 6, 64) == 2    # S | window length
+    assert D.choose_frame_shards(1, 8, 16, 2) == 2                                                   # S | coarsest hw
+    u = D.UnitSchedule(1, 8, 4)
+    assert u.groups == 2 and u.calls(0) == u.calls(3) == [(0, [0])] and u.calls(4) == u.calls(7) == [(0, [1])]
+    assert u.unit_ranks((0, 0)) == ([0, 1, 2, 3], 0) and u.unit_ranks((0, 1)) == ([4, 5, 6, 7], 0)
+    u = D.UnitSchedule(3, 4, 2)                              # 6 units over 2 groups of 2 ranks
+    assert [u.calls(r) for r in range(4)] == [[(0, [0, 1]), (1, [0])]] * 2 + [[(1, [1]), (2, [0, 1])]] * 2
+    with pytest.raises(ValueError):
+        D.UnitSchedule(1, 6, 4)

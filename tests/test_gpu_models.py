@@ -242,3 +242,31 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["windows"] == 2 and d["config"]["frames"] == 28
     assert d["value"] > 0 and d["scaling"] == "weak" and d["roofline"]["achieved"] > 0
+
+
+@pytest.mark.parametrize("world,S,F,cf,co", [(2, 2, 8, 8, 2), (4, 0, 8, 8, 2), (4, 2, 14, 8, 2)])
+def test_frame_sharded_loop_matches_single_rank(world, S, F, cf, co, tmp_path):
+    """SURVEY.md §8f rank 1 on the real kernels: S ranks per (window, CFG-half) unit, each running the UNet on f/S
+    frames with the motion modules exchanging layouts through all-to-alls inside the unit's process group (ranks folded
+    onto this GPU, gloo + host staging).  Against the single-rank loop on the same inputs.  Every kernel is
+    row-independent, so the only differences can come from tile-configuration choices that look at the per-rank row
+    count: bf16-rounding level (<= 1e-2 relative L2), usually exactly zero.  S = 0: the automatic policy (4 ranks,
+    one window -> 2 ranks per unit)."""
+    _need_gpu()
+    import subprocess
+    import sys
+    import dist_gpu_worker as W
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "lat.pt")
+    env = dict(os.environ, VX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29540 + world + S),
+           os.path.join(root, "tests", "dist_gpu_worker.py"), out, str(F), str(cf), str(co), "2", str(S)]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = torch.load(out)
+    ref = W.run(F, cf, co, 2, 0)                        # this process: no process group -> single rank
+    err = rel_l2(got, ref)
+    print(f"[frame shards world={world} S={S} F={F}] relL2 vs single rank = {err:.3g}, "
+          f"bit-identical = {torch.equal(got, ref)}")
+    assert torch.isfinite(got).all() and err <= 1e-2, err

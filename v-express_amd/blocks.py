@@ -180,27 +180,37 @@ def _spatial_transformer_write(P, x, *, frames, H, W, heads, groups, ehs):
     return out.view(frames, hw, c), bank
 
 
-def motion_module(P, x, *, b, f, H, W, heads, groups):
+def motion_module(P, x, *, b, f, H, W, heads, groups, shard=None):
     with ops.frame_rows(H * W, items=b):
-        return _motion_module(P, x, b=b, f=f, H=H, W=W, heads=heads, groups=groups)
+        return _motion_module(P, x, b=b, f=f, H=H, W=W, heads=heads, groups=groups, shard=shard)
 
 
-def _motion_module(P, x, *, b, f, H, W, heads, groups):
+def _motion_module(P, x, *, b, f, H, W, heads, groups, shard=None):
     """VanillaTemporalModule -> TemporalTransformer3DModel.forward (modules/motion_module.py:146-182), one
     TemporalTransformerBlock (:236-259): 2x [LN, +pe, QKV, attention over f, out-proj + residual], LN, GEGLU FF.
-    The additive sinusoid table goes through the LayerNorm kernel (pe enters Q, K and V: :365-366)."""
+    The additive sinusoid table goes through the LayerNorm kernel (pe enters Q, K and V: :365-366).
+    shard (distributed.FrameShard): x holds only this rank's f frames of the window.  The GroupNorm (per-frame
+    statistics) runs on them; the temporal transformer - per token except the attention over the frame axis - runs on
+    all shard.size * f frames of this rank's pixel slice between two all-to-alls; the output projection and the
+    residual add are per token again and run back in the frame-shard layout."""
     frames, hw, c = b * f, H * W, x.shape[-1]
-    m = frames * hw
     d = c // heads
     n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
+    f_all, hw_t = f, hw
+    if shard is not None:
+        n = shard.to_pixel_shard(n, b, f)
+        f_all, hw_t = f * shard.size, hw // shard.size
+    m = b * f_all * hw_t
     h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b)
     for A in P.attn:
-        ln = ops.layernorm(h, A.norm.g, A.norm.b, add=A.pe, add_rows_per_entry=hw, add_entries=f)
+        ln = ops.layernorm(h, A.norm.g, A.norm.b, add=A.pe, add_rows_per_entry=hw_t, add_entries=f_all)
         qkv = ops.gemm(ln, A.attn.wqkv, A.attn.bqkv)
-        a = ops.temporal_attention(qkv, b=b, f=f, hw=hw, heads=heads, head_dim=d)
+        a = ops.temporal_attention(qkv, b=b, f=f_all, hw=hw_t, heads=heads, head_dim=d)
         ops.gemm(a, A.attn.out.w, A.attn.out.b, residual=h, out=h)
     _feed_forward(P, h)
-    out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x.view(m, c))
+    if shard is not None:
+        h = shard.to_frame_shard(h.view(b * f_all, hw_t, c), b, f).view(frames * hw, c)
+    out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x.view(frames * hw, c))
     return out.view(frames, hw, c)
 
 

@@ -7,6 +7,12 @@ invariant: within one timestep every window's UNet call reads only the step-star
 So a timestep is 2*W independent units; each rank computes its units, ONE all-gather per timestep exchanges the
 raw conv_out predictions (<= 2 MiB per unit), and every rank redundantly applies CFG + mean-overlap + DDIM to the
 full clip — sums of <= 2 terms, identical bits on every rank, no all-reduce.
+
+Frame sharding inside a unit ("Ulysses-style"): when a clip has fewer units than ranks (a
+16-frame clip is 2 units), S ranks share one unit, each holding f/S frames of the window.  Everything in the UNet is
+per-frame except the temporal attention of the 21 motion modules, which needs all f frames of a pixel: there the group
+switches layout with one all-to-all ([b, f/S, hw, C] -> [b, f, hw/S, C]), runs the whole temporal transformer on its
+pixel slice, and switches back with a second all-to-all before the (per-token) output projection + residual.
 """
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
@@ -41,12 +47,27 @@ def group_calls(units: List[Tuple[int, int]]) -> List[Tuple[int, List[int]]]:
     return calls
 
 
-class UnitSchedule:
-    """Static (window, cfg_half) -> (rank, slot) map of one clip; identical on every rank."""
+def choose_frame_shards(num_windows: int, world_size: int, window_frames: int, min_hw: int) -> int:
+    """Largest power-of-two S such that the clip still has too few units for the ranks without it (2*W*S <= world),
+    S divides the world size, the window length and the token count of the coarsest UNet level."""
+    s = 1
+    while (2 * num_windows * (2 * s) <= world_size and world_size % (2 * s) == 0 and window_frames % (2 * s) == 0
+           and min_hw % (2 * s) == 0):
+        s *= 2
+    return s
 
-    def __init__(self, num_windows: int, world_size: int):
-        self.num_windows, self.world_size = num_windows, world_size
-        self.assign = partition_units(num_windows, world_size)
+
+class UnitSchedule:
+    """Static (window, cfg_half) -> (rank group, slot) map of one clip; identical on every rank.  With
+    frame_shards = S > 1 the ranks form world/S groups of S consecutive ranks; a group owns units like a single rank
+    does for S = 1 and member j of the group computes frames [j*f/S, (j+1)*f/S) of each of them."""
+
+    def __init__(self, num_windows: int, world_size: int, frame_shards: int = 1):
+        if frame_shards < 1 or world_size % frame_shards:
+            raise ValueError(f"frame_shards={frame_shards} must divide the world size {world_size}")
+        self.num_windows, self.world_size, self.frame_shards = num_windows, world_size, frame_shards
+        self.groups = world_size // frame_shards
+        self.assign = partition_units(num_windows, self.groups)
         self.max_units = max(len(a) for a in self.assign)
         self.slot = {}
         for r, units in enumerate(self.assign):
@@ -54,7 +75,12 @@ class UnitSchedule:
                 self.slot[u] = (r, s)
 
     def calls(self, rank: int):
-        return group_calls(self.assign[rank])
+        return group_calls(self.assign[rank // self.frame_shards])
+
+    def unit_ranks(self, unit):
+        """(ranks holding the frame shards of `unit`, in frame order), slot."""
+        g, s = self.slot[unit]
+        return [g * self.frame_shards + j for j in range(self.frame_shards)], s
 
     def rounds(self) -> int:
         """Half-window UNet passes on the critical path of one timestep (ideal speed-up = 2W / rounds)."""
@@ -98,6 +124,64 @@ class DistContext:
         if not self.enabled:
             return local.unsqueeze(0)
         return self._all_gather(local)
+
+    def frame_shard(self, frame_shards: int) -> Optional["FrameShard"]:
+        """This rank's FrameShard for groups of `frame_shards` consecutive ranks (None for 1).  Creating the process
+        groups is collective: every rank must call this with the same value (the pipeline does, once per clip)."""
+        if frame_shards <= 1:
+            return None
+        if self.world_size % frame_shards:
+            raise ValueError(f"frame_shards={frame_shards} must divide the world size {self.world_size}")
+        cache = self.__dict__.setdefault("_shard_groups", {})
+        if frame_shards not in cache:
+            mine = None
+            for g in range(self.world_size // frame_shards):
+                ranks = list(range(g * frame_shards, (g + 1) * frame_shards))
+                grp = dist.new_group(ranks)
+                if self.rank in ranks:
+                    mine = grp
+            cache[frame_shards] = mine
+        return FrameShard(self.rank % frame_shards, frame_shards, cache[frame_shards])
+
+
+class FrameShard:
+    """Layout switch of one frame-sharded unit between its S ranks (one all-to-all each way).
+    frame shard:  [b * f/S, hw, C]   - this rank's frames of every batch row, all pixels
+    pixel shard:  [b * f, hw/S, C]   - all frames, this rank's pixel slice."""
+
+    def __init__(self, index: int, size: int, group=None):
+        self.index, self.size, self.group = index, size, group
+
+    def _all_to_all(self, send: torch.Tensor) -> torch.Tensor:
+        """send[r] goes to member r; the result's [s] came from member s."""
+        recv = torch.empty_like(send)
+        if send.is_cuda and dist.get_backend(self.group) != "nccl":
+            # control-flow testing on a single-GPU box (gloo): stage through the host; never the measured path
+            hs = send.cpu()
+            hr = torch.empty_like(hs)
+            dist.all_to_all_single(hr, hs, group=self.group)
+            recv.copy_(hr)
+            return recv
+        dist.all_to_all_single(recv, send, group=self.group)
+        return recv
+
+    def to_pixel_shard(self, x: torch.Tensor, b: int, f_loc: int) -> torch.Tensor:
+        n, hw, c = x.shape
+        S = self.size
+        if n != b * f_loc or hw % S:
+            raise ValueError(f"frame shard [{n}, {hw}, {c}] does not split over {S} ranks (b={b}, f/S={f_loc})")
+        send = x.view(n, S, hw // S, c).transpose(0, 1).contiguous()                   # [S(dst), b*f_loc, hw/S, C]
+        recv = self._all_to_all(send)                                                    # [S(src), b*f_loc, hw/S, C]
+        return recv.view(S, b, f_loc, hw // S, c).permute(1, 0, 2, 3, 4).reshape(b * S * f_loc, hw // S, c)
+
+    def to_frame_shard(self, h: torch.Tensor, b: int, f_loc: int) -> torch.Tensor:
+        n, hw_t, c = h.shape
+        S = self.size
+        if n != b * S * f_loc:
+            raise ValueError(f"pixel shard [{n}, {hw_t}, {c}] is not b*f = {b}*{S * f_loc} frames")
+        send = h.view(b, S, f_loc, hw_t, c).permute(1, 0, 2, 3, 4).contiguous()         # [S(dst), b, f_loc, hw/S, C]
+        recv = self._all_to_all(send)                                                    # [S(src = pixel slice), ...]
+        return recv.view(S, b * f_loc, hw_t, c).transpose(0, 1).reshape(b * f_loc, S * hw_t, c)
 
 
 def split_frames(num_frames: int, world_size: int) -> List[Tuple[int, int]]:

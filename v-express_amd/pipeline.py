@@ -24,7 +24,7 @@ import torch
 
 from . import ops
 from .context import get_context_scheduler, overlap_plan
-from .distributed import DistContext, UnitSchedule, split_frames
+from .distributed import DistContext, UnitSchedule, choose_frame_shards, split_frames
 from .mutual_self_attention import ReferenceAttentionControl
 
 
@@ -42,6 +42,9 @@ class VExpressPipeline:
         self.scheduler = scheduler
         self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
         self.dist = DistContext.from_env()
+        # ranks per (window, CFG-half) unit, each holding 1/S of the window's frames; None = automatic (S > 1 only
+        # when the clip has fewer units than ranks, distributed.choose_frame_shards)
+        self.frame_shards = None
         self.last_timing = {}
 
     # ------------------------------------------------------------------ plumbing
@@ -171,11 +174,16 @@ class VExpressPipeline:
         terms = terms.to(dev)
         frame_ids = torch.tensor(sf, dtype=torch.int32, device=dev)
         counts = torch.tensor([float(plan["counts"][fr]) for fr in sf], dtype=torch.float32, device=dev)
-        # work units of this rank
-        sched_u = UnitSchedule(nW, dc.world_size)
-        my_calls, max_units, unit_slot = sched_u.calls(dc.rank), sched_u.max_units, sched_u.slot
+        # work units of this rank; S > 1: the window's frames are split over S ranks per unit (short clips)
+        S = self.frame_shards or choose_frame_shards(nW, dc.world_size, f, (H // 8) * (W // 8))
+        sched_u = UnitSchedule(nW, dc.world_size, S)
+        my_calls, max_units = sched_u.calls(dc.rank), sched_u.max_units
+        shard = dc.frame_shard(S)
+        f_loc = f // S
+        lo = (dc.rank % S) * f_loc                     # this rank's frames of every window it works on: [lo, lo+f_loc)
+        my_slot = {u: sched_u.slot[u][1] for u in sched_u.slot}
         n_out = 8
-        local = torch.zeros((max_units, f * hw, n_out), device=dev, dtype=torch.float32)
+        local = torch.zeros((max_units, f_loc * hw, n_out), device=dev, dtype=torch.float32)
         preds = torch.empty((nW, C, f, hw), device=dev, dtype=torch.float32)
         pair = torch.empty((2 * f * hw, n_out), device=dev, dtype=torch.float32)
         do_cfg = guidance_scale > 1.0
@@ -188,25 +196,29 @@ class VExpressPipeline:
         calls = []
         for wi, halves in my_calls:
             hsel = torch.tensor(halves, device=dev)
-            kps = kps_tokens.index_select(0, hsel).index_select(1, win_ids_long[wi]).reshape(len(halves) * f, hw, -1)
-            ehs = audio.index_select(0, hsel).index_select(1, win_ids_long[wi])
+            ids_long = win_ids_long[wi][lo:lo + f_loc]
+            kps = kps_tokens.index_select(0, hsel).index_select(1, ids_long).reshape(len(halves) * f_loc, hw, -1)
+            ehs = audio.index_select(0, hsel).index_select(1, ids_long)
             ehs = ehs.reshape(-1, ehs.shape[-1]).contiguous()
             # the audio K | V of all 16 transformer blocks is step-invariant: once per clip and window
-            calls.append((wi, halves, win_ids[wi], kps.contiguous(), ehs, unet.precompute_audio_kv(ehs)))
+            calls.append((wi, halves, win_ids[wi][lo:lo + f_loc].contiguous(), kps.contiguous(), ehs,
+                          unet.precompute_audio_kv(ehs)))
         for i, t in enumerate(timesteps):
             t = int(t)
             for wi, halves, ids, kps, ehs, akv in calls:
                 x_in = ops.gather_latents(latents, ids, reps=len(halves))
-                out = unet.forward_tokens(x_in, t, ehs, kps, b=len(halves), f=f, H=H, W=W, batch_rows=halves,
-                                          audio_kv=akv, audio_zero=[audio_is_zero[hh] for hh in halves])
+                out = unet.forward_tokens(x_in, t, ehs, kps, b=len(halves), f=f_loc, H=H, W=W, batch_rows=halves,
+                                          audio_kv=akv, audio_zero=[audio_is_zero[hh] for hh in halves],
+                                          frame_shard=shard)
                 for j, hlf in enumerate(halves):
-                    local[unit_slot[(wi, hlf)][1]].copy_(out[j * f * hw:(j + 1) * f * hw])
-            gathered = dc.all_gather_units(local, max_units)          # [world, max_units, f*hw, 8]
+                    local[my_slot[(wi, hlf)]].copy_(out[j * f_loc * hw:(j + 1) * f_loc * hw])
+            gathered = dc.all_gather_units(local, max_units)          # [world, max_units, (f/S)*hw, 8]
             for wi in range(nW):
-                ru, su = unit_slot[(wi, 0)]
-                rc, sc = unit_slot[(wi, 1)]
-                pair[:f * hw].copy_(gathered[ru, su])
-                pair[f * hw:].copy_(gathered[rc, sc])
+                for hlf in range(2):
+                    ranks, slot = sched_u.unit_ranks((wi, hlf))
+                    for j, r in enumerate(ranks):                    # frame shards in frame order
+                        base = (hlf * f + j * f_loc) * hw
+                        pair[base:base + f_loc * hw].copy_(gathered[r, slot])
                 ops.cfg_combine(pair, C, f, hw, guidance_scale, preds[wi])
             ops.overlap_ddim_step(latents, preds, terms, frame_ids, counts, self.scheduler.step_coefficients(t))
             if callback is not None and i % callback_steps == 0:

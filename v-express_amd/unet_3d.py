@@ -261,17 +261,24 @@ class UNet3DConditionModel(_UNetBase):
         return out
 
     def forward_tokens(self, x_in, timestep, ehs, kps, *, b, f, H, W, batch_rows=None, audio_kv=None,
-                       audio_zero=None):
+                       audio_zero=None, frame_shard=None):
         """x_in: bf16 [b*f, HW, 8] (latent channels zero-padded), ehs: bf16 [b*f*n_ctx, 768],
         kps: bf16 [b*f, HW, C0] or None -> fp32 [b*f*HW, 8] (columns >= out_channels are zero).
         batch_rows: which rows of the installed banks the b batch rows use (default 0..b-1; a lone CFG half
         running on another GPU passes [0] or [1]).  audio_kv: `precompute_audio_kv(ehs)`; audio_zero: per batch row,
-        True when that row's audio tokens are all zero (its audio cross-attention then reduces to the output bias)."""
+        True when that row's audio tokens are all zero (its audio cross-attention then reduces to the output bias).
+        frame_shard (distributed.FrameShard): all tensors hold only this rank's f of the window's f * size frames; the
+        motion modules exchange layouts inside the shard group."""
         P, cfg = self._prepared(), self.cfg
         g, eps, heads = cfg.norm_num_groups, cfg.norm_eps, cfg.heads
         frames = b * f
-        if f > cfg.temporal_max_len:
-            raise ValueError(f"window length {f} exceeds the positional-encoding table ({cfg.temporal_max_len})")
+        f_window = f * (frame_shard.size if frame_shard is not None else 1)
+        if f_window > cfg.temporal_max_len:
+            raise ValueError(f"window length {f_window} exceeds the positional-encoding table "
+                             f"({cfg.temporal_max_len})")
+        if frame_shard is not None and ((H // 8) * (W // 8)) % frame_shard.size:
+            raise ValueError(f"{frame_shard.size} frame shards do not divide the {H // 8}x{W // 8} tokens of the "
+                             "coarsest level")
         rows = self.time_rows(timestep, b)
         rpg_scale = f
         banks = self.banks
@@ -298,7 +305,8 @@ class UNet3DConditionModel(_UNetBase):
                 x = B.spatial_transformer_read(P[ap], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g, ehs=ehs,
                                                bank=[banks[ap][r] for r in rowsel], w_ref=w_ref, w_aud=w_aud,
                                                kv=None if audio_kv is None else audio_kv[ap], audio_zero=audio_zero)
-            return B.motion_module(P[f"{p}.motion_modules.{j}"], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g)
+            return B.motion_module(P[f"{p}.motion_modules.{j}"], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g,
+                                   shard=frame_shard)
 
         for blk in plan["down"]:
             p = blk["prefix"]
@@ -316,7 +324,8 @@ class UNet3DConditionModel(_UNetBase):
                                        w_ref=w_ref, w_aud=w_aud,
                                        kv=None if audio_kv is None else audio_kv["mid_block.attentions.0"],
                                        audio_zero=audio_zero)
-        x = B.motion_module(P["mid_block.motion_modules.0"], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g)
+        x = B.motion_module(P["mid_block.motion_modules.0"], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g,
+                            shard=frame_shard)
         x = B.resnet_block(P["mid_block.resnets.1"], x, frames, h_, w_, groups=g, eps=eps,
                            temb=self._temb(rows, "mid_block.resnets.1"), rows_per_group=rpg_scale * h_ * w_, items=b)
         for blk in plan["up"]:
