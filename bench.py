@@ -245,6 +245,8 @@ def main():
     fps = F * args.steps / elapsed
     scale = (args.size / 512.0) ** 2
     fpf = flop_per_frame(F, len(windows), args.ddim_steps, scale)
+    from v_express_amd.distributed import choose_frame_shards
+    fshards = pipe.frame_shards or choose_frame_shards(len(windows), world, ctx, (args.size // 64) ** 2)
 
     result = {
         "metric": "decoded frames/sec at 512x512, 25 DDIM steps", "value": fps, "unit": "frames/s",
@@ -254,7 +256,9 @@ def main():
         "config": {"workload": (f"{args.size}x{args.size}, {F} frames ({len(windows)} window(s) of {ctx}, overlap {ovl}), "
                                 f"{args.ddim_steps} DDIM steps, CFG 3.5, random-init UNet3D + ReferenceNet banks + "
                                 "sd-vae-ft-mse decode"),
-                   "frames": F, "windows": len(windows), "parallelism": f"window x CFG-half units over {world} GPU(s)"},
+                   "frames": F, "windows": len(windows), "frame_shards": fshards,
+                   "parallelism": (f"window x CFG-half units over {world} GPU(s)" +
+                                   (f", {fshards} frame shards per unit" if fshards > 1 else ""))},
         "prologue_ms": 1e3 * prologue_s, "model_build_s": t_build,
     }
 
