@@ -85,6 +85,45 @@ def test_unet_forward_vs_oracle_and_golden(name):
         assert torch.equal(y[0].cpu(), got[half].float().cpu()), f"CFG half {half} is not bit-identical when run alone"
 
 
+def test_full_size_unet_forward_vs_oracle():
+    """BASELINE.json configs[1] geometry against the oracle DIRECTLY: SD-1.5 widths, 512x512 (64x64 latents: 4096 tokens,
+    head dims 40 / 80 / 160), CFG batch of 2 - the shapes on which the ring GEMM, the pre-padded convs, attn2 and the
+    split-K path actually run - at f = 2 frames, the sample bench.py's cpu_baseline leg times (the fp32 oracle needs
+    ~20 s per forward on the host cores; 16 frames would take minutes).  ReferenceNet banks and one UNet3D CFG forward,
+    same tolerances as the small cases."""
+    _need_gpu()
+    from oracle import unet as OU
+    from v_express_amd import ReferenceAttentionControl, synth
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(64, os.cpu_count() or 1))           # the oracle is slower on all 256 hardware threads
+    try:
+        kw, F, h, w, t = cases.FULL, 2, 64, 64, 519
+        cfg, ocfg = cases.unet_cfg(kw), cases.oracle_cfg(kw)
+        sd3, sd2 = synth.unet3d_state_dict(cfg), synth.refnet_state_dict(cfg)
+        inp = synth.synthetic_inputs(cfg, F, h, w)
+        unet, refnet = build_models(kw, sd3, sd2)
+        writer = ReferenceAttentionControl(refnet, do_classifier_free_guidance=True, mode="write", fusion_blocks="full")
+        reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", fusion_blocks="full",
+                                           reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD)
+        refnet(inp["ref_latents"], timestep=0, encoder_hidden_states=torch.zeros(1, 1, 768), return_dict=False)
+        with torch.no_grad():
+            obanks = OU.refnet_banks(sd2, ocfg, inp["ref_latents"])
+        worst = max((rel_l2(refnet.banks[k].view_as(obanks[k][0]), obanks[k][0]), k) for k in obanks)
+        assert worst[0] <= 3e-2, f"bank parity at 64x64 latents: worst relL2 {worst}"
+        reader.update(writer, True)
+        x = inp["latents"].repeat(2, 1, 1, 1, 1)
+        ehs = inp["audio_embeddings"].reshape(-1, 5, 768)
+        got = unet(x, t, encoder_hidden_states=ehs, kps_features=inp["kps_features"], return_dict=False)[0]
+        with torch.no_grad():
+            ref = OU.unet3d_forward(sd3, ocfg, x, t, ehs, inp["kps_features"], OU.reader_banks(obanks), cases.W_REF,
+                                    cases.W_AUD)
+        r, c = rel_l2(got, ref), cosine(got, ref)
+        print(f"[full 512x512 f=2] worst bank relL2={worst[0]:.4g} ({worst[1]}); forward relL2={r:.4g} cosine={c:.6f}")
+        assert torch.isfinite(got).all() and r <= 3e-2 and c >= 0.999, (r, c)
+    finally:
+        torch.set_num_threads(nthreads)
+
+
 @pytest.mark.parametrize("name", list(cases.PIPELINE_CASES))
 def test_pipeline_vs_reference_golden(name):
     _need_gpu()
