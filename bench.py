@@ -249,7 +249,7 @@ def main():
     fshards = pipe.frame_shards or choose_frame_shards(len(windows), world, ctx, (args.size // 64) ** 2)
 
     result = {
-        "metric": "decoded frames/sec at 512x512, 25 DDIM steps", "value": fps, "unit": "frames/s",
+        "metric": f"decoded frames/sec at {args.size}x{args.size}, {args.ddim_steps} DDIM steps", "value": fps, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
