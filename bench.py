@@ -39,9 +39,16 @@ UNET_TFLOP_PER_FRAME_FWD = 1.277   # 40.86 TFLOP per CFG forward
 VAE_TFLOP_PER_FRAME = 2.515
 
 
+UNET_SDPA_TFLOP_PER_FRAME_FWD = 0.245   # attn1 + attn1_5 SDPA (2 x 3.92 TFLOP / 32 frame-forwards): quadratic in the tokens
+VAE_SDPA_TFLOP_PER_FRAME = 0.0344       # single-head mid attention over 4096 tokens, d = 512
+
+
 def flop_per_frame(num_frames, windows, steps, scale):
-    unet = steps * 2 * UNET_TFLOP_PER_FRAME_FWD * (16 * windows / num_frames)
-    return (unet + VAE_TFLOP_PER_FRAME) * scale
+    """Algorithmic TFLOP per decoded frame.  `scale` = pixel count relative to 512x512: the SDPA terms
+    grow with scale^2, everything else with scale (768x768: 113.97 TFLOP per CFG forward, 5.754 per decoded frame)."""
+    fwd = (UNET_TFLOP_PER_FRAME_FWD - UNET_SDPA_TFLOP_PER_FRAME_FWD) * scale + UNET_SDPA_TFLOP_PER_FRAME_FWD * scale ** 2
+    vae = (VAE_TFLOP_PER_FRAME - VAE_SDPA_TFLOP_PER_FRAME) * scale + VAE_SDPA_TFLOP_PER_FRAME * scale ** 2
+    return steps * 2 * fwd * (16 * windows / num_frames) + vae
 
 
 def _pmc_traffic(kernel_key):
