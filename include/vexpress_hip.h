@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 6
+#define VX_ABI_VERSION 7
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
@@ -120,6 +120,17 @@ int vx_layernorm(const void* x, int ldx, int rows, int c, float eps, const float
  * vt: bf16 [kv_batches, heads, head_dim, vt_pitch] (keys contiguous); out: bf16 rows, stride ldo. */
 int vx_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_pitch, void* out, int ldo,
                  int batch, int heads, int n_q, int n_kv, int head_dim, int q_per_kv, float scale, void* stream);
+
+/* vx_attention with the bounded softmax shift (the 64x64 level's d = 40 kernel; other head dims ignore the table and
+ * run vx_attention): m_i = scale |q_i| key_norm_max[kv batch, head] >= max_j s_ij replaces the running row max, which
+ * removes the per-tile max / rescale work from a VALU-bound kernel.  Same result up to fp32 rounding; rows whose
+ * probabilities would underflow under the looser shift are detected in the kernel and recomputed exactly.
+ * key_norm_max: float32 [batch / q_per_kv, heads] from vx_key_norm_max on the same k. */
+int vx_key_norm_max(const void* k, int ldk, int kv_batches, int heads, int n_kv, int head_dim, float* out,
+                    void* stream);
+int vx_attention_bounded(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_pitch, void* out,
+                         int ldo, int batch, int heads, int n_q, int n_kv, int head_dim, int q_per_kv, float scale,
+                         const float* key_norm_max, void* stream);
 
 /* ---- Temporal self-attention over the frame axis (one sequence per (batch row, pixel, head)) ---------------
  * Replaces VersatileAttention.forward (modules/motion_module.py:351-388) incl. both einops transposes:

@@ -366,6 +366,51 @@ def test_flash_attention_softmax_rescale_path(ops):
     check(out, ref, "attention with late max spike", rel=1e-2, mx=2 ** -6)
 
 
+def test_key_norm_max(ops):
+    for kvb, heads, n, d in ((3, 8, 100, 40), (1, 8, 4096, 40), (2, 4, 7, 64)):
+        k = rnd(kvb * n, heads * d, seed=n)
+        got = ops.key_norm_max(k, kv_batches=kvb, heads=heads, n_kv=n, head_dim=d)
+        ref = k.float().view(kvb, n, heads, d).norm(dim=-1).amax(dim=1).reshape(-1)
+        assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6), (got, ref)
+
+
+@pytest.mark.parametrize("qs,ks,spike", [(1.0, 1.0, 0.0), (6.0, 6.0, 0.0), (25.0, 25.0, 0.0), (1.0, 1.0, 300.0),
+                                         (3.0, 3.0, 40.0)])
+def test_bounded_softmax_attention_matches_exact(ops, qs, ks, spike):
+    """vx_attention_bounded (d = 40): the Cauchy-Schwarz shift c |q_i| Kmax instead of the running row max.
+    qs / ks scale the query / key magnitudes (scores up to ~ +-qs*ks*40/sqrt(40)); `spike` plants one key with a huge
+    norm that is orthogonal-ish to most queries: Kmax becomes useless as a bound for them, every probability underflows
+    under the shift, and the in-kernel check must send those blocks through the exact recompute.  In all cases the
+    result has to agree with the exact kernel (vx_attention) and with the fp32 reference."""
+    batch, heads, n_q, n_kv, d = 2, 8, 200, 333, 40
+    c = heads * d
+    q = (rnd(batch * n_q, c).float() * qs).to(BF)
+    k = rnd(batch * n_kv, c, seed=1).float() * ks
+    if spike:
+        k[17] = spike * torch.sign(k[17])                       # |k| = spike * sqrt(40) per head
+        k[n_kv + 250] = -spike * torch.sign(k[n_kv + 250])
+    k = k.to(BF)
+    v = rnd(batch * n_kv, c, seed=2)
+    vt = ops.alloc_vt(batch, heads, d, n_kv, "cuda")
+    vt[..., :n_kv] = v.view(batch, n_kv, heads, d).permute(0, 2, 3, 1)
+    kw = dict(batch=batch, heads=heads, n_q=n_q, n_kv=n_kv, head_dim=d)
+    assert ops._BOUNDED_SOFTMAX[0]
+    bounded = ops.attention(q, k, vt, **kw)
+    pre = ops.attention(q, k, vt, kmax=ops.key_norm_max(k, kv_batches=batch, heads=heads, n_kv=n_kv, head_dim=d), **kw)
+    assert torch.equal(bounded, pre)
+    try:
+        ops._BOUNDED_SOFTMAX[0] = False
+        exact = ops.attention(q, k, vt, **kw)
+    finally:
+        ops._BOUNDED_SOFTMAX[0] = True
+    ref = _sdpa_ref(q.view(batch, n_q, heads, d).transpose(1, 2), k.view(batch, n_kv, heads, d).transpose(1, 2),
+                    v.view(batch, n_kv, heads, d).transpose(1, 2)).transpose(1, 2).reshape(batch * n_q, c)
+    assert torch.isfinite(bounded).all()
+    check(exact, ref, f"exact attention qs={qs} spike={spike}", rel=1e-2, mx=2 ** -6)
+    check(bounded, ref, f"bounded attention qs={qs} spike={spike}", rel=1e-2, mx=2 ** -6)
+    check(bounded, exact, f"bounded vs exact qs={qs} spike={spike}", rel=6e-3, mx=2 ** -6)
+
+
 @pytest.mark.parametrize("b,f,hw,heads,d", [(2, 4, 16, 8, 8), (2, 16, 64, 8, 40), (1, 24, 16, 8, 80), (2, 8, 4, 8, 160),
                                             (1, 1, 8, 8, 16), (2, 32, 5, 8, 32)])
 def test_temporal_attention(ops, b, f, hw, heads, d):

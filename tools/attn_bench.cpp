@@ -43,6 +43,9 @@ static inline uint32_t hash32(uint32_t x) {
 typedef int (*attn_fn)(const void*, int, const void*, int, const void*, int, void*, int, int, int, int, int, int, int,
                        float, void*);
 typedef const char* (*err_fn)(void);
+typedef int (*knorm_fn)(const void*, int, int, int, int, int, float*, void*);
+typedef int (*attnb_fn)(const void*, int, const void*, int, const void*, int, void*, int, int, int, int, int, int, int,
+                        float, const float*, void*);
 
 struct Shape { const char* name; int batch, heads, nq, nkv, d, q_per_kv, per_fwd; };
 
@@ -58,6 +61,12 @@ int main(int argc, char** argv) {
   }
   attn_fn attn = (attn_fn)dlsym(lib, "vx_attention");
   err_fn lasterr = (err_fn)dlsym(lib, "vx_last_error_string");
+  // ATTN_BOUND=1: time vx_key_norm_max + vx_attention_bounded (the pair the model issues) instead of vx_attention
+  knorm_fn knorm = (knorm_fn)dlsym(lib, "vx_key_norm_max");
+  attnb_fn attnb = (attnb_fn)dlsym(lib, "vx_attention_bounded");
+  const bool bound = getenv("ATTN_BOUND") && atoi(getenv("ATTN_BOUND")) && knorm && attnb;
+  float kscale = getenv("ATTN_KSCALE") ? (float)atof(getenv("ATTN_KSCALE")) : 1.0f;   // key magnitude (looser bound)
+  printf("mode: %s, key scale %.1f\n", bound ? "bounded softmax (key norm + attention timed together)" : "exact", kscale);
   int reps = argc > 2 ? atoi(argv[2]) : 10;
   const char* filter = argc > 3 ? argv[3] : nullptr;
   const Shape shapes[] = {
@@ -83,7 +92,8 @@ int main(int argc, char** argv) {
     const size_t nvt = (size_t)kvb * s.heads * s.d * pitch;
     std::vector<bf16_t> hq(nq), hk(nk), hvt(nvt, 0);
     for (size_t i = 0; i < nq; ++i) hq[i] = f2bf(((int)(hash32((uint32_t)i * 2654435761u + 1u) & 0xffff) - 32768) / 16384.0f);
-    for (size_t i = 0; i < nk; ++i) hk[i] = f2bf(((int)(hash32((uint32_t)i * 2654435761u + 2u) & 0xffff) - 32768) / 16384.0f);
+    for (size_t i = 0; i < nk; ++i)
+      hk[i] = f2bf(kscale * ((int)(hash32((uint32_t)i * 2654435761u + 2u) & 0xffff) - 32768) / 16384.0f);
     for (int b = 0; b < kvb; ++b)
       for (int h = 0; h < s.heads; ++h)
         for (int dd = 0; dd < s.d; ++dd)
@@ -97,7 +107,15 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dvt, hvt.data(), nvt * 2, hipMemcpyHostToDevice));
     CK(hipMemset(dout, 0, nq * 2));
     const float scale = 1.0f / sqrtf((float)s.d);
-    int rc = attn(dq, C, dk, C, dvt, pitch, dout, C, s.batch, s.heads, s.nq, s.nkv, s.d, s.q_per_kv, scale, st);
+    float* dkm = nullptr;
+    CK(hipMalloc(&dkm, sizeof(float) * kvb * s.heads));
+    auto run = [&]() -> int {
+      if (!bound) return attn(dq, C, dk, C, dvt, pitch, dout, C, s.batch, s.heads, s.nq, s.nkv, s.d, s.q_per_kv, scale, st);
+      int r = knorm(dk, C, kvb, s.heads, s.nkv, s.d, dkm, st);
+      if (r) return r;
+      return attnb(dq, C, dk, C, dvt, pitch, dout, C, s.batch, s.heads, s.nq, s.nkv, s.d, s.q_per_kv, scale, dkm, st);
+    };
+    int rc = run();
     if (rc != 0) {
       printf("%-42s launch error %d: %s\n", s.name, rc, lasterr());
       continue;
@@ -134,9 +152,9 @@ int main(int argc, char** argv) {
       }
     }
     bool ok = maxerr <= maxref / 64.0 + 1e-4;
-    for (int i = 0; i < 2; ++i) attn(dq, C, dk, C, dvt, pitch, dout, C, s.batch, s.heads, s.nq, s.nkv, s.d, s.q_per_kv, scale, st);
+    for (int i = 0; i < 2; ++i) run();
     CK(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; ++i) attn(dq, C, dk, C, dvt, pitch, dout, C, s.batch, s.heads, s.nq, s.nkv, s.d, s.q_per_kv, scale, st);
+    for (int i = 0; i < reps; ++i) run();
     CK(hipEventRecord(e1, st));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -145,7 +163,7 @@ int main(int argc, char** argv) {
     printf("%-42s %10.1f %9.1f %10.3e %s (max|ref| %.3f)\n", s.name, us, fl / us * 1e-6, maxerr, ok ? "ok" : "MISMATCH", maxref);
     fflush(stdout);
     tot_us += us * s.per_fwd;
-    CK(hipFree(dq)); CK(hipFree(dk)); CK(hipFree(dvt)); CK(hipFree(dout));
+    CK(hipFree(dq)); CK(hipFree(dk)); CK(hipFree(dvt)); CK(hipFree(dout)); CK(hipFree(dkm));
   }
   printf("per CFG forward (self + reference attention, counts per_fwd): %.2f ms\n", tot_us * 1e-3);
   return 0;

@@ -98,7 +98,7 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
     """Transformer3DModel.forward (modules/transformer_3d.py:103-169) with the block forward patched by
     ReferenceAttentionControl in *read* mode (modules/mutual_self_attention.py:176-267).
     x: [b*f, HW, C]; ehs: bf16 [b*f*n_ctx, 768] audio tokens; bank: list over the b batch rows of
-    None (all-zero bank -> the attention output is exactly to_out.bias) or (k, vt)."""
+    None (all-zero bank -> the attention output is exactly to_out.bias) or (k, vt, kmax)."""
     frames, hw, c = b * f, H * W, x.shape[-1]
     m = frames * hw
     x2d = x.view(m, c)
@@ -115,12 +115,12 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
         if bank[bi] is None:
             ops.add_row_bias(hb, P.attn1_5.out.b, w_ref)
         else:
-            kref, vtref = bank[bi]
+            kref, vtref, kmax = bank[bi]
             ln = ops.layernorm(hb, P.norm1_5.g, P.norm1_5.b)
             with ops.frame_rows(hw, items=1):          # these launches cover ONE batch item
                 q = ops.gemm(ln, P.attn1_5.wq)
                 a = ops.attention(q, kref, vtref, batch=f, heads=heads, n_q=hw, n_kv=kref.shape[0], head_dim=d,
-                                  q_per_kv=f)
+                                  q_per_kv=f, kmax=kmax)
                 ops.gemm(a, P.attn1_5.out.w, P.attn1_5.out.b, residual=hb, alpha=w_ref, out=hb)
     # 2. audio cross-attention (:227-244).  A batch row whose audio tokens are ALL ZERO (the unconditional CFG half:
     # torch.zeros_like, pipelines/v_express_pipeline.py:403-405) has K = V = 0 (to_k / to_v carry no bias): every
@@ -222,4 +222,5 @@ def bank_kv(A, bank_tokens, heads):
     k = torch.empty((n, c), device=bank_tokens.device, dtype=ops.BF16)
     vt = ops.alloc_vt(1, heads, d, n, bank_tokens.device)
     ops.gemm_split(bank_tokens, A.wkv, None, [("rows", k), ("vt", vt)], part_cols=c, seq_len=n, head_dim=d)
-    return k, vt
+    # max key norm per head: the bound table of the bounded-softmax attention kernel (step-invariant like K itself)
+    return k, vt, ops.key_norm_max(k, kv_batches=1, heads=heads, n_kv=n, head_dim=d)

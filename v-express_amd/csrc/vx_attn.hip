@@ -31,6 +31,7 @@ struct AttnParams {
   bf16_t* out; int ldo;
   int batch, heads, n_q, n_kv, d, q_per_kv;
   float c;   // scale * log2(e)
+  const float* kmax;   // [kv batches * heads] max key norm of the head slice (bounded-softmax variant of attn2), or null
 };
 
 __device__ __forceinline__ int k_lds_off(int slab, int key, int grp) {
@@ -169,8 +170,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s_[kt][qt][r]);
-      mx = wave_xor_max(mx, 16);
-      mx = wave_xor_max(mx, 32);
+      mx = wave_rows_max(mx);
       float mnew = fmaxf(m_run[qt], mx * p.c);
       float alpha = __builtin_amdgcn_exp2f(m_run[qt] - mnew);
       m_run[qt] = mnew;
@@ -277,7 +277,17 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
 //     grew in this tile (alpha == 1 for every lane): after the first few tiles that is the common case;
 //   * row max through v_max3_f32 (fmaxf nests fold to it).
 // LDS: single K / V^T buffers; the next tile waits in registers while this one is multiplied (T14 split).
-template <int KK, int DT, int QT, bool ONES>
+//
+// BOUND (p.kmax != null): softmax is invariant to the per-query shift, so the shift need not be the running row max -
+// any m_i >= max_j s_ij keeps every exponent <= 0.  Cauchy-Schwarz gives one for free: s_ij <= |q_i| max_j |k_j|.
+// With m_i = c |q_i| Kmax fixed for the whole key loop (Kmax per (batch, head) from vx_key_norm_max, |q_i| from the Q
+// fragments) the per-tile row max (16 v_max3/v_max + 2 cross-row exchanges per query tile, all on the dependency chain
+// in front of the exponentials), the running-max update, alpha and the accumulator rescale disappear: a tile is
+// 32 fma + 32 exp + 16 cvt.  The price is range: a query whose true max lies more than ~100 (log2 units) under its
+// bound has all its probabilities flushed towards zero.  Detected at the end (row sum < 2^-100), block-uniformly, and
+// the block then recomputes with the exact online softmax - never a wrong result, at worst the old speed plus one
+// wasted pass (outlier-norm keys in trained weights can trigger that; random-init weights never do).
+template <int KK, int DT, int QT, bool ONES, bool BOUND>
 __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
   constexpr int NV = (DT + 1) / 2;   // V^T chunks per thread per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -321,6 +331,25 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
     l_run[qt] = 0.f;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  float mfix[QT];   // BOUND: c |q_i| Kmax, identical in the 4 lanes of a query column
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mfix[qt] = 0.f;
+    if (BOUND) {
+      float ss = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        float f[8];
+        unpack_bf16x8(qf[qt][kk], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+      }
+      ss = wave_xor_sum(ss, 16);
+      ss = wave_xor_sum(ss, 32);
+      mfix[qt] = p.c * sqrtf(ss) * p.kmax[kvb * p.heads + h];
+    }
   }
 
   // ---- staging coordinates (loop-invariant): thread -> (key, 16-B channel chunk) of the K tile and (dim row, 8-key
@@ -409,14 +438,10 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
     }
   };
 
-  // prologue: K(0), V(0) -> LDS
-  VX_ATTN2_LOAD(0, n_tiles == 1 && ragged);
-  VX_ATTN2_STORE();
-  __syncthreads();
-
-  // one key tile.  MASK: tile t reaches beyond n_kv.
-  auto step = [&](auto mask_c, const int t) {
+  // one key tile.  MASK: tile t reaches beyond n_kv.  FIXED: the bounded-softmax body (see BOUND above).
+  auto step = [&](auto mask_c, auto fixed_c, const int t) {
     constexpr bool MASK = decltype(mask_c)::value;
+    constexpr bool FIXED = decltype(fixed_c)::value;
     // registers <- K(t+1), V(t+1)   (written to LDS after this tile's MFMAs: T14 issue-early / write-late)
     if (t + 1 < n_tiles) {
       const bool edge = ragged && t + 1 == n_tiles - 1;
@@ -435,6 +460,21 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
           }
         }
     }
+    if constexpr (FIXED) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pv = __builtin_amdgcn_exp2f(fmaf(cur[kt][qt][r], p.c, -mfix[qt]));
+            if (!ONES) rs += pv;
+            cur[kt][qt][r] = pv;
+          }
+        if (!ONES) l_run[qt] += rs;
+      }
+    } else {
     float alpha[QT];
     bool grew = false;
 #pragma unroll
@@ -447,8 +487,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
       mx = fmaxf(fmaxf(mx, cur[2][qt][3]), cur[3][qt][0]);
       mx = fmaxf(fmaxf(mx, cur[3][qt][1]), cur[3][qt][2]);
       mx = fmaxf(mx, cur[3][qt][3]);
-      mx = wave_xor_max(mx, 16);
-      mx = wave_xor_max(mx, 32);
+      mx = wave_rows_max(mx);
       const float mnew = fmaxf(m_run[qt], mx * p.c);
       grew |= mnew > m_run[qt];
       alpha[qt] = __builtin_amdgcn_exp2f(m_run[qt] - mnew);
@@ -472,6 +511,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
           o[dt][qt][0] *= alpha[qt]; o[dt][qt][1] *= alpha[qt]; o[dt][qt][2] *= alpha[qt]; o[dt][qt][3] *= alpha[qt];
         }
     }
+    }   // !FIXED
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int ks_ = 0; ks_ < 2; ++ks_) {
@@ -500,15 +540,17 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
     __syncthreads();
   };
 
-  {
+  // the whole key loop (prologue: K(0), V(0) -> LDS; every step ends with a block barrier, so LDS is free on entry)
+  auto run = [&](auto fixed_c) {
+    VX_ATTN2_LOAD(0, n_tiles == 1 && ragged);
+    VX_ATTN2_STORE();
+    __syncthreads();
     const int n_plain = ragged ? n_tiles - 1 : n_tiles;   // tiles that need no key masking
-    for (int t = 0; t < n_plain; ++t) step(std::false_type{}, t);
-    if (ragged) step(std::true_type{}, n_tiles - 1);
-  }
-
-  // ---- normalise and store: lane holds 4 consecutive d-columns of one query
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
+    for (int t = 0; t < n_plain; ++t) step(std::false_type{}, fixed_c, t);
+    if (ragged) step(std::true_type{}, fixed_c, n_tiles - 1);
+  };
+  // softmax denominator of query tile qt (every lane of the query's column gets it)
+  auto row_sum = [&](int qt) -> float {
     float l;
     if (ONES) {
       // O^T[d][query i] lives in fragment d / 16, lane group (d % 16) / 4, register d % 4
@@ -525,6 +567,35 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
       l = wave_xor_sum(l, 16);
       l = wave_xor_sum(l, 32);
     }
+    return l;
+  };
+
+  if constexpr (BOUND) {
+    run(std::true_type{});
+    bool bad = false;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const float l = row_sum(qt);
+      bad |= (q0 + 16 * qt + i < p.n_q) && !(l >= 7.8886e-31f);   // 2^-100; also catches NaN
+    }
+    if (__syncthreads_or(bad)) {   // block-uniform (the K / V^T staging is shared by the 4 waves): exact recompute
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        m_run[qt] = -INFINITY;
+        l_run[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      run(std::false_type{});
+    }
+  } else {
+    run(std::false_type{});
+  }
+
+  // ---- normalise and store: lane holds 4 consecutive d-columns of one query
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const float l = row_sum(qt);
     float inv = 1.0f / l;
     int qrow = q0 + 16 * qt + i;
     if (qrow >= p.n_q) continue;
@@ -545,10 +616,10 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
 #undef VX_ATTN2_LOAD
 #undef VX_ATTN2_STORE
 
-template <int KK, int DT, int QT, bool ONES>
+template <int KK, int DT, int QT, bool ONES, bool BOUND>
 int launch_attn2(const AttnParams& p, hipStream_t stream) {
   constexpr int smem = KK * 4096 + DT * 2048;
-  auto kern = attn2_kernel<KK, DT, QT, ONES>;
+  auto kern = attn2_kernel<KK, DT, QT, ONES, BOUND>;
   static bool attr_set = false;
   if (!attr_set && smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -774,12 +845,70 @@ __global__ __launch_bounds__(256) void small_kv_attn_kernel(const bf16_t* __rest
   }
 }
 
+// max over the keys of one (kv batch, head) of the Euclidean norm of the key's head slice (fp32): the Kmax of the
+// bounded-softmax attention.  One block per (kv batch, head); a thread walks keys tid, tid + 256, ... with 16-B loads.
+__global__ __launch_bounds__(256) void key_norm_max_kernel(const bf16_t* __restrict__ k, int ldk, int heads, int n_kv,
+                                                           int d, float* __restrict__ out) {
+  __shared__ float red[256];
+  const int bh = blockIdx.x, b = bh / heads, h = bh - b * heads;
+  const bf16_t* base = k + (size_t)b * n_kv * ldk + h * d;
+  const int chunks = d >> 3;
+  float best = 0.f;
+  for (int key = threadIdx.x; key < n_kv; key += 256) {
+    const bf16_t* row = base + (size_t)key * ldk;
+    float ss = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+      float f[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(row + 8 * c), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+    }
+    best = fmaxf(best, ss);
+  }
+  red[threadIdx.x] = best;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[bh] = sqrtf(red[0]);
+}
+
+int attention_impl(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_pitch, void* out, int ldo,
+                   int batch, int heads, int n_q, int n_kv, int head_dim, int q_per_kv, float scale,
+                   const float* key_norm_max, hipStream_t stream);
+
 }  // namespace
+
+extern "C" int vx_key_norm_max(const void* k, int ldk, int kv_batches, int heads, int n_kv, int head_dim, float* out,
+                               void* stream) {
+  VX_REQUIRE(k && out, "vx_key_norm_max: null pointer");
+  VX_REQUIRE(kv_batches > 0 && heads > 0 && n_kv > 0 && head_dim > 0 && (head_dim % 8) == 0 && (ldk % 8) == 0,
+             "vx_key_norm_max: bad sizes (head_dim=%d ldk=%d)", head_dim, ldk);
+  hipLaunchKernelGGL(key_norm_max_kernel, dim3(kv_batches * heads), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)k, ldk, heads, n_kv, head_dim, out);
+  return vx_check_launch("vx_key_norm_max");
+}
 
 extern "C" int vx_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_pitch, void* out,
                             int ldo, int batch, int heads, int n_q, int n_kv, int head_dim, int q_per_kv,
-                            float scale, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+                            float scale, void* stream) {
+  return attention_impl(q, ldq, k, ldk, vt, vt_pitch, out, ldo, batch, heads, n_q, n_kv, head_dim, q_per_kv, scale,
+                        nullptr, (hipStream_t)stream);
+}
+
+extern "C" int vx_attention_bounded(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_pitch,
+                                    void* out, int ldo, int batch, int heads, int n_q, int n_kv, int head_dim,
+                                    int q_per_kv, float scale, const float* key_norm_max, void* stream) {
+  VX_REQUIRE(key_norm_max != nullptr, "vx_attention_bounded: null key_norm_max");
+  return attention_impl(q, ldq, k, ldk, vt, vt_pitch, out, ldo, batch, heads, n_q, n_kv, head_dim, q_per_kv, scale,
+                        key_norm_max, (hipStream_t)stream);
+}
+
+namespace {
+int attention_impl(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_pitch, void* out, int ldo,
+                   int batch, int heads, int n_q, int n_kv, int head_dim, int q_per_kv, float scale,
+                   const float* key_norm_max, hipStream_t stream) {
   VX_REQUIRE(q && k && vt && out, "vx_attention: null pointer");
   VX_REQUIRE(batch > 0 && heads > 0 && n_q > 0 && n_kv > 0 && q_per_kv > 0 && (batch % q_per_kv) == 0,
              "vx_attention: bad sizes");
@@ -788,13 +917,16 @@ extern "C" int vx_attention(const void* q, int ldq, const void* k, int ldk, cons
              "vx_attention: alignment (head_dim=%d ldq=%d ldk=%d pitch=%d ldo=%d)", head_dim, ldq, ldk, vt_pitch, ldo);
   VX_REQUIRE((long)batch * heads <= 65535, "vx_attention: batch*heads too large for grid.y");
   AttnParams p{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)vt, vt_pitch, (bf16_t*)out, ldo,
-               batch, heads, n_q, n_kv, head_dim, q_per_kv, scale * 1.4426950408889634f};
+               batch, heads, n_q, n_kv, head_dim, q_per_kv, scale * 1.4426950408889634f, key_norm_max};
+  VX_REQUIRE(scale > 0.f, "vx_attention: scale must be positive");
   const int d = head_dim;
   static int v1 = -1;
   if (v1 < 0) v1 = getenv("VX_ATTN_V1") != nullptr;
   // attn2: the software-pipelined kernel; instantiated for the head dims whose register budget fits two S tiles
   // (d = 40: the 64x64 level, 85 % of the attention time).  Other head dims keep the plain kernel.
-  if (!v1 && d > 32 && d <= 48 && (d % 16) != 0) return launch_attn2<2, 3, 2, true>(p, stream);
+  // With a key-norm table the bounded-softmax body runs (exact fallback inside the kernel); other head dims ignore it.
+  if (!v1 && d > 32 && d <= 48 && (d % 16) != 0)
+    return key_norm_max ? launch_attn2<2, 3, 2, true, true>(p, stream) : launch_attn2<2, 3, 2, true, false>(p, stream);
   if (d <= 32) return launch_attn<1, 2, 4, true>(p, stream);
   if (d <= 48) return launch_attn<2, 3, 2, true>(p, stream);
   if (d <= 64) return launch_attn<2, 4, 2, true>(p, stream);
@@ -806,6 +938,7 @@ extern "C" int vx_attention(const void* q, int ldq, const void* k, int ldk, cons
   vx_set_error("vx_attention: unsupported head_dim %d", d);
   return VX_ERR_UNSUPPORTED;
 }
+}  // namespace
 
 extern "C" int vx_temporal_attention(const void* qkv, int ldqkv, void* out, int ldo, int b, int f, int hw, int heads,
                                      int head_dim, float scale, void* stream_) {

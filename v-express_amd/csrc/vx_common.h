@@ -81,5 +81,16 @@ __device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_
 
 __device__ __forceinline__ float wave_xor_max(float v, int mask) { return fmaxf(v, __shfl_xor(v, mask, 64)); }
 __device__ __forceinline__ float wave_xor_sum(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
+// max over the four lanes {l, l^16, l^32, l^48} (one value per 16-lane row) with no LDS round trip: v_permlane16_swap
+// exchanges the odd 16-lane rows of its first operand with the even rows of the second, v_permlane32_swap the upper
+// half of the first with the lower half of the second.  With the same value in both operands the two results hold
+// "my row" and "my partner row" in every lane.  (__shfl_xor compiles to ds_bpermute_b32: ~100 cycles of LDS latency in
+// the middle of the online-softmax dependency chain row max -> exp.)
+__device__ __forceinline__ float wave_rows_max(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -85,6 +85,8 @@ def _load():
     lib.vx_groupnorm.argtypes = [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, i32, i32, i32, vp]
     lib.vx_layernorm.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp]
     lib.vx_attention.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp]
+    lib.vx_attention_bounded.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
+    lib.vx_key_norm_max.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     lib.vx_temporal_attention.argtypes = [vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp]
     lib.vx_small_kv_attention.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp]
     lib.vx_add_row_bias.argtypes = [vp, i32, i32, i32, vp, f32, vp]
@@ -102,7 +104,7 @@ def _load():
         if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name",
                         "vx_gemm_splitk_ws_bytes"):
             fn.restype = i32
-    if lib.vx_abi_version() != 6:
+    if lib.vx_abi_version() != 7:
         raise ImportError("libvexpress_hip.so ABI version mismatch")
     return lib
 

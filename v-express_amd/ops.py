@@ -6,6 +6,7 @@ channels-last tokens `[frames, H*W, C]`; weights are pre-laid-out by `weights.py
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -340,12 +341,33 @@ def layernorm(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_e
     return out
 
 
-def attention(q, k, vt, *, batch, heads, n_q, n_kv, head_dim, q_per_kv=1, out=None):
-    """q: [batch*n_q, *] view; k: [kv_batches*n_kv, *] view; vt: [kv_batches, heads, head_dim, pitch]."""
+_BOUNDED_SOFTMAX = [os.environ.get("VX_ATTN_BOUND", "1") != "0"]
+
+
+def key_norm_max(k, *, kv_batches, heads, n_kv, head_dim):
+    """float32 [kv_batches * heads]: max over the keys of |k_j| per (kv batch, head) - the Kmax of the bounded softmax."""
+    ldk, _ = _row_stride(k)
+    out = torch.empty((kv_batches * heads,), device=k.device, dtype=torch.float32)
+    L.check(_lib.vx_key_norm_max(_ptr(k), ldk, kv_batches, heads, n_kv, head_dim, _ptr(out), _stream()),
+            "vx_key_norm_max")
+    return out
+
+
+def attention(q, k, vt, *, batch, heads, n_q, n_kv, head_dim, q_per_kv=1, out=None, kmax=None):
+    """q: [batch*n_q, *] view; k: [kv_batches*n_kv, *] view; vt: [kv_batches, heads, head_dim, pitch].
+    The 64x64 level's head dim (32 < d <= 48, not a multiple of 16: SD-1.5's d = 40) runs the bounded-softmax kernel
+    (vx_attention_bounded; `kmax` = a precomputed key_norm_max of k, e.g. of a step-invariant reference bank)."""
     ldq, _ = _row_stride(q)
     ldk, _ = _row_stride(k)
     if out is None:
         out = torch.empty((batch * n_q, heads * head_dim), device=q.device, dtype=BF16)
+    if _BOUNDED_SOFTMAX[0] and 32 < head_dim <= 48 and head_dim % 16:
+        if kmax is None:
+            kmax = key_norm_max(k, kv_batches=batch // q_per_kv, heads=heads, n_kv=n_kv, head_dim=head_dim)
+        L.check(_lib.vx_attention_bounded(_ptr(q), ldq, _ptr(k), ldk, _ptr(vt), vt.shape[-1], _ptr(out),
+                                          _row_stride(out)[0], batch, heads, n_q, n_kv, head_dim, q_per_kv,
+                                          head_dim ** -0.5, _ptr(kmax), _stream()), "vx_attention_bounded")
+        return out
     L.check(_lib.vx_attention(_ptr(q), ldq, _ptr(k), ldk, _ptr(vt), vt.shape[-1], _ptr(out), _row_stride(out)[0],
                               batch, heads, n_q, n_kv, head_dim, q_per_kv, head_dim ** -0.5, _stream()),
             "vx_attention")
