@@ -74,7 +74,7 @@ def gemm_split(a, w, bias, parts, *, part_cols, seq_len=0, head_dim=0, geom=None
             t[..., :seq_len] = col.view(seqs, seq_len, heads, head_dim).permute(0, 2, 3, 1).to(BF16)
 
 
-def attention(q, k, vt, *, batch, heads, n_q, n_kv, head_dim, q_per_kv=1, out=None):
+def attention(q, k, vt, *, batch, heads, n_q, n_kv, head_dim, q_per_kv=1, out=None, kmax=None):
     assert q_per_kv == 1
     qh = q.float().view(batch, n_q, heads, head_dim).transpose(1, 2)
     kh = k.float().view(batch, n_kv, heads, head_dim).transpose(1, 2)

@@ -176,6 +176,9 @@ class VExpressPipeline:
         counts = torch.tensor([float(plan["counts"][fr]) for fr in sf], dtype=torch.float32, device=dev)
         # work units of this rank; S > 1: the window's frames are split over S ranks per unit (short clips)
         S = self.frame_shards or choose_frame_shards(nW, dc.world_size, f, (H // 8) * (W // 8))
+        if S < 1 or dc.world_size % S or f % S or ((H // 8) * (W // 8)) % S:
+            raise ValueError(f"frame_shards={S} must divide the world size ({dc.world_size}), the window length ({f}) "
+                             f"and the {H // 8}x{W // 8} tokens of the coarsest UNet level")
         sched_u = UnitSchedule(nW, dc.world_size, S)
         my_calls, max_units = sched_u.calls(dc.rank), sched_u.max_units
         shard = dc.frame_shard(S)
