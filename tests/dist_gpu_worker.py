@@ -15,16 +15,30 @@ sys.path.insert(0, HERE)
 import cases  # noqa: E402
 
 
-def run(F, cf, co, steps, frame_shards, latent=16):
-    from v_express_amd import (AutoencoderKLDecoder, DDIMScheduler, UNet2DConditionModel, UNet3DConditionModel,
-                               VExpressPipeline, synth)
+def emulate_kernels():
+    """CPU suite only: tests/fake_ops.py stands in for the HIP wrappers and the device guards are lifted, so the whole
+    host side (models, loop, sharding) runs in a process without a GPU."""
+    import fake_ops
+    from v_express_amd import ops, unet_3d, vae
+
+    class _Patch:
+        def setattr(self, obj, name, value):
+            setattr(obj, name, value)
+    fake_ops.install(_Patch(), ops)
+    unet_3d._UNetBase._need_gpu = lambda self: None
+    vae.AutoencoderKLDecoder._need_gpu = lambda self: None
+
+
+def run(F, cf, co, steps, frame_shards, latent=16, device="cuda"):
+    from v_express_amd import (AutoencoderKLDecoder, DDIMScheduler, ReferenceAttentionControl, UNet2DConditionModel,
+                               UNet3DConditionModel, VExpressPipeline, ops, synth)
     cfg = cases.unet_cfg(cases.SMALL)
     vcfg = synth.VaeConfig(**cases.SMALL_VAE)
-    unet = UNet3DConditionModel(cfg).to("cuda")
-    refnet = UNet2DConditionModel(cfg).to("cuda")
+    unet = UNet3DConditionModel(cfg).to(device)
+    refnet = UNet2DConditionModel(cfg).to(device)
     unet.load_state_dict(synth.unet3d_state_dict(cfg), strict=True)
     refnet.load_state_dict(synth.refnet_state_dict(cfg), strict=True)
-    vae = AutoencoderKLDecoder(vcfg).to("cuda")
+    vae = AutoencoderKLDecoder(vcfg).to(device)
     vae.load_state_dict(synth.vae_decoder_state_dict(vcfg))
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
                           steps_offset=1, prediction_type="v_prediction", rescale_betas_zero_snr=True,
@@ -32,6 +46,24 @@ def run(F, cf, co, steps, frame_shards, latent=16):
     pipe = VExpressPipeline(vae=vae, reference_net=refnet, denoising_unet=unet, scheduler=sched)
     pipe.frame_shards = frame_shards or None
     inp = synth.synthetic_inputs(cfg, F, latent, latent)
+    if device != "cuda":
+        # the pieces of VExpressPipeline.__call__ (which times itself with CUDA events), in its order
+        from v_express_amd.context import get_context_scheduler
+        writer = ReferenceAttentionControl(refnet, do_classifier_free_guidance=True, mode="write", fusion_blocks="full")
+        reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", fusion_blocks="full",
+                                           reference_attention_weight=cases.W_REF,
+                                           audio_attention_weight=cases.W_AUD)
+        refnet(inp["ref_latents"], timestep=0, encoder_hidden_states=torch.zeros(1, 1, 768), return_dict=False)
+        reader.update(writer, True)
+        sched.set_timesteps(steps)
+        windows = list(get_context_scheduler("uniform")(step=0, num_frames=F, context_size=cf, context_stride=1,
+                                                        context_overlap=co, closed_loop=False))
+        c0 = cfg.block_out_channels[0]
+        kps = ops.ncfhw_to_nhwc(inp["kps_features"], c0).view(2, F, latent * latent, c0)
+        audio = inp["audio_embeddings"].to(torch.bfloat16).contiguous()
+        lat = inp["latents"].clone().float()
+        pipe.denoise(lat, kps, audio, sched.timesteps.tolist(), windows, cases.GUIDANCE)
+        return lat
     lat = pipe(None, None, None, latent * 8, latent * 8, F, steps, cases.GUIDANCE, context_frames=cf,
                context_overlap=co, reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD,
                reference_latents=inp["ref_latents"], kps_features=inp["kps_features"],

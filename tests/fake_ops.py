@@ -2,7 +2,8 @@
 
 They let the *host composition* of a model (weight re-layouts, strided window views, buffer plumbing, call order) be
 checked against the oracle in the dev container, where no GPU exists.  Same signatures and output dtypes (bf16 rounding
-at every kernel boundary) as the real wrappers; the arithmetic inside is plain fp32 torch.  Never imported by the
+at every kernel boundary) as the real wrappers; the arithmetic inside is float64 torch, so - like the real kernels - a
+row's result does not depend on how many other rows share the call (fp32 BLAS blocking would).  Never imported by the
 package; the GPU tests run the same model code on the real kernels.
 """
 import torch
@@ -17,44 +18,105 @@ def _act(y, act):
 
 def wave_conv1d(wave, wt, stride):
     taps, _ = wt.shape
-    return (wave.unfold(0, taps, stride) @ wt).to(BF16)
+    return (wave.double().unfold(0, taps, stride) @ wt.double()).to(BF16)
 
 
 def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=None, pad_hw=None):
-    assert x2 is None and out is None and pad_hw is None and x1.is_contiguous()
-    x = x1.float().view(frames, hw, -1).transpose(1, 2)
-    y = F.group_norm(x, groups, gamma, beta, eps)
-    return _act(y, int(silu)).transpose(1, 2).contiguous().to(BF16)
+    from v_express_amd import ops as real_ops
+    x = x1.double().view(frames, hw, -1)
+    if x2 is not None:
+        x = torch.cat([x, x2.double().view(frames, hw, -1)], dim=-1)
+    c = x.shape[-1]
+    y = F.group_norm(x.transpose(1, 2), groups, gamma.double(), beta.double(), eps) if hw * (c // groups) > 1 else \
+        beta.double().expand(frames, c)[:, :, None].expand(frames, c, hw)
+    y = _act(y, int(silu)).transpose(1, 2).to(BF16)
+    if pad_hw is not None:
+        H, W = pad_hw
+        assert out is None and H * W == hw
+        buf = real_ops.padded_buffer(x1.device, frames, H, W, c)
+        buf.view(frames, H + 2, W + 2, c)[:, 1:H + 1, 1:W + 1].copy_(y.reshape(frames, H, W, c))
+        return buf
+    if out is not None:
+        out.copy_(y.reshape(out.shape))
+        return out
+    return y.contiguous()
 
 
 def layernorm(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_entries=1, out=None):
-    assert add is None and x.dtype == BF16
-    y = F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps).to(BF16)
+    assert x.dtype == BF16
+    x2 = x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x
+    y = F.layer_norm(x2.double(), (x2.shape[-1],), gamma.double(), beta.double(), eps)
+    if add is not None:
+        idx = (torch.arange(y.shape[0]) // add_rows_per_entry) % add_entries
+        y = y + add.double().reshape(-1, y.shape[-1])[idx]
+    y = y.to(BF16)
     if out is not None:
         out.copy_(y)
         return out
     return y
+
+
+def _conv_rows(a, a2, w, geom):
+    """Implicit-GEMM semantics of vx_gemm: rows (frame, y, x) of NHWC sources (channel-concatenated), weight [N, kh*kw*C]
+    with (ky, kx, c) column order, nearest-2x upsample before the conv, zero padding `pad` before each spatial axis and
+    whatever the output size needs after it."""
+    x = a.double() if a2 is None else torch.cat([a.double(), a2.double()], dim=-1)
+    nb, h, wd = geom.nb, geom.h_in, geom.w_in
+    c = x.shape[-1]
+    n = w.shape[0]
+    assert x.shape[0] == nb * h * wd and w.shape[1] == geom.kh * geom.kw * c, (x.shape, w.shape, vars(geom))
+    img = x.view(nb, h, wd, c).permute(0, 3, 1, 2)
+    if geom.upsample:
+        img = F.interpolate(img, scale_factor=2, mode="nearest")
+    he, we = img.shape[-2:]
+    need_h = (geom.h_out - 1) * geom.stride + geom.kh - he
+    need_w = (geom.w_out - 1) * geom.stride + geom.kw - we
+    img = F.pad(img, (geom.pad, max(need_w - geom.pad, 0), geom.pad, max(need_h - geom.pad, 0)))
+    wt = w.double().view(n, geom.kh, geom.kw, c).permute(0, 3, 1, 2)
+    y = F.conv2d(img, wt, stride=geom.stride)[:, :, :geom.h_out, :geom.w_out]
+    return y.permute(0, 2, 3, 1).reshape(geom.m, n)
 
 
 def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=0, rowbias=None, rows_per_group=0,
          out=None, out_f32=False):
-    assert geom is None and a2 is None and rowbias is None and a.dtype == BF16 and w.dtype == BF16
-    assert a.stride(-1) == 1 and a.stride(0) % 8 == 0 and w.is_contiguous() and a.shape[1] == w.shape[1]
-    y = a.float() @ w.float().t()
+    assert a.dtype == BF16 and w.dtype == BF16 and a.stride(-1) == 1 and w.is_contiguous()
+    if geom is None:
+        assert a.dim() == 2 and a.stride(0) % 8 == 0
+        x = a.double() if a2 is None else torch.cat([a.double(), a2.double()], dim=-1)
+        assert x.shape[1] == w.shape[1], (x.shape, w.shape)
+        y = x @ w.double().t()
+    else:
+        y = _conv_rows(a.reshape(-1, a.shape[-1]), None if a2 is None else a2.reshape(-1, a2.shape[-1]), w, geom)
     if bias is not None:
         assert bias.dtype == torch.float32
         y = y + bias
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32 and rows_per_group > 0
+        grp = torch.arange(y.shape[0]) // rows_per_group
+        y = y + rowbias[grp, :y.shape[1]]
     y = _act(y, act)
     if residual is not None:
-        y = residual.float() + alpha * y
+        y = residual.double().reshape(y.shape) + alpha * y
     elif alpha != 1.0:
         y = alpha * y
-    y = y if out_f32 else y.to(BF16)
+    y = y.float() if out_f32 else y.to(BF16)
     if out is not None:
-        assert out.shape == y.shape and out.stride(-1) == 1
-        out.copy_(y)
+        assert out.shape[-1] == y.shape[-1] and out.stride(-1) == 1
+        out.reshape(y.shape).copy_(y) if out.is_contiguous() else out.copy_(y)
         return out
     return y
+
+
+def geglu(a, w_interleaved, bias_interleaved, out=None):
+    y = a.double() @ w_interleaved.double().t()
+    if bias_interleaved is not None:
+        y = y + bias_interleaved
+    blk = y.view(y.shape[0], -1, 2, 8)                      # blocks of 8 value columns followed by their 8 gates
+    r = (blk[:, :, 0] * F.gelu(blk[:, :, 1])).reshape(y.shape[0], -1).to(BF16)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
 
 
 def alloc_vt(seqs, heads, head_dim, n, device):
@@ -62,7 +124,7 @@ def alloc_vt(seqs, heads, head_dim, n, device):
 
 
 def gemm_split(a, w, bias, parts, *, part_cols, seq_len=0, head_dim=0, geom=None):
-    y = a.float() @ w.float().t()
+    y = a.double() @ w.double().t()
     if bias is not None:
         y = y + bias
     for i, (kind, t) in enumerate(parts):
@@ -74,18 +136,103 @@ def gemm_split(a, w, bias, parts, *, part_cols, seq_len=0, head_dim=0, geom=None
             t[..., :seq_len] = col.view(seqs, seq_len, heads, head_dim).permute(0, 2, 3, 1).to(BF16)
 
 
+def key_norm_max(k, *, kv_batches, heads, n_kv, head_dim):
+    return k.double().reshape(kv_batches, n_kv, -1)[..., :heads * head_dim].reshape(
+        kv_batches, n_kv, heads, head_dim).norm(dim=-1).amax(dim=1).reshape(-1).float()
+
+
 def attention(q, k, vt, *, batch, heads, n_q, n_kv, head_dim, q_per_kv=1, out=None, kmax=None):
-    assert q_per_kv == 1
-    qh = q.float().view(batch, n_q, heads, head_dim).transpose(1, 2)
-    kh = k.float().view(batch, n_kv, heads, head_dim).transpose(1, 2)
-    vh = vt[..., :n_kv].float().transpose(-1, -2)
-    o = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(batch * n_q, heads * head_dim).to(BF16)
+    c = heads * head_dim
+    kvb = batch // q_per_kv
+    qh = q.double().reshape(batch, n_q, heads, head_dim).transpose(1, 2)
+    kh = k.double().reshape(kvb, n_kv, heads, head_dim).transpose(1, 2).repeat_interleave(q_per_kv, dim=0)
+    vh = vt[..., :n_kv].double().transpose(-1, -2).repeat_interleave(q_per_kv, dim=0)
+    o = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(batch * n_q, c).to(BF16)
     if out is not None:
         out.copy_(o)
         return out
     return o
 
 
+def temporal_attention(qkv, *, b, f, hw, heads, head_dim, out=None):
+    c = heads * head_dim
+    q, k, v = (t.reshape(b, f, hw, heads, head_dim).permute(0, 2, 3, 1, 4) for t in qkv.double().chunk(3, dim=-1))
+    o = F.scaled_dot_product_attention(q, k, v).permute(0, 3, 1, 2, 4).reshape(b * f * hw, c).to(BF16)
+    if out is not None:
+        out.copy_(o)
+        return out
+    return o
+
+
+def small_kv_attention(q, kv, *, batch, n_q, n_kv, heads, head_dim, out=None):
+    c = heads * head_dim
+    qh = q.double().reshape(batch, n_q, heads, head_dim).transpose(1, 2)
+    kvf = kv.double().reshape(batch, n_kv, 2 * c)
+    kh = kvf[..., :c].reshape(batch, n_kv, heads, head_dim).transpose(1, 2)
+    vh = kvf[..., c:].reshape(batch, n_kv, heads, head_dim).transpose(1, 2)
+    o = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(batch * n_q, c).to(BF16)
+    if out is not None:
+        out.copy_(o)
+        return out
+    return o
+
+
+def add_row_bias(x, bias, alpha=1.0):
+    x.copy_((x.double() + alpha * bias).to(BF16))
+    return x
+
+
+def gather_latents(latents, frame_ids, reps, c_pad=8):
+    _, c, _, h, w = latents.shape
+    x = latents[0][:, frame_ids.long()].reshape(c, -1, h * w).permute(1, 2, 0)            # [f, hw, C]
+    out = torch.zeros((reps, x.shape[0], h * w, c_pad), dtype=BF16)
+    out[..., :c] = x.to(BF16)
+    return out.reshape(reps * x.shape[0], h * w, c_pad)
+
+
+def cfg_combine(unet_out, c, f, hw, guidance, pred_slot):
+    u, cnd = unet_out[:f * hw, :c].double(), unet_out[f * hw:2 * f * hw, :c].double()
+    pred_slot.copy_((u + guidance * (cnd - u)).reshape(f, hw, c).permute(2, 0, 1))
+
+
+def overlap_ddim_step(latents, preds, terms, frame_ids, counts, coef):
+    sa, s1a, sap, s1ap = (float(v) for v in coef)
+    _, c, _, h, w = latents.shape
+    new = {}
+    for i, fr in enumerate(frame_ids.tolist()):
+        v = None
+        for slot, li in terms[i].tolist():
+            if slot < 0:
+                continue
+            term = preds[slot, :, li] / counts[i]
+            v = term if v is None else v + term
+        x = latents[0, :, fr].reshape(c, h * w)
+        new[fr] = (sap * (sa * x - s1a * v) + s1ap * (sa * v + s1a * x)).reshape(c, h, w)
+    for fr, val in new.items():
+        latents[0, :, fr] = val
+
+
+def ncfhw_to_nhwc(x, c_pad=None):
+    b, c, f, h, w = x.shape
+    c_pad = c_pad or (c + 7) // 8 * 8
+    out = torch.zeros((b * f, h * w, c_pad), dtype=BF16)
+    out[..., :c] = x.double().permute(0, 2, 3, 4, 1).reshape(b * f, h * w, c).to(BF16)
+    return out
+
+
+def nhwc_to_ncfhw(x, b, c, f, h, w):
+    return x[:, :c].float().reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3).contiguous()
+
+
+def vae_postprocess(x, n, c, h, w):
+    return (x[:, :c].float().reshape(n, h, w, c).permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1).contiguous()
+
+
+ALL = ("wave_conv1d", "groupnorm", "layernorm", "gemm", "geglu", "alloc_vt", "gemm_split", "key_norm_max", "attention",
+       "temporal_attention", "small_kv_attention", "add_row_bias", "gather_latents", "cfg_combine", "overlap_ddim_step",
+       "ncfhw_to_nhwc", "nhwc_to_ncfhw", "vae_postprocess")
+
+
 def install(monkeypatch, ops):
-    for name in ("wave_conv1d", "groupnorm", "layernorm", "gemm", "alloc_vt", "gemm_split", "attention"):
+    for name in ALL:
         monkeypatch.setattr(ops, name, globals()[name])

@@ -1,0 +1,155 @@
+"""The whole HOST side on CPU: models, denoising loop and multi-rank sharding run with tests/fake_ops.py standing in for
+the HIP wrappers (fp32 torch arithmetic, bf16 rounding at every kernel boundary like the real kernels) and are compared
+with the reference's golden outputs and the fp32 oracle.  This checks everything that is not a kernel - weight
+re-layouts (NHWC conv matrices, fused QKV, GEGLU interleave), the padded-image convolutions, bank handling and the CFG
+shortcuts, window / overlap bookkeeping, unit and frame sharding with their collectives - in the dev container, where
+no GPU exists.  The kernels themselves, and the same host code on top of them, are what the `-m gpu` tests check."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import cases
+import dist_gpu_worker as W
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+@pytest.fixture()
+def emulated(monkeypatch):
+    import fake_ops
+    from v_express_amd import ops, prologue, unet_3d, vae
+    fake_ops.install(monkeypatch, ops)
+    monkeypatch.setattr(unet_3d._UNetBase, "_need_gpu", lambda self: None)
+    monkeypatch.setattr(vae.AutoencoderKLDecoder, "_need_gpu", lambda self: None)
+    monkeypatch.setattr(prologue._Module, "_need_gpu", lambda self: None)
+    monkeypatch.setattr(ops, "_PADDED", {})
+    return ops
+
+
+@pytest.mark.parametrize("name", ["small_f4_8x8", "small_f8_16x8"])
+def test_unet_forward_host_composition_vs_reference_golden(emulated, name):
+    import v_express_amd as vx
+    from oracle import unet as OU
+    from v_express_amd import synth
+    kw, F, h, w, t = cases.FORWARD_CASES[name]
+    cfg, ocfg = cases.unet_cfg(kw), cases.oracle_cfg(kw)
+    sd3, sd2 = synth.unet3d_state_dict(cfg), synth.refnet_state_dict(cfg)
+    inp = synth.synthetic_inputs(cfg, F, h, w)
+    unet, refnet = vx.UNet3DConditionModel(cfg).to("cpu"), vx.UNet2DConditionModel(cfg).to("cpu")
+    unet.load_state_dict(sd3, strict=True)
+    refnet.load_state_dict(sd2, strict=True)
+    writer = vx.ReferenceAttentionControl(refnet, do_classifier_free_guidance=True, mode="write", fusion_blocks="full")
+    reader = vx.ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", fusion_blocks="full",
+                                          reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD)
+    refnet(inp["ref_latents"], timestep=0, encoder_hidden_states=torch.zeros(1, 1, 768), return_dict=False)
+    obanks = OU.refnet_banks(sd2, ocfg, inp["ref_latents"])
+    assert sorted(refnet.banks) == sorted(obanks)
+    assert max(rel_l2(refnet.banks[k].view_as(obanks[k][0]), obanks[k][0]) for k in obanks) <= 3e-2
+    reader.update(writer, True)
+    x = inp["latents"].repeat(2, 1, 1, 1, 1)
+    ehs = inp["audio_embeddings"].reshape(-1, 5, 768)
+    got = unet(x, t, encoder_hidden_states=ehs, kps_features=inp["kps_features"], return_dict=False)[0]
+    gold = torch.load(os.path.join(GOLD, f"forward_{name}.pt"), weights_only=False)["pred"]
+    assert got.shape == gold.shape and rel_l2(got, gold) <= 3e-2
+
+
+@pytest.mark.parametrize("name", ["aligned_F10_c4o2", "reflected_F11_c4o2"])
+def test_denoising_loop_and_decode_host_composition_vs_reference_golden(emulated, name):
+    import v_express_amd as vx
+    from v_express_amd import ops, synth
+    from v_express_amd.context import get_context_scheduler
+    import ref_import as R
+    Fn, cf, co, steps = cases.PIPELINE_CASES[name]
+    cfg = cases.unet_cfg(cases.SMALL)
+    vcfg = synth.VaeConfig(**cases.SMALL_VAE)
+    unet, refnet = vx.UNet3DConditionModel(cfg).to("cpu"), vx.UNet2DConditionModel(cfg).to("cpu")
+    unet.load_state_dict(synth.unet3d_state_dict(cfg), strict=True)
+    refnet.load_state_dict(synth.refnet_state_dict(cfg), strict=True)
+    vae = vx.AutoencoderKLDecoder(vcfg).to("cpu")
+    vae.load_state_dict(synth.vae_decoder_state_dict(vcfg))
+    sched = vx.DDIMScheduler(**R.NOISE_SCHEDULER_KWARGS)
+    pipe = vx.VExpressPipeline(vae=vae, reference_net=refnet, denoising_unet=unet, scheduler=sched)
+    inp = synth.synthetic_inputs(cfg, Fn, 8, 8)
+    writer = vx.ReferenceAttentionControl(refnet, do_classifier_free_guidance=True, mode="write", fusion_blocks="full")
+    reader = vx.ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", fusion_blocks="full",
+                                          reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD)
+    refnet(inp["ref_latents"], timestep=0, encoder_hidden_states=torch.zeros(1, 1, 768), return_dict=False)
+    reader.update(writer, True)
+    sched.set_timesteps(steps)
+    windows = list(get_context_scheduler("uniform")(step=0, num_frames=Fn, context_size=cf, context_stride=1,
+                                                    context_overlap=co, closed_loop=False))
+    c0 = cfg.block_out_channels[0]
+    kps = ops.ncfhw_to_nhwc(inp["kps_features"], c0).view(2, Fn, 64, c0)
+    audio = inp["audio_embeddings"].to(torch.bfloat16).contiguous()
+    lat = inp["latents"].clone().float()
+    pipe.denoise(lat, kps, audio, sched.timesteps.tolist(), windows, cases.GUIDANCE)
+    g = torch.load(os.path.join(GOLD, f"pipeline_{name}.pt"), weights_only=False)
+    assert rel_l2(lat, g["latents"]) <= 5e-2
+    video = pipe.decode_latents(lat)
+    assert video.shape == g["video_f16"].shape
+    assert (video - g["video_f16"].float()).abs().mean().item() <= 2e-2
+
+
+def test_prologue_models_host_composition_vs_reference_golden(emulated):
+    import v_express_amd as vx
+    from v_express_amd import synth
+    g = torch.load(os.path.join(GOLD, "prologue.pt"), weights_only=False)
+    inp = cases.prologue_inputs()
+    kcfg = synth.KpsGuiderConfig(**cases.KPS_SMALL)
+    m = vx.VKpsGuider(kcfg.conditioning_embedding_channels, block_out_channels=kcfg.block_out_channels).to("cpu")
+    m.load_state_dict(synth.kps_guider_state_dict(kcfg))
+    assert rel_l2(m(inp["kps_images"]), g["kps_small"]) <= 2e-2
+    acfg = synth.AudioProjectionConfig(**cases.AUDIO_SMALL)
+    a = vx.AudioProjection(dim=acfg.dim, depth=acfg.depth, dim_head=acfg.dim_head, heads=acfg.heads,
+                           num_queries=acfg.num_queries, embedding_dim=acfg.embedding_dim, output_dim=acfg.output_dim,
+                           max_seq_len=acfg.max_seq_len).to("cpu")
+    a.load_state_dict(synth.audio_projection_state_dict(acfg))
+    assert rel_l2(a(inp["audio_windows_small"]), g["audio_small"]) <= 2e-2
+    vcfg = synth.VaeConfig(**cases.SMALL_VAE)
+    v = vx.AutoencoderKL(vcfg).to("cpu")
+    v.load_state_dict({**synth.vae_decoder_state_dict(vcfg), **synth.vae_encoder_state_dict(vcfg)})
+    assert rel_l2(v.encode(inp["ref_image"]).latent_dist.mean, g["vae_mean"]) <= 2e-2
+
+
+def _worker(rank, world, port, F, cf, co, S, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W.emulate_kernels()
+    lat = W.run(F, cf, co, 2, S, device="cpu")
+    q.put((rank, lat))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,S,F,cf,co", [(2, 2, 8, 8, 2), (4, 0, 8, 8, 2), (2, 1, 14, 8, 2)])
+def test_sharded_loop_with_the_real_host_code_matches_single_process(emulated, world, S, F, cf, co):
+    """`VExpressPipeline.denoise` + `UNet3DConditionModel.forward_tokens` + `blocks.motion_module(shard=)` under real
+    process groups (gloo): unit sharding (S = 1), frame sharding (S = 2) and the automatic policy (S = 0: 4 ranks, one
+    window -> 2 ranks per unit) against the single-process loop.  Like the real kernels, the emulated ones (float64
+    inside, bf16 at the boundaries) give a row the same result whatever else shares the call, so sharding is pure data
+    movement and the clip must come out BIT-identical, on every rank."""
+    ref = W.run(F, cf, co, 2, 0, device="cpu")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, F, cf, co, S, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, lat in results:
+        assert torch.isfinite(lat).all() and torch.equal(lat, ref), (rank, rel_l2(lat, ref))

@@ -130,12 +130,15 @@ class _UNetBase:
         self.load_state_dict(gen(self.cfg, seed=seed), strict=True)
         return self
 
+    def _need_gpu(self):
+        if self._device.type != "cuda":
+            raise RuntimeError("v_express_amd models run on an MI355X only: call .to('cuda') (no CPU path exists)")
+
     # ---- weight preparation
     def _prepared(self):
         if self._P is not None:
             return self._P
-        if self._device.type != "cuda":
-            raise RuntimeError("v_express_amd models run on an MI355X only: call .to('cuda') (no CPU path exists)")
+        self._need_gpu()
         missing = [k for k in self.expected_keys() if k not in self._raw]
         if missing:
             raise RuntimeError(f"weights not loaded (or released): {len(missing)} tensors missing, e.g. {missing[:3]}")

@@ -65,11 +65,14 @@ class AutoencoderKLDecoder:
         self.load_state_dict(synth.vae_decoder_state_dict(self.cfg, seed=seed))
         return self
 
+    def _need_gpu(self):
+        if self._device.type != "cuda":
+            raise RuntimeError("v_express_amd models run on an MI355X only: call .to('cuda')")
+
     def _prepared(self):
         if self._P is not None:
             return self._P
-        if self._device.type != "cuda":
-            raise RuntimeError("v_express_amd models run on an MI355X only: call .to('cuda')")
+        self._need_gpu()
         sd, dev, cfg = self._raw, self._device, self.cfg
         P = Wt.Prepared()
         P["post_quant"] = Wt.prep_conv(sd, "post_quant_conv", dev)
@@ -154,8 +157,7 @@ class AutoencoderKL(AutoencoderKLDecoder):
     def _prepared_encoder(self):
         if self._PE is not None:
             return self._PE
-        if self._device.type != "cuda":
-            raise RuntimeError("v_express_amd models run on an MI355X only: call .to('cuda')")
+        self._need_gpu()
         sd, dev, cfg = self._raw, self._device, self.cfg
         P = Wt.Prepared()
         P["conv_in"] = Wt.prep_conv(sd, "encoder.conv_in", dev)
