@@ -3,7 +3,8 @@
 Values follow /root/reference/inference_v2.yaml:1-23 and the SD-1.5 UNet config the reference
 loads (`model_ckpts/stable-diffusion-v1-5/unet/config.json`).
 """
-from dataclasses import dataclass, field
+
+from dataclasses import dataclass
 from typing import Tuple
 
 

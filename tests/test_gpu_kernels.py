@@ -4,7 +4,6 @@ a float32 PyTorch restatement of the same op fed the same bf16-rounded inputs.
 Tolerance (written per test): outputs are bf16, so the only error vs an fp32 evaluation of the same bf16 inputs is
 accumulation order + one final rounding:  max|err| <= 2^-7 * max|ref| (+ tiny abs) and relative L2 <= 6e-3.
 """
-import math
 
 import pytest
 import torch

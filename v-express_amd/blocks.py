@@ -8,7 +8,6 @@ collapses to this one resident layout.
 """
 import torch
 
-from . import lib as L
 from . import ops
 from .ops import ConvGeom
 

@@ -5,7 +5,6 @@ shapes/strides and `torch.cuda.current_stream()` to libvexpress_hip.so.  Activat
 channels-last tokens `[frames, H*W, C]`; weights are pre-laid-out by `weights.py`.
 """
 import ctypes as C
-import math
 import os
 
 import torch

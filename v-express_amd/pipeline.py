@@ -17,7 +17,6 @@ kernels when the v_express_amd classes are passed (prologue.py, vae.AutoencoderK
 transformers module.  The benchmark and the loop parity tests pass the prologue outputs in directly
 (`reference_latents=`, `kps_features=`, `audio_embeddings=`, `latents=` keyword arguments).
 """
-import math
 from typing import Callable, List, Optional, Union
 
 import torch

@@ -6,7 +6,6 @@ restated from its published behaviour — SURVEY.md Appendix A).
 Host side only: the per-step update itself runs in the fused `vx_overlap_ddim_step` kernel, fed by
 `step_coefficients(t)`; `step()` is kept as the reference-compatible tensor API.
 """
-import math
 from types import SimpleNamespace
 
 import numpy as np
