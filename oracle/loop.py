@@ -69,11 +69,13 @@ class DDIM:
 
 def mean_overlap(unet_fn, latents, timesteps, ddim, windows, guidance_scale, kps_feature, audio_embeddings,
                  callback=None):
-    """pipelines/v_express_pipeline.py:526-583 with CFG.
+    """pipelines/v_express_pipeline.py:526-583.
 
-    unet_fn(input_latents[2,4,f,h,w], t, ehs[2f,5,768], kps[2,320,f,h,w]) -> [2,4,f,h,w]
-    latents [1,4,F,h,w]; kps_feature [2,320,F,h,w]; audio_embeddings [2,F,5,768].  Returns final latents.
+    unet_fn(input_latents[b,4,f,h,w], t, ehs[b*f,5,768], kps[b,320,f,h,w]) -> [b,4,f,h,w]
+    latents [1,4,F,h,w]; kps_feature [b,320,F,h,w]; audio_embeddings [b,F,5,768] with b = 2 (uncond, cond) under
+    classifier-free guidance (guidance_scale > 1, :443) and b = 1 without.  Returns final latents.
     """
+    do_cfg = guidance_scale > 1.0
     latents = latents.clone()
     F_ = latents.shape[2]
     num_frame_context = torch.zeros(F_, dtype=torch.long)
@@ -86,10 +88,11 @@ def mean_overlap(unet_fn, latents, timesteps, ddim, windows, guidance_scale, kps
             kps = kps_feature[:, :, ctx]
             aud = audio_embeddings[:, ctx]
             aud = aud.reshape(-1, aud.shape[-2], aud.shape[-1])
-            inp = latents[:, :, ctx].repeat(2, 1, 1, 1, 1)
+            inp = latents[:, :, ctx].repeat(2 if do_cfg else 1, 1, 1, 1, 1)    # :539
             pred = unet_fn(inp, t, aud, kps)
-            u, c = pred.chunk(2)
-            pred = u + guidance_scale * (c - u)                            # :548-550
+            if do_cfg:
+                u, c = pred.chunk(2)
+                pred = u + guidance_scale * (c - u)                        # :548-550
             counter[ctx] += 1
             pred = pred / num_frame_context[ctx][None, None, :, None, None]   # :553
             ids, preds = [], []

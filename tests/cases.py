@@ -23,6 +23,15 @@ PIPELINE_CASES = {
 }
 
 
+# guidance_scale <= 1: no classifier-free guidance - batch of 1, conditional inputs only, bank without the zero half
+NOCFG_CASE = ("nocfg_F10_c4o2", 10, 4, 2, 3)          # name, F, context_frames, context_overlap, steps
+
+
+def cond_only(inp):
+    """The conditional half of synthetic_inputs' CFG pairs (what the prologue hooks return without CFG)."""
+    return dict(inp, kps_features=inp["kps_features"][1:], audio_embeddings=inp["audio_embeddings"][1:])
+
+
 def unet_cfg(kw):
     return synth.UNetConfig(**kw)
 

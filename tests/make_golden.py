@@ -71,6 +71,20 @@ def wav2vec2(out):
     print("wav2vec2", {k: (tuple(v.shape) if hasattr(v, "shape") else v) for k, v in g.items()})
 
 
+def nocfg(out):
+    """guidance_scale = 1.0: the reference loop without classifier-free guidance (batch of 1)."""
+    cfg = cases.unet_cfg(cases.SMALL)
+    unet, refnet = H.build_reference_unets(cfg)
+    vae = H.build_reference_vae(synth.VaeConfig(**cases.SMALL_VAE))
+    name, F, cf, co, steps = cases.NOCFG_CASE
+    inp = cases.cond_only(synth.synthetic_inputs(cfg, F, 8, 8))
+    video, trace = H.reference_pipeline_run(unet, refnet, vae, inp, F, steps, 1.0, cf, co, cases.W_REF, cases.W_AUD,
+                                            64, 64)
+    torch.save(dict(latents=trace[-1].clone(), latents_step0=trace[0].clone(), video_f16=video.to(torch.float16)),
+               os.path.join(out, f"pipeline_{name}.pt"))
+    print(name, video.shape, float(video.mean()))
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     out = os.path.join(HERE, "golden")
@@ -79,6 +93,8 @@ def main():
         return prologue(out)
     if len(sys.argv) > 1 and sys.argv[1] == "wav2vec2":
         return wav2vec2(out)
+    if len(sys.argv) > 1 and sys.argv[1] == "nocfg":
+        return nocfg(out)
     prologue(out)
     wav2vec2(out)
     built = {}
@@ -108,6 +124,7 @@ def main():
                  video_f16=video.to(torch.float16))
         torch.save(g, os.path.join(out, f"pipeline_{name}.pt"))
         print(name, video.shape, float(video.mean()))
+    nocfg(out)
     # window lists straight from the reference's pipelines/context.py
     from pipelines.context import uniform
     wins = {}

@@ -159,6 +159,34 @@ def test_pipeline_vs_reference_golden(name):
     assert video.min().item() >= 0.0 and video.max().item() <= 1.0
 
 
+def test_pipeline_without_cfg_vs_reference_golden():
+    """guidance_scale = 1.0 through VExpressPipeline.__call__: no classifier-free guidance, batch of 1, the reference
+    bank without the zero half (pipelines/v_express_pipeline.py:443,539,548; mutual_self_attention.py:357-363)."""
+    _need_gpu()
+    from v_express_amd import AutoencoderKLDecoder, DDIMScheduler, VExpressPipeline, synth
+    import ref_import as R
+    name, Fn, cf, co, steps = cases.NOCFG_CASE
+    cfg = cases.unet_cfg(cases.SMALL)
+    vcfg = synth.VaeConfig(**cases.SMALL_VAE)
+    unet, refnet = build_models(cases.SMALL, synth.unet3d_state_dict(cfg), synth.refnet_state_dict(cfg))
+    vae = AutoencoderKLDecoder(vcfg).to("cuda")
+    vae.load_state_dict(synth.vae_decoder_state_dict(vcfg))
+    pipe = VExpressPipeline(vae=vae, reference_net=refnet, denoising_unet=unet,
+                            scheduler=DDIMScheduler(**R.NOISE_SCHEDULER_KWARGS))
+    inp = cases.cond_only(synth.synthetic_inputs(cfg, Fn, 8, 8))
+    trace = []
+    video = pipe(None, None, None, 64, 64, Fn, steps, 1.0, context_frames=cf, context_overlap=co,
+                 reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD,
+                 reference_latents=inp["ref_latents"], kps_features=inp["kps_features"],
+                 audio_embeddings=inp["audio_embeddings"], latents=inp["latents"],
+                 callback=lambda i, t, l: trace.append(l.detach().cpu().clone()))
+    g = torch.load(os.path.join(GOLD, f"pipeline_{name}.pt"), weights_only=False)
+    r1, c1 = rel_l2(trace[-1], g["latents"]), cosine(trace[-1], g["latents"])
+    mae = (video - g["video_f16"].float()).abs().mean().item()
+    print(f"[{name}] final relL2={r1:.4g} cos={c1:.6f} video MAE={mae:.4g}")
+    assert r1 <= 5e-2 and c1 >= 0.998 and mae <= 2e-2, (r1, c1, mae)
+
+
 def test_vae_decode_vs_oracle_full_width():
     """sd-vae-ft-mse widths (128/256/512/512, attention head dim 512) on a 16x16 latent."""
     _need_gpu()

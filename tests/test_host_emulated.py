@@ -61,13 +61,15 @@ def test_unet_forward_host_composition_vs_reference_golden(emulated, name):
     assert got.shape == gold.shape and rel_l2(got, gold) <= 3e-2
 
 
-@pytest.mark.parametrize("name", ["aligned_F10_c4o2", "reflected_F11_c4o2"])
+@pytest.mark.parametrize("name", ["aligned_F10_c4o2", "reflected_F11_c4o2", cases.NOCFG_CASE[0]])
 def test_denoising_loop_and_decode_host_composition_vs_reference_golden(emulated, name):
     import v_express_amd as vx
     from v_express_amd import ops, synth
     from v_express_amd.context import get_context_scheduler
     import ref_import as R
-    Fn, cf, co, steps = cases.PIPELINE_CASES[name]
+    do_cfg = name != cases.NOCFG_CASE[0]            # the last case: guidance_scale = 1.0, batch of 1
+    Fn, cf, co, steps = cases.PIPELINE_CASES[name] if do_cfg else cases.NOCFG_CASE[1:]
+    guidance = cases.GUIDANCE if do_cfg else 1.0
     cfg = cases.unet_cfg(cases.SMALL)
     vcfg = synth.VaeConfig(**cases.SMALL_VAE)
     unet, refnet = vx.UNet3DConditionModel(cfg).to("cpu"), vx.UNet2DConditionModel(cfg).to("cpu")
@@ -78,19 +80,27 @@ def test_denoising_loop_and_decode_host_composition_vs_reference_golden(emulated
     sched = vx.DDIMScheduler(**R.NOISE_SCHEDULER_KWARGS)
     pipe = vx.VExpressPipeline(vae=vae, reference_net=refnet, denoising_unet=unet, scheduler=sched)
     inp = synth.synthetic_inputs(cfg, Fn, 8, 8)
-    writer = vx.ReferenceAttentionControl(refnet, do_classifier_free_guidance=True, mode="write", fusion_blocks="full")
-    reader = vx.ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", fusion_blocks="full",
+    if not do_cfg:
+        inp = cases.cond_only(inp)
+    nb = inp["kps_features"].shape[0]
+    writer = vx.ReferenceAttentionControl(refnet, do_classifier_free_guidance=do_cfg, mode="write",
+                                          fusion_blocks="full")
+    reader = vx.ReferenceAttentionControl(unet, do_classifier_free_guidance=do_cfg, mode="read", fusion_blocks="full",
                                           reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD)
     refnet(inp["ref_latents"], timestep=0, encoder_hidden_states=torch.zeros(1, 1, 768), return_dict=False)
-    reader.update(writer, True)
+    reader.update(writer, do_cfg)
     sched.set_timesteps(steps)
     windows = list(get_context_scheduler("uniform")(step=0, num_frames=Fn, context_size=cf, context_stride=1,
                                                     context_overlap=co, closed_loop=False))
     c0 = cfg.block_out_channels[0]
-    kps = ops.ncfhw_to_nhwc(inp["kps_features"], c0).view(2, Fn, 64, c0)
+    kps = ops.ncfhw_to_nhwc(inp["kps_features"], c0).view(nb, Fn, 64, c0)
     audio = inp["audio_embeddings"].to(torch.bfloat16).contiguous()
     lat = inp["latents"].clone().float()
-    pipe.denoise(lat, kps, audio, sched.timesteps.tolist(), windows, cases.GUIDANCE)
+    if not do_cfg:
+        with pytest.raises(ValueError):                        # CFG-shaped inputs with guidance_scale <= 1
+            pipe.denoise(lat.clone(), torch.cat([kps, kps]), torch.cat([audio, audio]), sched.timesteps.tolist(),
+                         windows, guidance)
+    pipe.denoise(lat, kps, audio, sched.timesteps.tolist(), windows, guidance)
     g = torch.load(os.path.join(GOLD, f"pipeline_{name}.pt"), weights_only=False)
     assert rel_l2(lat, g["latents"]) <= 5e-2
     video = pipe.decode_latents(lat)

@@ -131,3 +131,22 @@ def test_wav2vec2_oracle_matches_transformers_golden_and_live(tag):
     legacy[p + "weight_g"] = sd[p + "parametrizations.weight.original0"]
     legacy[p + "weight_v"] = sd[p + "parametrizations.weight.original1"]
     assert torch.equal(OW.pos_conv_weight(legacy), OW.pos_conv_weight(sd))
+
+
+def test_loop_without_cfg_matches_reference_golden():
+    """guidance_scale = 1.0 (pipelines/v_express_pipeline.py:443: no classifier-free guidance): batch of 1, conditional
+    inputs only, reference bank without the zero half (mutual_self_attention.py:357-363)."""
+    name, F, cf, co, steps = cases.NOCFG_CASE
+    cfg, ocfg = cases.unet_cfg(cases.SMALL), cases.oracle_cfg(cases.SMALL)
+    vcfg, ovcfg = synth.VaeConfig(**cases.SMALL_VAE), oracle.VaeConfig(**cases.SMALL_VAE)
+    sd3, sd2, sdv = synth.unet3d_state_dict(cfg), synth.refnet_state_dict(cfg), synth.vae_decoder_state_dict(vcfg)
+    inp = cases.cond_only(synth.synthetic_inputs(cfg, F, 8, 8))
+    g = _load(f"pipeline_{name}.pt")
+    banks = OU.reader_banks(OU.refnet_banks(sd2, ocfg, inp["ref_latents"]), do_classifier_free_guidance=False)
+    ddim = OL.DDIM()
+    lat = OL.mean_overlap(lambda x, t, e, k: OU.unet3d_forward(sd3, ocfg, x, t, e, k, banks, cases.W_REF, cases.W_AUD),
+                          inp["latents"], ddim.set_timesteps(steps), ddim, OL.uniform_windows(F, cf, co), 1.0,
+                          inp["kps_features"], inp["audio_embeddings"])
+    assert (lat - g["latents"]).abs().max().item() < 5 * TOL
+    video = OV.decode_latents(sdv, ovcfg, lat)
+    assert (video - g["video_f16"].float()).abs().max().item() < 2e-3

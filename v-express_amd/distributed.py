@@ -21,11 +21,12 @@ import torch
 import torch.distributed as dist
 
 
-def partition_units(num_windows: int, world_size: int) -> List[List[Tuple[int, int]]]:
+def partition_units(num_windows: int, world_size: int, halves: int = 2) -> List[List[Tuple[int, int]]]:
     """Contiguous block assignment of the (window, cfg_half) units: rank r gets units [starts[r], starts[r+1])
     of the list (w0,u),(w0,c),(w1,u),(w1,c),...  Sizes differ by at most one, adjacent units stay together so
-    that both halves of a window usually land on one rank and run as one b=2 batch."""
-    units = [(w, h) for w in range(num_windows) for h in range(2)]
+    that both halves of a window usually land on one rank and run as one b=2 batch.  halves = 1: no classifier-free
+    guidance (guidance_scale <= 1), a unit is a whole window's single batch row."""
+    units = [(w, h) for w in range(num_windows) for h in range(halves)]
     n = len(units)
     base, extra = divmod(n, world_size)
     out, pos = [], 0
@@ -47,11 +48,11 @@ def group_calls(units: List[Tuple[int, int]]) -> List[Tuple[int, List[int]]]:
     return calls
 
 
-def choose_frame_shards(num_windows: int, world_size: int, window_frames: int, min_hw: int) -> int:
-    """Largest power-of-two S such that the clip still has too few units for the ranks without it (2*W*S <= world),
-    S divides the world size, the window length and the token count of the coarsest UNet level."""
+def choose_frame_shards(num_windows: int, world_size: int, window_frames: int, min_hw: int, halves: int = 2) -> int:
+    """Largest power-of-two S such that the clip still has too few units for the ranks without it
+    (halves*W*S <= world), S divides the world size, the window length and the token count of the coarsest UNet level."""
     s = 1
-    while (2 * num_windows * (2 * s) <= world_size and world_size % (2 * s) == 0 and window_frames % (2 * s) == 0
+    while (halves * num_windows * (2 * s) <= world_size and world_size % (2 * s) == 0 and window_frames % (2 * s) == 0
            and min_hw % (2 * s) == 0):
         s *= 2
     return s
@@ -62,12 +63,13 @@ class UnitSchedule:
     frame_shards = S > 1 the ranks form world/S groups of S consecutive ranks; a group owns units like a single rank
     does for S = 1 and member j of the group computes frames [j*f/S, (j+1)*f/S) of each of them."""
 
-    def __init__(self, num_windows: int, world_size: int, frame_shards: int = 1):
+    def __init__(self, num_windows: int, world_size: int, frame_shards: int = 1, halves: int = 2):
         if frame_shards < 1 or world_size % frame_shards:
             raise ValueError(f"frame_shards={frame_shards} must divide the world size {world_size}")
         self.num_windows, self.world_size, self.frame_shards = num_windows, world_size, frame_shards
+        self.halves = halves
         self.groups = world_size // frame_shards
-        self.assign = partition_units(num_windows, self.groups)
+        self.assign = partition_units(num_windows, self.groups, halves)
         self.max_units = max(len(a) for a in self.assign)
         self.slot = {}
         for r, units in enumerate(self.assign):

@@ -154,7 +154,8 @@ class VExpressPipeline:
     def denoise(self, latents, kps_tokens, audio, timesteps, windows, guidance_scale, callback=None,
                 callback_steps=1):
         """pipelines/v_express_pipeline.py:526-583.  latents fp32 [1,4,F,h,w] (device, updated in place);
-        kps_tokens bf16 [2, F, hw, C0]; audio bf16 [2, F, n_ctx, 768]."""
+        kps_tokens bf16 [b, F, hw, C0]; audio bf16 [b, F, n_ctx, 768] with b = 2 (uncond, cond) under classifier-free
+        guidance (guidance_scale > 1, :443) and b = 1 (the conditional row only) without."""
         unet, dc, dev = self.denoising_unet, self.dist, latents.device
         _, C, F, H, W = latents.shape
         hw = H * W
@@ -174,11 +175,16 @@ class VExpressPipeline:
         frame_ids = torch.tensor(sf, dtype=torch.int32, device=dev)
         counts = torch.tensor([float(plan["counts"][fr]) for fr in sf], dtype=torch.float32, device=dev)
         # work units of this rank; S > 1: the window's frames are split over S ranks per unit (short clips)
-        S = self.frame_shards or choose_frame_shards(nW, dc.world_size, f, (H // 8) * (W // 8))
+        do_cfg = guidance_scale > 1.0
+        halves_n = 2 if do_cfg else 1
+        if kps_tokens.shape[0] != halves_n or audio.shape[0] != halves_n:
+            raise ValueError(f"guidance_scale={guidance_scale} needs {halves_n} batch row(s) of kps features / audio "
+                             f"embeddings, got {kps_tokens.shape[0]} / {audio.shape[0]}")
+        S = self.frame_shards or choose_frame_shards(nW, dc.world_size, f, (H // 8) * (W // 8), halves_n)
         if S < 1 or dc.world_size % S or f % S or ((H // 8) * (W // 8)) % S:
             raise ValueError(f"frame_shards={S} must divide the world size ({dc.world_size}), the window length ({f}) "
                              f"and the {H // 8}x{W // 8} tokens of the coarsest UNet level")
-        sched_u = UnitSchedule(nW, dc.world_size, S)
+        sched_u = UnitSchedule(nW, dc.world_size, S, halves_n)
         my_calls, max_units = sched_u.calls(dc.rank), sched_u.max_units
         shard = dc.frame_shard(S)
         f_loc = f // S
@@ -188,9 +194,6 @@ class VExpressPipeline:
         local = torch.zeros((max_units, f_loc * hw, n_out), device=dev, dtype=torch.float32)
         preds = torch.empty((nW, C, f, hw), device=dev, dtype=torch.float32)
         pair = torch.empty((2 * f * hw, n_out), device=dev, dtype=torch.float32)
-        do_cfg = guidance_scale > 1.0
-        if not do_cfg:
-            raise NotImplementedError("guidance_scale <= 1 (no CFG) is not wired; V-Express defaults to 3.5")
         # per-call constants (window ids, conditioning slices) do not depend on the timestep: build them once so
         # the timestep loop issues kernels only (no host->device copies, no syncs)
         # which CFG halves carry all-zero audio tokens (the unconditional half, :403-405): one device reduction per clip
@@ -216,12 +219,16 @@ class VExpressPipeline:
                     local[my_slot[(wi, hlf)]].copy_(out[j * f_loc * hw:(j + 1) * f_loc * hw])
             gathered = dc.all_gather_units(local, max_units)          # [world, max_units, (f/S)*hw, 8]
             for wi in range(nW):
-                for hlf in range(2):
+                for hlf in range(halves_n):
                     ranks, slot = sched_u.unit_ranks((wi, hlf))
                     for j, r in enumerate(ranks):                    # frame shards in frame order
                         base = (hlf * f + j * f_loc) * hw
                         pair[base:base + f_loc * hw].copy_(gathered[r, slot])
-                ops.cfg_combine(pair, C, f, hw, guidance_scale, preds[wi])
+                if do_cfg:
+                    ops.cfg_combine(pair, C, f, hw, guidance_scale, preds[wi])
+                else:                                                # :548-550 skipped: u + 1 * (c - u) with u = c, exactly c
+                    pair[f * hw:].copy_(pair[:f * hw])
+                    ops.cfg_combine(pair, C, f, hw, 1.0, preds[wi])
             ops.overlap_ddim_step(latents, preds, terms, frame_ids, counts, self.scheduler.step_coefficients(t))
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, latents)
