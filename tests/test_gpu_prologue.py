@@ -300,3 +300,27 @@ def test_audio_path_waveform_to_audio_tokens_on_device():
                         wcfg.num_conv_pos_embedding_groups, wcfg.conv_stride, wcfg.layer_norm_eps)
     ref = OP.audio_projection(asd, OP.audio_windows(states, F_, pad), acfg.depth, acfg.heads)
     _close(got[1], ref, "waveform -> audio tokens", rel=3e-2, mx=2 ** -4)
+
+
+def test_pipeline_call_end_to_end_vs_oracle():
+    """VExpressPipeline.__call__ from raw inputs (reference image, keypoint images, 16 kHz waveform) through every model
+    on the HIP kernels - VAE encode, VKpsGuider, wav2vec2 + windows + AudioProjection, ReferenceNet banks, the windowed
+    CFG loop, VAE decode - against the same chain built from the oracle pieces (tests/test_host_emulated.py holds the
+    builders; the CPU suite runs the identical comparison over emulated kernels)."""
+    _need_gpu()
+    import test_host_emulated as E
+    F_, steps, cf, co = 6, 2, 4, 2
+    pipe, sd, cfgs = E.build_end_to_end("cuda")
+    inp = E.end_to_end_inputs(F_)
+    trace = []
+    video = pipe(inp["ref_image"], inp["kps_images"], inp["waveform"], 64, 64, F_, steps, cases.GUIDANCE,
+                 context_frames=cf, context_overlap=co, reference_attention_weight=cases.W_REF,
+                 audio_attention_weight=cases.W_AUD, latents=inp["latents"],
+                 callback=lambda i, t, l: trace.append(l.detach().cpu().clone()))
+    with torch.no_grad():
+        lat_ref, video_ref = E.oracle_end_to_end(sd, cfgs, inp, F_, steps, cf, co)
+    assert video.device.type == "cpu" and video.shape == video_ref.shape
+    err = (trace[-1] - lat_ref).norm() / lat_ref.norm()
+    mae = (video - video_ref).abs().mean().item()
+    print(f"[end to end] latents relL2={err:.4g} video MAE={mae:.4g}")
+    assert err <= 5e-2 and mae <= 2e-2, (err, mae)

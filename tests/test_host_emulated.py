@@ -163,3 +163,90 @@ def test_sharded_loop_with_the_real_host_code_matches_single_process(emulated, w
         assert p.exitcode == 0
     for rank, lat in results:
         assert torch.isfinite(lat).all() and torch.equal(lat, ref), (rank, rel_l2(lat, ref))
+
+
+def build_end_to_end(device):
+    """Every model of VExpressPipeline.__call__ at its small test configuration with seeded synthetic weights:
+    (pipeline, state dicts, configs)."""
+    import v_express_amd as vx
+    from v_express_amd import synth
+    import ref_import as R
+    cfg = cases.unet_cfg(cases.SMALL)
+    vcfg = synth.VaeConfig(**cases.SMALL_VAE)
+    kcfg = synth.KpsGuiderConfig(**cases.KPS_SMALL)
+    wcfg = synth.Wav2Vec2Config(**cases.W2V_SMALL)
+    acfg = synth.AudioProjectionConfig(dim=128, depth=2, dim_head=16, heads=8, num_queries=5,
+                                       embedding_dim=wcfg.hidden_size, output_dim=cfg.cross_attention_dim, max_seq_len=10)
+    sd = dict(unet=synth.unet3d_state_dict(cfg), refnet=synth.refnet_state_dict(cfg),
+              vae={**synth.vae_decoder_state_dict(vcfg), **synth.vae_encoder_state_dict(vcfg)},
+              kps=synth.kps_guider_state_dict(kcfg), w2v=synth.wav2vec2_state_dict(wcfg),
+              proj=synth.audio_projection_state_dict(acfg))
+    unet, refnet = vx.UNet3DConditionModel(cfg).to(device), vx.UNet2DConditionModel(cfg).to(device)
+    unet.load_state_dict(sd["unet"], strict=True)
+    refnet.load_state_dict(sd["refnet"], strict=True)
+    vae = vx.AutoencoderKL(vcfg).to(device)
+    vae.load_state_dict(sd["vae"])
+    guider = vx.VKpsGuider(kcfg.conditioning_embedding_channels, block_out_channels=kcfg.block_out_channels).to(device)
+    guider.load_state_dict(sd["kps"])
+    enc = vx.Wav2Vec2Model(wcfg).to(device)
+    enc.load_state_dict(sd["w2v"])
+    proj = vx.AudioProjection(dim=acfg.dim, depth=acfg.depth, dim_head=acfg.dim_head, heads=acfg.heads,
+                              num_queries=acfg.num_queries, embedding_dim=acfg.embedding_dim,
+                              output_dim=acfg.output_dim, max_seq_len=acfg.max_seq_len).to(device)
+    proj.load_state_dict(sd["proj"])
+    pipe = vx.VExpressPipeline(vae=vae, reference_net=refnet, denoising_unet=unet, v_kps_guider=guider,
+                               audio_processor=vx.WaveformProcessor(), audio_encoder=enc, audio_projection=proj,
+                               scheduler=vx.DDIMScheduler(**R.NOISE_SCHEDULER_KWARGS))
+    return pipe, sd, dict(unet=cfg, vae=vcfg, w2v=wcfg, proj=acfg)
+
+
+def end_to_end_inputs(F_=6, size=64, seed=21):
+    g = torch.Generator().manual_seed(seed)
+    return dict(ref_image=torch.rand(1, 3, size, size, generator=g),
+                kps_images=[torch.rand(1, 3, size, size, generator=g) for _ in range(F_)],
+                waveform=torch.randn(9600, generator=g) * 0.2 + 0.05,                   # 0.6 s @ 16 kHz
+                latents=torch.randn(1, 4, F_, size // 8, size // 8, generator=g))
+
+
+def oracle_end_to_end(sd, cfgs, inp, F_, steps, cf, co, pad=2):
+    """The reference's __call__ (pipelines/v_express_pipeline.py:409-589) restated with the oracle pieces."""
+    import oracle
+    from oracle import loop as OL, prologue as OP, unet as OU, vae as OV, wav2vec2 as OW
+    ocfg = cases.oracle_cfg(cases.SMALL)
+    ovcfg = oracle.VaeConfig(**cases.SMALL_VAE)
+    ref_lat = OP.vae_encode_mean(sd["vae"], ovcfg, 2.0 * inp["ref_image"] - 1.0) * 0.18215           # :343-348
+    kps = OP.kps_guider(sd["kps"], torch.cat(inp["kps_images"], dim=0))                                # [F, C, h, w]
+    kps = kps.permute(1, 0, 2, 3)[None]
+    kps = torch.cat([torch.zeros_like(kps), kps], dim=0)                                               # :368-371
+    wc = cfgs["w2v"]
+    states = OW.forward(sd["w2v"], OW.normalize_waveform(inp["waveform"])[None], wc.num_hidden_layers,
+                        wc.num_attention_heads, wc.num_conv_pos_embedding_groups, wc.conv_stride, wc.layer_norm_eps)
+    aud = OP.audio_projection(sd["proj"], OP.audio_windows(states, F_, pad), cfgs["proj"].depth,
+                              cfgs["proj"].heads)[None]
+    aud = torch.cat([torch.zeros_like(aud), aud], dim=0)                                               # :403-405
+    banks = OU.reader_banks(OU.refnet_banks(sd["refnet"], ocfg, ref_lat))
+    ddim = OL.DDIM()
+    lat = OL.mean_overlap(lambda x, t, e, k: OU.unet3d_forward(sd["unet"], ocfg, x, t, e, k, banks, cases.W_REF,
+                                                               cases.W_AUD),
+                          inp["latents"], ddim.set_timesteps(steps), ddim, OL.uniform_windows(F_, cf, co),
+                          cases.GUIDANCE, kps, aud)
+    return lat, OV.decode_latents(sd["vae"], ovcfg, lat)
+
+
+def test_pipeline_call_end_to_end_host_composition_vs_oracle(emulated):
+    """VExpressPipeline.__call__ from raw inputs - reference image, keypoint images, 16 kHz waveform - through every
+    model (VAE encode, VKpsGuider, wav2vec2 + windows + AudioProjection, ReferenceNet banks, the windowed CFG loop, VAE
+    decode) against the same chain built from the oracle pieces."""
+    F_, steps, cf, co = 6, 2, 4, 2
+    pipe, sd, cfgs = build_end_to_end("cpu")
+    inp = end_to_end_inputs(F_)
+    trace = []
+    video = pipe(inp["ref_image"], inp["kps_images"], inp["waveform"], 64, 64, F_, steps, cases.GUIDANCE,
+                 context_frames=cf, context_overlap=co, reference_attention_weight=cases.W_REF,
+                 audio_attention_weight=cases.W_AUD, latents=inp["latents"], output_device=None,
+                 callback=lambda i, t, l: trace.append(l.detach().clone()))
+    with torch.no_grad():
+        lat_ref, video_ref = oracle_end_to_end(sd, cfgs, inp, F_, steps, cf, co)
+    assert video.shape == video_ref.shape == (1, 3, F_, 64, 64)
+    assert rel_l2(trace[-1], lat_ref) <= 5e-2
+    assert (video - video_ref).abs().mean().item() <= 2e-2

@@ -302,16 +302,20 @@ class VExpressPipeline:
             b2, c0, F, h, w = kps_features.shape
             kps_tokens = ops.ncfhw_to_nhwc(kps_features.to(dev), c0).view(b2, F, h * w, c0)
         audio = audio_embeddings.to(device=dev, dtype=ops.BF16).contiguous()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        ev[0].record()
+        timed = lat.is_cuda          # (host-logic tests run this method on CPU tensors over emulated kernels)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
+        if timed:
+            ev[0].record()
         self.denoise(lat, kps_tokens, audio, timesteps, windows, guidance_scale, callback, callback_steps or 1)
-        ev[1].record()
+        if timed:
+            ev[1].record()
         reader.clear()
         writer.clear()
         if not decode:
             return lat
         video = self.decode_latents(lat)
-        ev[2].record()
+        if timed:
+            ev[2].record()
         self._events = ev
         if output_device is not None:
             video = video.to(output_device)
