@@ -266,3 +266,19 @@ def test_wav2vec2_host_composition_with_emulated_kernels(tag, monkeypatch):
         WaveformProcessor()(raw, sampling_rate=8000)
     with pytest.raises(NotImplementedError):
         Wav2Vec2Model(synth.Wav2Vec2Config(do_stable_layer_norm=True))
+
+
+def test_bench_algorithmic_flops_match_the_survey_figures():
+    """bench.py's whole-path denominator: SURVEY.md 8d gives 66.4 / 82.3 / 84.9 TFLOP per decoded frame for the 16-, 64-
+    and 124-frame clips at 512x512 and 183.8 at 768x768 (the SDPA terms grow with the square of the pixel count)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vx_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert abs(bench.flop_per_frame(16, 1, 25, 1.0) - 66.4) < 0.05
+    assert abs(bench.flop_per_frame(64, 5, 25, 1.0) - 82.3) < 0.05
+    assert abs(bench.flop_per_frame(124, 10, 25, 1.0) - 84.9) < 0.05
+    assert abs(bench.flop_per_frame(16, 1, 25, 2.25) - 183.8) < 0.1
+    traffic, src = bench._pmc_traffic("gemm_ring_kernel<256x320x64,8w,STORE,fast>")
+    assert traffic and traffic > 1e8 and src.startswith("profiles/")
