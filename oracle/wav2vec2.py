@@ -1,7 +1,7 @@
 """Oracle restatement of the wav2vec2 audio encoder — TEST INFRASTRUCTURE.
 
 The reference feeds `Wav2Vec2Model(audio).last_hidden_state` into the audio-window construction
-(pipelines/v_express_pipeline.py:374-378; loaded from `facebook/wav2vec2-base-960h` by inference.py:109-110).  The
+(pipelines/v_express_pipeline.py:374-378; loaded from `facebook/wav2vec2-base-960h` by inference.py:165-166).  The
 model lives in a third-party dependency (transformers==4.41.1, requirements.txt:10; 5.x is what this image has) and is
 restated here from its published architecture for the one variant V-Express uses: `feat_extract_norm="group"`,
 `do_stable_layer_norm=False`, no convolution bias, eval mode (no SpecAugment masking, no dropout, no LayerDrop).

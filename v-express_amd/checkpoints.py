@@ -96,7 +96,7 @@ def load_audio_projection(audio_projection_path, dtype=torch.bfloat16, device="c
 
 
 def load_audio_encoder(audio_encoder_path, dtype=torch.bfloat16, device="cuda"):
-    """inference.py:109-110: `Wav2Vec2Model.from_pretrained(path)` + `Wav2Vec2Processor.from_pretrained(path)` ->
+    """inference.py:165-166: `Wav2Vec2Model.from_pretrained(path)` + `Wav2Vec2Processor.from_pretrained(path)` ->
     (encoder on the HIP kernels, waveform processor)."""
     from .wav2vec2 import Wav2Vec2Model, WaveformProcessor
     proc = WaveformProcessor()

@@ -318,7 +318,7 @@ class AudioProjectionConfig:
 
 @dataclass
 class Wav2Vec2Config:
-    """facebook/wav2vec2-base-960h (the audio encoder inference.py:109-110 loads): transformers Wav2Vec2Config fields
+    """facebook/wav2vec2-base-960h (the audio encoder inference.py:165-166 loads): transformers Wav2Vec2Config fields
     that shape the eval-mode forward.  Only the group-norm / post-LayerNorm variant is supported."""
     hidden_size: int = 768
     num_hidden_layers: int = 12

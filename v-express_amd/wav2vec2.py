@@ -2,7 +2,7 @@
 
 Drop-in for the `audio_encoder` the reference pipeline calls once per clip (`self.audio_encoder(wave).last_hidden_state`,
 pipelines/v_express_pipeline.py:377; transformers `Wav2Vec2Model.from_pretrained("facebook/wav2vec2-base-960h")`,
-inference.py:109-110), for the one variant that checkpoint uses: group-norm feature encoder, post-LayerNorm
+inference.py:165-166), for the one variant that checkpoint uses: group-norm feature encoder, post-LayerNorm
 transformer, eval mode.  Same constructor-from-config / `load_state_dict` / `forward(input_values)` surface and the
 transformers state_dict key names.
 
@@ -67,7 +67,7 @@ class Wav2Vec2Model(_Module):
 
     @classmethod
     def from_pretrained(cls, path, dtype=torch.bfloat16, device="cuda"):
-        """`Wav2Vec2Model.from_pretrained(audio_encoder_path)` (inference.py:109) for the transformers directory layout:
+        """`Wav2Vec2Model.from_pretrained(audio_encoder_path)` (inference.py:165) for the transformers directory layout:
         `config.json` + `model.safetensors` / `pytorch_model.bin`.  A `Wav2Vec2ForCTC` checkpoint (what
         wav2vec2-base-960h is) is accepted: the `wav2vec2.` prefix is stripped and the CTC head dropped."""
         from .checkpoints import _load_file
