@@ -327,7 +327,7 @@ def test_frame_sharded_loop_matches_single_rank(world, S, F, cf, co, tmp_path):
     out = str(tmp_path / "lat.pt")
     env = dict(os.environ, VX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(29540 + world + S),
+           "--master-addr", "127.0.0.1", "--master-port", str(29540 + 10 * world + S + F),
            os.path.join(root, "tests", "dist_gpu_worker.py"), out, str(F), str(cf), str(co), "2", str(S)]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
