@@ -250,3 +250,21 @@ def test_pipeline_call_end_to_end_host_composition_vs_oracle(emulated):
     assert video.shape == video_ref.shape == (1, 3, F_, 64, 64)
     assert rel_l2(trace[-1], lat_ref) <= 5e-2
     assert (video - video_ref).abs().mean().item() <= 2e-2
+
+
+def test_merging_windows_into_one_unet_call_changes_nothing(emulated):
+    """`VExpressPipeline.units_per_call = 4`: two windows (4 CFG rows) per UNet call instead of one.  Batch rows are
+    independent in every kernel, so the clip must be bit-identical to the default one-window-per-call loop."""
+    import v_express_amd as vx
+    ref = W.run(14, 8, 2, 2, 0, device="cpu")
+    orig = vx.VExpressPipeline.__init__
+
+    def patched(self, *a, **k):
+        orig(self, *a, **k)
+        self.units_per_call = 4
+    vx.VExpressPipeline.__init__ = patched
+    try:
+        got = W.run(14, 8, 2, 2, 0, device="cpu")
+    finally:
+        vx.VExpressPipeline.__init__ = orig
+    assert torch.equal(got, ref)

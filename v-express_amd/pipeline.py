@@ -44,6 +44,9 @@ class VExpressPipeline:
         # ranks per (window, CFG-half) unit, each holding 1/S of the window's frames; None = automatic (S > 1 only
         # when the clip has fewer units than ranks, distributed.choose_frame_shards)
         self.frame_shards = None
+        # batch rows per UNet call: 2 = the two CFG halves of one window (default); 4, 6, ... also merge consecutive
+        # windows of this rank into one call
+        self.units_per_call = 2
         self.last_timing = {}
 
     # ------------------------------------------------------------------ plumbing
@@ -198,25 +201,44 @@ class VExpressPipeline:
         # the timestep loop issues kernels only (no host->device copies, no syncs)
         # which CFG halves carry all-zero audio tokens (the unconditional half, :403-405): one device reduction per clip
         audio_is_zero = [bool((audio[hh] == 0).all().item()) for hh in range(audio.shape[0])]
-        calls = []
+        # UNet calls of this rank: the units of one window always share a call; `units_per_call` > 2 also merges
+        # consecutive windows into one batch (every kernel is batch-invariant, so the rows come out identical - only
+        # the launches get fatter, which helps the 16x16 / 8x8 levels of multi-window clips)
+        limit = int(self.units_per_call)
+        merged, cur = [], []
         for wi, halves in my_calls:
-            hsel = torch.tensor(halves, device=dev)
-            ids_long = win_ids_long[wi][lo:lo + f_loc]
-            kps = kps_tokens.index_select(0, hsel).index_select(1, ids_long).reshape(len(halves) * f_loc, hw, -1)
-            ehs = audio.index_select(0, hsel).index_select(1, ids_long)
-            ehs = ehs.reshape(-1, ehs.shape[-1]).contiguous()
-            # the audio K | V of all 16 transformer blocks is step-invariant: once per clip and window
-            calls.append((wi, halves, win_ids[wi][lo:lo + f_loc].contiguous(), kps.contiguous(), ehs,
-                          unet.precompute_audio_kv(ehs)))
+            if cur and (limit <= 2 or sum(len(h) for _, h in cur) + len(halves) > limit):
+                merged.append(cur)
+                cur = []
+            cur.append((wi, halves))
+        if cur:
+            merged.append(cur)
+        calls = []
+        for group in merged:
+            rows = [(wi, hlf) for wi, halves in group for hlf in halves]          # batch rows of the call, in order
+            kps_l, ehs_l = [], []
+            for wi, halves in group:
+                hsel = torch.tensor(halves, device=dev)
+                ids_long = win_ids_long[wi][lo:lo + f_loc]
+                kps_l.append(kps_tokens.index_select(0, hsel).index_select(1, ids_long)
+                             .reshape(len(halves) * f_loc, hw, -1))
+                e = audio.index_select(0, hsel).index_select(1, ids_long)
+                ehs_l.append(e.reshape(-1, e.shape[-1]))
+            kps = torch.cat(kps_l, dim=0).contiguous()
+            ehs = torch.cat(ehs_l, dim=0).contiguous()
+            gathers = [(win_ids[wi][lo:lo + f_loc].contiguous(), len(halves)) for wi, halves in group]
+            # the audio K | V of all 16 transformer blocks is step-invariant: once per clip and call
+            calls.append((rows, gathers, kps, ehs, unet.precompute_audio_kv(ehs)))
         for i, t in enumerate(timesteps):
             t = int(t)
-            for wi, halves, ids, kps, ehs, akv in calls:
-                x_in = ops.gather_latents(latents, ids, reps=len(halves))
-                out = unet.forward_tokens(x_in, t, ehs, kps, b=len(halves), f=f_loc, H=H, W=W, batch_rows=halves,
-                                          audio_kv=akv, audio_zero=[audio_is_zero[hh] for hh in halves],
-                                          frame_shard=shard)
-                for j, hlf in enumerate(halves):
-                    local[my_slot[(wi, hlf)]].copy_(out[j * f_loc * hw:(j + 1) * f_loc * hw])
+            for rows, gathers, kps, ehs, akv in calls:
+                parts = [ops.gather_latents(latents, ids, reps=reps) for ids, reps in gathers]
+                x_in = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+                out = unet.forward_tokens(x_in, t, ehs, kps, b=len(rows), f=f_loc, H=H, W=W,
+                                          batch_rows=[hlf for _, hlf in rows], audio_kv=akv,
+                                          audio_zero=[audio_is_zero[hlf] for _, hlf in rows], frame_shard=shard)
+                for j, unit in enumerate(rows):
+                    local[my_slot[unit]].copy_(out[j * f_loc * hw:(j + 1) * f_loc * hw])
             gathered = dc.all_gather_units(local, max_units)          # [world, max_units, (f/S)*hw, 8]
             for wi in range(nW):
                 for hlf in range(halves_n):
