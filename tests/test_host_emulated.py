@@ -34,7 +34,7 @@ def emulated(monkeypatch):
     return ops
 
 
-@pytest.mark.parametrize("name", ["small_f4_8x8", "small_f8_16x8"])
+@pytest.mark.parametrize("name", ["small_f4_8x8", "small_f8_16x8", "full_f4_8x8"])      # full = the SD-1.5 widths
 def test_unet_forward_host_composition_vs_reference_golden(emulated, name):
     import v_express_amd as vx
     from oracle import unet as OU
