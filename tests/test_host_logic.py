@@ -282,3 +282,41 @@ def test_bench_algorithmic_flops_match_the_survey_figures():
     assert abs(bench.flop_per_frame(16, 1, 25, 2.25) - 183.8) < 0.1
     traffic, src = bench._pmc_traffic("gemm_ring_kernel<256x320x64,8w,STORE,fast>")
     assert traffic and traffic > 1e8 and src.startswith("profiles/")
+
+
+def test_audio_encoder_directory_loader(tmp_path, monkeypatch):
+    """checkpoints.load_audio_encoder / Wav2Vec2Model.from_pretrained on a transformers-style directory (config.json,
+    preprocessor_config.json, model.safetensors of a Wav2Vec2ForCTC checkpoint: `wav2vec2.` prefix + CTC head), then
+    one emulated forward against the oracle."""
+    import json
+    import cases
+    import fake_ops
+    from safetensors.torch import save_file
+    from oracle import wav2vec2 as OW
+    from v_express_amd import checkpoints, ops
+    from v_express_amd.wav2vec2 import Wav2Vec2Model
+    fake_ops.install(monkeypatch, ops)
+    monkeypatch.setattr(Wav2Vec2Model, "_need_gpu", lambda self: None)
+    kw, samples = cases.W2V_CASES["small"]
+    cfg = synth.Wav2Vec2Config(**kw)
+    sd = synth.wav2vec2_state_dict(cfg)
+    d = tmp_path / "wav2vec2-tiny"
+    d.mkdir()
+    conf = {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.__dict__.items()}
+    conf.update(architectures=["Wav2Vec2ForCTC"], vocab_size=32, model_type="wav2vec2")      # extra keys are ignored
+    (d / "config.json").write_text(json.dumps(conf))
+    (d / "preprocessor_config.json").write_text(json.dumps({"do_normalize": True, "sampling_rate": 16000}))
+    ckpt = {("wav2vec2." + k): v.contiguous() for k, v in sd.items()}
+    ckpt["lm_head.weight"], ckpt["lm_head.bias"] = torch.zeros(32, cfg.hidden_size), torch.zeros(32)
+    save_file(ckpt, str(d / "model.safetensors"))
+    enc, proc = checkpoints.load_audio_encoder(str(d), device="cpu")
+    assert enc.cfg == cfg and proc.sampling_rate == 16000 and proc.do_normalize
+    raw = torch.randn(samples, generator=torch.Generator().manual_seed(1)) * 0.1
+    wav = proc(raw, return_tensors="pt", sampling_rate=16000)["input_values"]
+    got = enc(wav).last_hidden_state
+    want = OW.forward(sd, wav, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.num_conv_pos_embedding_groups,
+                      cfg.conv_stride, cfg.layer_norm_eps)
+    assert ((got - want).norm() / want.norm()).item() < 2e-2
+    with pytest.raises(FileNotFoundError):
+        (d / "model.safetensors").unlink()
+        checkpoints.load_audio_encoder(str(d), device="cpu")
