@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 7
+#define VX_ABI_VERSION 8
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
@@ -155,6 +155,15 @@ int vx_gather_latents(const float* latents, int c, int total_frames, int hw, con
  * [2f, hw, ld] float32 (rows: uncond frames then cond frames).  pipelines/v_express_pipeline.py:548-550. */
 int vx_cfg_combine(const float* unet_out, int ld, int c, int f, int hw, float guidance, float* pred_slot,
                    void* stream);
+/* Multi-GPU exchange of a timestep's predictions (one process per GPU).  vx_pack_rows: the first c
+ * channels of the conv_out result float32 [rows, ld] densely packed into this rank's send slots [rows, c].
+ * vx_combine_units: the all-gathered buffer float32 [units_total, (f / shards) * hw, c] -> CFG-combined predictions
+ * float32 [n_windows, c, f, hw] = u + s (c - u) for every window in one launch; unit_index: int32
+ * [n_windows][halves][shards] = which unit buffer holds frame shard j of (window, CFG half); halves == 1 (no
+ * classifier-free guidance) copies the prediction.  pipelines/v_express_pipeline.py:548-550. */
+int vx_pack_rows(const float* src, int ld, int64_t rows, int c, float* dst, void* stream);
+int vx_combine_units(const float* gathered, const int32_t* unit_index, int n_windows, int halves, int shards, int c,
+                     int f, int hw, float guidance, float* preds, void* stream);
 /* per-frame mean-overlap + DDIM v-prediction step (eta=0):  v = sum_t (pred[term_slot[t]] / count) ;
  * latents[:, :, frame] = step(v).  terms: int32 [n_frames][max_terms][2] = (window slot, latent idx) or -1.
  * pipelines/v_express_pipeline.py:552-572 + diffusers DDIMScheduler.step.  */

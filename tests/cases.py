@@ -27,6 +27,11 @@ PIPELINE_CASES = {
 NOCFG_CASE = ("nocfg_F10_c4o2", 10, 4, 2, 3)          # name, F, context_frames, context_overlap, steps
 
 
+# BASELINE.json configs[1] through the reference itself (make_golden.py fullsize): F, ctx frames, overlap, steps
+FULLSIZE_CASE = (16, 16, 4, 25)
+FULLSIZE_FRAMES = (0, 15)                             # decoded 512x512 frames kept in the golden file
+
+
 def cond_only(inp):
     """The conditional half of synthetic_inputs' CFG pairs (what the prologue hooks return without CFG)."""
     return dict(inp, kps_features=inp["kps_features"][1:], audio_embeddings=inp["audio_embeddings"][1:])

@@ -29,9 +29,10 @@ def emulate_kernels():
     vae.AutoencoderKLDecoder._need_gpu = lambda self: None
 
 
-def run(F, cf, co, steps, frame_shards, latent=16, device="cuda"):
-    from v_express_amd import (AutoencoderKLDecoder, DDIMScheduler, ReferenceAttentionControl, UNet2DConditionModel,
-                               UNet3DConditionModel, VExpressPipeline, ops, synth)
+def build_pipeline(device):
+    """The small-config pipeline (UNet3D + ReferenceNet + VAE decoder, seeded synthetic weights)."""
+    from v_express_amd import (AutoencoderKLDecoder, DDIMScheduler, UNet2DConditionModel, UNet3DConditionModel,
+                               VExpressPipeline, synth)
     cfg = cases.unet_cfg(cases.SMALL)
     vcfg = synth.VaeConfig(**cases.SMALL_VAE)
     unet = UNet3DConditionModel(cfg).to(device)
@@ -43,7 +44,19 @@ def run(F, cf, co, steps, frame_shards, latent=16, device="cuda"):
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
                           steps_offset=1, prediction_type="v_prediction", rescale_betas_zero_snr=True,
                           timestep_spacing="trailing")
-    pipe = VExpressPipeline(vae=vae, reference_net=refnet, denoising_unet=unet, scheduler=sched)
+    return VExpressPipeline(vae=vae, reference_net=refnet, denoising_unet=unet, scheduler=sched)
+
+
+def run(F, cf, co, steps, frame_shards, latent=16, device="cuda"):
+    from v_express_amd import ReferenceAttentionControl, ops, synth
+    cfg = cases.unet_cfg(cases.SMALL)
+    pipe = build_pipeline(device)
+    unet, refnet, sched = pipe.denoising_unet, pipe.reference_net, pipe.scheduler
+    return _run(pipe, unet, refnet, sched, cfg, F, cf, co, steps, frame_shards, latent, device)
+
+
+def _run(pipe, unet, refnet, sched, cfg, F, cf, co, steps, frame_shards, latent, device):
+    from v_express_amd import ReferenceAttentionControl, ops, synth
     pipe.frame_shards = frame_shards or None
     inp = synth.synthetic_inputs(cfg, F, latent, latent)
     if device != "cuda":

@@ -195,6 +195,21 @@ def cfg_combine(unet_out, c, f, hw, guidance, pred_slot):
     pred_slot.copy_((u + guidance * (cnd - u)).reshape(f, hw, c).permute(2, 0, 1))
 
 
+def pack_rows(src, c, dst):
+    dst.view(-1, c).copy_(src[:, :c])
+
+
+def combine_units(gathered, unit_index, c, f, hw, guidance, preds):
+    nW, halves, S = unit_index.shape
+    f_loc = f // S
+    g = gathered.reshape(-1, f_loc * hw, c)
+    for wi in range(nW):
+        h = [torch.cat([g[int(unit_index[wi, hh, j])] for j in range(S)], dim=0) for hh in range(halves)]   # [f*hw, c]
+        u, cnd = h[0].double(), h[-1].double()
+        r = u + guidance * (cnd - u)
+        preds[wi].copy_(r.view(f, hw, c).permute(2, 0, 1))
+
+
 def overlap_ddim_step(latents, preds, terms, frame_ids, counts, coef):
     sa, s1a, sap, s1ap = (float(v) for v in coef)
     _, c, _, h, w = latents.shape
@@ -229,7 +244,7 @@ def vae_postprocess(x, n, c, h, w):
 
 
 ALL = ("wave_conv1d", "groupnorm", "layernorm", "gemm", "geglu", "alloc_vt", "gemm_split", "key_norm_max", "attention",
-       "temporal_attention", "small_kv_attention", "add_row_bias", "gather_latents", "cfg_combine", "overlap_ddim_step",
+       "temporal_attention", "small_kv_attention", "add_row_bias", "gather_latents", "cfg_combine", "pack_rows", "combine_units", "overlap_ddim_step",
        "ncfhw_to_nhwc", "nhwc_to_ncfhw", "vae_postprocess")
 
 

@@ -85,6 +85,62 @@ def nocfg(out):
     print(name, video.shape, float(video.mean()))
 
 
+def fullsize(out):
+    """BASELINE.json configs[1] through the reference ITSELF: SD-1.5 widths, 64x64 latents (512x512), one 16-frame
+    window (context 16 / overlap 4), CFG 3.5, 25 DDIM steps, sd-vae-ft-mse-shaped decode - the reference's own
+    `VExpressPipeline.__call__` loop (pipelines/v_express_pipeline.py:526-589) and `decode_latents` (:152-166) on the
+    seeded synthetic weights, fp32 on the host cores (~35-40 min on 8 idle cores).  Stores the first UNet prediction,
+    the latents after steps 0 / 4 / 12 / 24 (= final) and two decoded frames.  Resumable: the latents after every step
+    go to a scratch checkpoint; a restart continues through the reference's own `strength` path (get_timesteps,
+    :334-341), which starts the same loop at a later timestep."""
+    import time
+    import types
+    cfg = cases.unet_cfg(cases.FULL)
+    unet, refnet = H.build_reference_unets(cfg)
+    vae = H.build_reference_vae(synth.VaeConfig())
+    F, cf, co, steps = cases.FULLSIZE_CASE
+    inp = synth.synthetic_inputs(cfg, F, 64, 64)
+    ckpt_path = os.path.join(os.path.dirname(HERE), "gpurun_out", "fullsize_ckpt.pt")
+    ck = torch.load(ckpt_path, weights_only=False) if os.path.exists(ckpt_path) else dict(done=0, keep={}, secs=0.0)
+    orig = unet.forward
+
+    def spy(*a, **k):
+        o = orig(*a, **k)
+        if "pred_step0" not in ck["keep"]:
+            ck["keep"]["pred_step0"] = (o[0] if isinstance(o, tuple) else o.sample).clone()
+        return o
+    unet.forward = spy
+    base = ck["done"]
+    t_last = [time.time()]
+
+    def on_step(i, t, lat):
+        g = base + i
+        if g in (0, 4, 12, steps - 1):
+            ck["keep"]["latents" if g == steps - 1 else f"latents_step{g}"] = lat.clone()
+        ck["done"], ck["last"] = g + 1, lat.clone()
+        ck["secs"] += time.time() - t_last[0]
+        t_last[0] = time.time()
+        os.makedirs(os.path.dirname(ckpt_path), exist_ok=True)
+        torch.save(ck, ckpt_path + ".tmp")
+        os.replace(ckpt_path + ".tmp", ckpt_path)
+        print(f"step {g} t={int(t)} done ({ck['secs']:.0f} s so far)", flush=True)
+    if base < steps:
+        H.reference_pipeline_run(unet, refnet, vae, inp, F, steps, cases.GUIDANCE, cf, co, cases.W_REF, cases.W_AUD,
+                                 512, 512, decode=False, strength=(steps - base + 0.5) / steps,
+                                 start_latents=ck.get("last"), on_step=on_step)
+    g = dict(ck["keep"], loop_seconds=ck["secs"], threads=torch.get_num_threads())
+    # decode_latents as the reference does it (v_express_pipeline.py:152-166), two frames kept
+    _, pipelines = __import__("ref_import").import_reference()
+    t0 = time.time()
+    keep = list(cases.FULLSIZE_FRAMES)
+    video = pipelines.VExpressPipeline.decode_latents(types.SimpleNamespace(vae=vae), g["latents"][:, :, keep])
+    g["decode_seconds_per_frame"] = (time.time() - t0) / len(keep)
+    g["video_frames"] = keep
+    g["video_f16"] = video.to(torch.float16)
+    torch.save(g, os.path.join(out, "fullsize_F16_512.pt"))
+    print("fullsize", {k: (tuple(v.shape) if hasattr(v, "shape") else v) for k, v in g.items()})
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     out = os.path.join(HERE, "golden")
@@ -95,6 +151,8 @@ def main():
         return wav2vec2(out)
     if len(sys.argv) > 1 and sys.argv[1] == "nocfg":
         return nocfg(out)
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize":      # ~40 min; not part of the default regeneration
+        return fullsize(out)
     prologue(out)
     wav2vec2(out)
     built = {}

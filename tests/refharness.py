@@ -65,7 +65,8 @@ def reference_unet_forward(unet, refnet, inputs, t, w_ref, w_aud, frames=None):
 
 @torch.no_grad()
 def reference_pipeline_run(unet, refnet, vae, inputs, num_frames, steps, guidance, ctx_frames, ctx_overlap,
-                           w_ref, w_aud, height, width, decode=True):
+                           w_ref, w_aud, height, width, decode=True, strength=1.0, start_latents=None,
+                           on_step=None):
     """Run the reference's own VExpressPipeline.mean_overlap loop (+decode_latents) unmodified; only the
     out-of-scope prologue (VAE-encode of the reference image, kps guider, wav2vec2/audio projection —
     SURVEY.md §2 rows 13-15) is replaced by the synthetic tensors."""
@@ -78,7 +79,9 @@ def reference_pipeline_run(unet, refnet, vae, inputs, num_frames, steps, guidanc
     pipe.prepare_reference_latent = lambda *a, **k: inputs["ref_latents"]
     pipe.prepare_kps_feature = lambda *a, **k: inputs["kps_features"]
     pipe.prepare_audio_embeddings = lambda *a, **k: inputs["audio_embeddings"]
-    lat0 = inputs["latents"]
+    # strength < 1 makes the reference's own get_timesteps (:334-341) start at a later timestep: with `start_latents` =
+    # the latents after step k-1 this resumes an interrupted run bit-identically (every step is deterministic)
+    lat0 = inputs["latents"] if start_latents is None else start_latents
     pipe.prepare_latents = lambda *a, **k: lat0.clone()
     trace = []
     if not decode:
@@ -87,5 +90,6 @@ def reference_pipeline_run(unet, refnet, vae, inputs, num_frames, steps, guidanc
                  video_length=num_frames, num_inference_steps=steps, guidance_scale=guidance,
                  context_frames=ctx_frames, context_overlap=ctx_overlap, reference_attention_weight=w_ref,
                  audio_attention_weight=w_aud,
-                 callback=lambda i, t, l: trace.append(l.clone()))
+                 strength=strength,
+                 callback=lambda i, t, l: (trace.append(l.clone()), on_step and on_step(i, t, l)))
     return video, trace

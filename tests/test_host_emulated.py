@@ -268,3 +268,42 @@ def test_merging_windows_into_one_unet_call_changes_nothing(emulated):
     finally:
         vx.VExpressPipeline.__init__ = orig
     assert torch.equal(got, ref)
+
+
+def _call_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.set_num_threads(2)
+    torch.manual_seed(1000 + rank)                 # every rank's default generator differs, as in a real launch
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W.emulate_kernels()
+    from v_express_amd import synth
+    pipe = W.build_pipeline("cpu")
+    cfg = cases.unet_cfg(cases.SMALL)
+    F_ = 6
+    inp = synth.synthetic_inputs(cfg, F_, 8, 8)
+    lat = pipe(None, None, None, 64, 64, F_, 2, cases.GUIDANCE, context_frames=4, context_overlap=2,
+               reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD, generator=None,
+               reference_latents=inp["ref_latents"], kps_features=inp["kps_features"],
+               audio_embeddings=inp["audio_embeddings"], decode=False)
+    q.put((rank, lat.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_call_without_generator_gives_every_rank_the_same_clip():
+    """with generator=None every rank draws its own noise; `__call__` must broadcast rank 0's draw, or the
+    per-step all-gather mixes predictions of different clips.  Two gloo ranks, different default-generator seeds."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_call_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert torch.isfinite(results[0]).all() and torch.equal(results[0], results[1])

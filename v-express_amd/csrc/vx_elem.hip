@@ -45,6 +45,38 @@ __global__ void cfg_combine_kernel(const float* unet_out, int ld, int c, int f, 
   for (int ch = 0; ch < c; ++ch) pred_slot[(size_t)ch * f * hw + idx] = u[ch] + guidance * (cnd[ch] - u[ch]);
 }
 
+// conv_out result fp32 [rows, ld] -> the first c channels densely packed [rows, c]: what one rank contributes to the
+// per-timestep exchange (the GEMM pads conv_out's 4 output channels to 8; only 4 travel)
+__global__ void pack_rows_kernel(const float* __restrict__ src, int ld, long rows, int c, float* __restrict__ dst) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (row, ch)
+  if (idx >= rows * c) return;
+  long r = idx / c;
+  int ch = (int)(idx - r * c);
+  dst[idx] = src[r * ld + ch];
+}
+
+// The all-gathered unit predictions [units_total, f_loc*hw, c] -> CFG-combined window predictions [nW, c, f, hw] in ONE
+// launch (replaces the per-slot copies + one cfg_combine per window).  unit_index: int32 [nW][halves][S] = index of the
+// unit buffer holding frame shard j of (window, CFG half).  halves == 1: the prediction itself (no guidance, :548-550
+// skipped: u + 1 * (u - u) is exactly u).
+__global__ void combine_units_kernel(const float* __restrict__ gathered, const int32_t* __restrict__ unit_index,
+                                     int n_windows, int halves, int shards, int c, int f, int f_loc, int hw,
+                                     float guidance, float* __restrict__ preds) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (window, li, pixel)
+  long total = (long)n_windows * f * hw;
+  if (idx >= total) return;
+  int px = (int)(idx % hw);
+  int li = (int)((idx / hw) % f);
+  int wi = (int)(idx / ((long)hw * f));
+  int j = li / f_loc;
+  long row = (long)(li - j * f_loc) * hw + px;
+  long unit_sz = (long)f_loc * hw * c;
+  const float* u = gathered + unit_index[(wi * halves + 0) * shards + j] * unit_sz + row * c;
+  const float* cnd = halves > 1 ? gathered + unit_index[(wi * halves + 1) * shards + j] * unit_sz + row * c : u;
+  for (int ch = 0; ch < c; ++ch)
+    preds[(((size_t)wi * c + ch) * f + li) * hw + px] = u[ch] + guidance * (cnd[ch] - u[ch]);
+}
+
 __global__ void overlap_ddim_kernel(float* latents, int c, int total_frames, int hw, const float* preds, int f_window,
                                     const int32_t* terms, int max_terms, const int32_t* frame_ids,
                                     const float* count, int n_frames, float sqrt_a, float sqrt_1ma,
@@ -218,6 +250,23 @@ extern "C" int vx_cfg_combine(const float* unet_out, int ld, int c, int f, int h
   hipLaunchKernelGGL(cfg_combine_kernel, grid1d((long)f * hw), dim3(256), 0, (hipStream_t)stream, unet_out, ld, c, f,
                      hw, guidance, pred_slot);
   return vx_check_launch("vx_cfg_combine");
+}
+
+extern "C" int vx_pack_rows(const float* src, int ld, int64_t rows, int c, float* dst, void* stream) {
+  VX_REQUIRE(src && dst && rows > 0 && c > 0 && ld >= c, "vx_pack_rows: bad arguments");
+  hipLaunchKernelGGL(pack_rows_kernel, grid1d((long)rows * c), dim3(256), 0, (hipStream_t)stream, src, ld, (long)rows,
+                     c, dst);
+  return vx_check_launch("vx_pack_rows");
+}
+
+extern "C" int vx_combine_units(const float* gathered, const int32_t* unit_index, int n_windows, int halves,
+                                int shards, int c, int f, int hw, float guidance, float* preds, void* stream) {
+  VX_REQUIRE(gathered && unit_index && preds && n_windows > 0 && (halves == 1 || halves == 2) && shards > 0 && c > 0 &&
+                 f > 0 && hw > 0 && f % shards == 0,
+             "vx_combine_units: bad arguments");
+  hipLaunchKernelGGL(combine_units_kernel, grid1d((long)n_windows * f * hw), dim3(256), 0, (hipStream_t)stream,
+                     gathered, unit_index, n_windows, halves, shards, c, f, f / shards, hw, guidance, preds);
+  return vx_check_launch("vx_combine_units");
 }
 
 extern "C" int vx_overlap_ddim_step(float* latents, int c, int total_frames, int hw, const float* preds, int f_window,

@@ -116,6 +116,18 @@ class DistContext:
         dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1), group=self.group)
         return out
 
+    def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        """In-place broadcast from `src` (rank 0's noise draw becomes every rank's initial latents)."""
+        if not self.enabled:
+            return t
+        if t.is_cuda and dist.get_backend(self.group) != "nccl":
+            host = t.detach().cpu().contiguous()          # single-GPU control-flow testing over gloo
+            dist.broadcast(host, src=src, group=self.group)
+            t.copy_(host)
+            return t
+        dist.broadcast(t, src=src, group=self.group)
+        return t
+
     def all_gather_units(self, local: torch.Tensor, max_units: int) -> torch.Tensor:
         """local: [max_units, ...] (this rank's unit outputs, zero-padded) -> [world, max_units, ...]."""
         if not self.enabled:

@@ -92,6 +92,8 @@ def _load():
     lib.vx_add_row_bias.argtypes = [vp, i32, i32, i32, vp, f32, vp]
     lib.vx_gather_latents.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp]
     lib.vx_cfg_combine.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
+    lib.vx_pack_rows.argtypes = [vp, i32, i64, i32, vp, vp]
+    lib.vx_combine_units.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp]
     lib.vx_overlap_ddim_step.argtypes = [vp, i32, i32, i32, vp, i32, vp, i32, vp, vp, i32, f32, f32, f32, f32, vp]
     lib.vx_ncfhw_to_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     lib.vx_nhwc_to_ncfhw.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
@@ -104,7 +106,7 @@ def _load():
         if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name",
                         "vx_gemm_splitk_ws_bytes"):
             fn.restype = i32
-    if lib.vx_abi_version() != 7:
+    if lib.vx_abi_version() != 8:
         raise ImportError("libvexpress_hip.so ABI version mismatch")
     return lib
 

@@ -422,6 +422,25 @@ def cfg_combine(unet_out, c, f, hw, guidance, pred_slot):
                                 _stream()), "vx_cfg_combine")
 
 
+def pack_rows(src, c, dst):
+    """src fp32 [rows, ld] -> dst fp32 [rows, c] (dense): this rank's conv_out rows into its send slots."""
+    if src.dtype != torch.float32 or dst.dtype != torch.float32 or not dst.is_contiguous():
+        raise TypeError("pack_rows: float32 tensors, contiguous destination")
+    rows = src.shape[0]
+    if dst.numel() != rows * c:
+        raise ValueError("pack_rows: destination size mismatch")
+    L.check(_lib.vx_pack_rows(_ptr(src), src.stride(0), rows, c, _ptr(dst), _stream()), "vx_pack_rows")
+
+
+def combine_units(gathered, unit_index, c, f, hw, guidance, preds):
+    """gathered fp32 [units_total, (f/S)*hw, c]; unit_index int32 [nW, halves, S] -> preds fp32 [nW, c, f, hw]."""
+    nW, halves, S = unit_index.shape
+    if unit_index.dtype != torch.int32 or not unit_index.is_contiguous() or not gathered.is_contiguous():
+        raise TypeError("combine_units: contiguous int32 index / contiguous gathered buffer expected")
+    L.check(_lib.vx_combine_units(_ptr(gathered), _ptr(unit_index), nW, halves, S, c, f, hw, float(guidance),
+                                  _ptr(preds), _stream()), "vx_combine_units")
+
+
 def overlap_ddim_step(latents, preds, terms, frame_ids, counts, coef):
     """latents fp32 [1,C,F,h,w] updated in place for `frame_ids`; preds fp32 [slots, C, f, hw]."""
     _, c, F, h, w = latents.shape

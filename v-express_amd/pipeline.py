@@ -193,10 +193,17 @@ class VExpressPipeline:
         f_loc = f // S
         lo = (dc.rank % S) * f_loc                     # this rank's frames of every window it works on: [lo, lo+f_loc)
         my_slot = {u: sched_u.slot[u][1] for u in sched_u.slot}
-        n_out = 8
-        local = torch.zeros((max_units, f_loc * hw, n_out), device=dev, dtype=torch.float32)
+        # per-timestep exchange: only conv_out's C real channels travel (the GEMM pads them to 8); unit_index tells the
+        # combine kernel which gathered unit buffer holds frame shard j of (window, CFG half)
+        local = torch.zeros((max_units, f_loc * hw, C), device=dev, dtype=torch.float32)
         preds = torch.empty((nW, C, f, hw), device=dev, dtype=torch.float32)
-        pair = torch.empty((2 * f * hw, n_out), device=dev, dtype=torch.float32)
+        uidx = torch.empty((nW, halves_n, S), dtype=torch.int32)
+        for wi in range(nW):
+            for hlf in range(halves_n):
+                ranks, slot = sched_u.unit_ranks((wi, hlf))
+                for j, r in enumerate(ranks):
+                    uidx[wi, hlf, j] = r * max_units + slot
+        uidx = uidx.to(dev)
         # per-call constants (window ids, conditioning slices) do not depend on the timestep: build them once so
         # the timestep loop issues kernels only (no host->device copies, no syncs)
         # which CFG halves carry all-zero audio tokens (the unconditional half, :403-405): one device reduction per clip
@@ -237,20 +244,12 @@ class VExpressPipeline:
                 out = unet.forward_tokens(x_in, t, ehs, kps, b=len(rows), f=f_loc, H=H, W=W,
                                           batch_rows=[hlf for _, hlf in rows], audio_kv=akv,
                                           audio_zero=[audio_is_zero[hlf] for _, hlf in rows], frame_shard=shard)
-                for j, unit in enumerate(rows):
-                    local[my_slot[unit]].copy_(out[j * f_loc * hw:(j + 1) * f_loc * hw])
-            gathered = dc.all_gather_units(local, max_units)          # [world, max_units, (f/S)*hw, 8]
-            for wi in range(nW):
-                for hlf in range(halves_n):
-                    ranks, slot = sched_u.unit_ranks((wi, hlf))
-                    for j, r in enumerate(ranks):                    # frame shards in frame order
-                        base = (hlf * f + j * f_loc) * hw
-                        pair[base:base + f_loc * hw].copy_(gathered[r, slot])
-                if do_cfg:
-                    ops.cfg_combine(pair, C, f, hw, guidance_scale, preds[wi])
-                else:                                                # :548-550 skipped: u + 1 * (c - u) with u = c, exactly c
-                    pair[f * hw:].copy_(pair[:f * hw])
-                    ops.cfg_combine(pair, C, f, hw, 1.0, preds[wi])
+                # a call's units occupy consecutive send slots, in row order: one strided pack per call
+                s0 = my_slot[rows[0]]
+                ops.pack_rows(out, C, local[s0:s0 + len(rows)])
+            gathered = dc.all_gather_units(local, max_units)          # [world, max_units, (f/S)*hw, C]
+            # CFG combine of every window in one launch (:548-550; without CFG the prediction itself)
+            ops.combine_units(gathered, uidx, C, f, hw, guidance_scale if do_cfg else 1.0, preds)
             ops.overlap_ddim_step(latents, preds, terms, frame_ids, counts, self.scheduler.step_coefficients(t))
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, latents)
@@ -320,6 +319,10 @@ class VExpressPipeline:
         reader.update(writer, do_cfg, dtype=self.dtype)
         lat = self.prepare_latents(num_images_per_prompt, self.denoising_unet.in_channels, width, height,
                                    video_length, self.dtype, dev, generator, latents)
+        if self.dist.enabled and latents is None:
+            # every rank drew from its own CPU generator; the loop needs identical step-start latents on all ranks
+            # (each rank's UNet inputs are gathered from them and every rank applies the DDIM update): rank 0's draw wins
+            lat = self.dist.broadcast(lat.contiguous(), src=0)
         if kps_tokens is None:
             b2, c0, F, h, w = kps_features.shape
             kps_tokens = ops.ncfhw_to_nhwc(kps_features.to(dev), c0).view(b2, F, h * w, c0)
