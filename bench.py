@@ -9,18 +9,25 @@ mean-overlap loop (CFG UNet3D forwards + fused CFG/overlap/DDIM update) followed
 every frame.  Inputs (latents, kps features, audio embeddings, reference banks) are resident in HBM when the
 timed region starts; the once-per-clip prologue (ReferenceNet + bank K/V precompute) is timed separately.
 
-Workload: N=1 is BASELINE.json configs[1] (16 frames = one 16-frame window).  N>1 is weak scaling: F = 12*N + 4
-frames = N windows of 16 with overlap 4, i.e. one window (both CFG halves) per GPU per DDIM step, latents
-exchanged by one RCCL all-gather per step; the decode is split over the ranks.  value = F*K / max-over-ranks time.
+Workload: N=1 is BASELINE.json configs[1] (16 frames = one 16-frame window).  N>1 defaults to BASELINE configs[3]
+("strong" scaling, the north-star multi-GPU number): the F = 124 clip inference.py:255-264 makes of a 128-frame
+request = 10 windows of 16 / overlap 4 = 20 (window, CFG-half) units sharded over the N ranks, one RCCL all-gather of
+the 4-channel predictions per DDIM step, decode split over the ranks; rank 0 then also runs the SAME clip alone
+(`same_clip_1gpu_fps`) so that the multi-GPU speed-up is a ratio of like with like.  `--scaling weak` keeps round 1's
+F = 12*N + 4 (one window per GPU per step).  value = F*K / max-over-ranks time.
+`python bench.py --gpus N` without a torchrun environment re-launches itself under torch.distributed.run with N ranks
+(one per GPU, RCCL); a world size that differs from --gpus is an error.
 
 Extra objects in the JSON line:
   roofline      dominant kernel = the MFMA GEMM / implicit-conv kernel (bound "mfma"): algorithmic FLOPs of every
                 vx_gemm launch (2*M*N*K) / its HIP-event duration, measured on ONE extra instrumented DDIM step after
                 the timed region (events on the launch stream); `whole_path` = fps * algorithmic FLOP per frame
                 (66.4 TFLOP/frame at F=16) / peak.
-  cpu_baseline  the fp32 oracle (port of the reference path) on the host cores (thread count picked by a 1-second probe):
-                one CFG UNet3D forward at 512^2 with a 2-frame window + one frame of VAE decode (a bounded ~10-30 s
-                sample), extrapolated linearly (x8 windows-worth of frames, x25 steps, x16 frames of decode).
+  cpu_baseline  the fp32 oracle (port of the reference path) on the host cores (thread count picked by probing the three
+                op classes of the UNet itself: conv, linear, SDPA): one CFG UNet3D forward at 512^2 with a 4-frame
+                window + one frame of VAE decode (a bounded sample), extrapolated linearly (x4 frames - the
+                reference's own modules scale 18.1 s -> 78.1 s from f=4 to f=16, SURVEY.md E6 - x25 steps, x16 frames
+                of decode).  The reference-module figure of SURVEY.md E6 is printed beside it.
 """
 import argparse
 import json
@@ -73,19 +80,29 @@ def _pmc_traffic(kernel_key):
 
 
 def _pick_threads():
-    """Thread count for the CPU leg: the fastest of a few candidates on a 1-second conv probe (a 256-thread box
-    runs the fp32 oracle several times SLOWER with all hardware threads than with one thread per few cores)."""
+    """Thread count for the CPU leg: the fastest of a few candidates on a probe made of the UNet's own three op classes
+    at the 64x64 level (3x3 conv, short-K linear, 4096-token SDPA with d = 40) - a 256-thread box runs the fp32 oracle
+    several times SLOWER with all hardware threads than with one thread per few cores, and a conv-only probe picked
+    counts that were wrong for the attention half of the forward."""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cands = sorted({c for c in (8, 16, 32, 64, 128, avail) if c <= avail} or {avail})
-    x = torch.randn(2, 320, 64, 64)
+    F = torch.nn.functional
+    x = torch.randn(4, 320, 64, 64)
     wt = torch.randn(320, 320, 3, 3)
+    tok = torch.randn(4 * 4096, 320)
+    wl = torch.randn(2560, 320)
+    q = torch.randn(4, 8, 4096, 40)
+
+    def probe():
+        F.conv2d(x, wt, padding=1)
+        F.linear(tok, wl)
+        F.scaled_dot_product_attention(q, q, q)
     best, best_t = cands[0], float("inf")
     for c in cands:
         torch.set_num_threads(c)
-        torch.nn.functional.conv2d(x, wt, padding=1)
+        probe()
         t0 = time.time()
-        for _ in range(3):
-            torch.nn.functional.conv2d(x, wt, padding=1)
+        probe()
         dt = time.time() - t0
         if dt < best_t:
             best, best_t = c, dt
@@ -102,7 +119,7 @@ def cpu_baseline(size, seconds_budget):
     torch.set_num_threads(threads)
     cfg, ocfg = synth.UNetConfig(), oracle.UNetConfig()
     h = w = size // 8
-    f = 2
+    f = 4
     t0 = time.time()
     sd3 = synth.unet3d_state_dict(cfg)
     inp = synth.synthetic_inputs(cfg, f, h, w)
@@ -144,7 +161,11 @@ def cpu_baseline(size, seconds_budget):
                 sample=(f"oracle fp32: 1 CFG UNet3D forward {size}x{size} f={f} ({unet_s:.1f} s) + 1 frame VAE decode "
                         f"({vae_s:.1f} s) on {torch.get_num_threads()} threads; extrapolated x(16/{f}) frames x25 "
                         f"steps + x16 frames = {clip_s:.0f} s per 16-frame clip"),
-                unet_forward_s=unet_s, vae_frame_s=vae_s)
+                unet_forward_s=unet_s, vae_frame_s=vae_s,
+                reference_modules_dev_container=dict(
+                    value=16.0 / (25 * 78.1 + 16 * 5.5), cores=8, unet_forward_s=78.1,
+                    note="SURVEY.md E6: the reference's own modules (fp32, f=16 CFG forward) on the 8 cores of the dev "
+                         "container, measured once during the survey; not re-measured on the GPU box"))
 
 
 def main():
@@ -154,11 +175,29 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=25)
-    ap.add_argument("--frames", type=int, default=0, help="override the clip length (default 12*gpus+4)")
+    ap.add_argument("--frames", type=int, default=0, help="override the clip length")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N>1: strong = the F=124 clip of BASELINE configs[3] for every N; weak = F = 12*N+4")
+    ap.add_argument("--no-same-clip-1gpu", action="store_true",
+                    help="N>1: skip rank 0's single-GPU run of the same clip after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-shapes", default="", help="write the per-shape vx_gemm timing table of the roofline leg here")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: become N ranks (one per GPU) under torch.distributed.run
+        have = torch.cuda.device_count()
+        if have < args.gpus and os.environ.get("VX_DIST_BACKEND", "nccl") == "nccl":
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible")
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,8 +214,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus})")
 
     import v_express_amd as vx
     from v_express_amd import ops, synth
@@ -184,7 +224,15 @@ def main():
 
     cfg, vcfg = synth.UNetConfig(), synth.VaeConfig()
     ctx, ovl = 16, 4
-    F = args.frames or (ctx - ovl) * world + ovl
+    if args.frames:
+        F = args.frames
+    elif world == 1:
+        F = ctx                                           # BASELINE configs[1]: one 16-frame window
+    elif args.scaling == "strong":
+        F = 124                                           # BASELINE configs[3]: inference.py:255-264 of a 128-frame request
+    else:
+        F = (ctx - ovl) * world + ovl
+    scaling = "weak" if (world > 1 and args.scaling == "weak" and not args.frames) else "strong"
     h = w = args.size // 8
     t_build = time.time()
     unet = vx.UNet3DConditionModel(cfg).to(dev)
@@ -258,7 +306,7 @@ def main():
     result = {
         "metric": f"decoded frames/sec at {args.size}x{args.size}, {args.ddim_steps} DDIM steps", "value": fps, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": (f"{args.size}x{args.size}, {F} frames ({len(windows)} window(s) of {ctx}, overlap {ovl}), "
                                 f"{args.ddim_steps} DDIM steps, CFG 3.5, random-init UNet3D + ReferenceNet banks + "
@@ -303,6 +351,20 @@ def main():
             "whole_path": {"tflop_per_frame": fpf, "achieved": fps * fpf / world, "frac": fps * fpf / world / PEAK_BF16_TFLOPS,
                            "note": "fps x algorithmic TFLOP/frame (SURVEY.md 8d) per GPU / 2.5 PFLOP/s"},
         }
+    if world > 1 and not args.no_same_clip_1gpu:
+        # the same clip on ONE GPU (rank 0 alone, sharding off) so that the multi-GPU speed-up compares like with like
+        if rank == 0:
+            from v_express_amd.distributed import DistContext
+            saved = pipe.dist
+            pipe.dist = DistContext()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            one_clip()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter() - t0
+            pipe.dist = saved
+            result["same_clip_1gpu_fps"] = F / t1
+            result["speedup_vs_1gpu_same_clip"] = fps / (F / t1)
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -307,3 +307,15 @@ def test_call_without_generator_gives_every_rank_the_same_clip():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert torch.isfinite(results[0]).all() and torch.equal(results[0], results[1])
+
+
+@pytest.mark.parametrize("layout", ["new_attn", "old_attn"])
+def test_checkpoint_files_load_into_identical_models_unets(emulated, tmp_path, layout):
+    """SURVEY.md 8f rank 4 on the CPU (emulated kernels): the bodies of tests/test_gpu_checkpoints.py."""
+    import ckpt_cases
+    ckpt_cases.unet_and_reference_net_from_files(tmp_path, layout, "cpu")
+
+
+def test_checkpoint_files_load_into_identical_models_vae_guider_projection(emulated, tmp_path):
+    import ckpt_cases
+    ckpt_cases.vae_guider_and_audio_projection_from_files(tmp_path, "cpu")

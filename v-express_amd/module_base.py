@@ -1,0 +1,124 @@
+"""torch.nn.Module-like surface shared by the v_express_amd model classes (they are not nn.Modules: weights live in
+kernel-specific device layouts).  What the reference's call sites use is here: `.to(device / dtype)`, `.device`,
+`.dtype`, `.eval()`, `.requires_grad_()`, `load_state_dict(sd, strict)`, `state_dict()`, `parameters()`
+(inference.py:77-129,150-163; pipelines/v_express_pipeline.py:345).
+
+Compute dtype: the gfx950 kernels store activations and weights in bf16 and accumulate in fp32 (MFMA
+v_mfma_f32_16x16x32_bf16).  `torch.float16` - the reference's default (`inference.py:44`) - is NOT implemented and is
+rejected instead of being silently replaced: run the reference entry point with `--dtype bf16` (inference.py:150-157).
+`torch.float32` is accepted as an I/O dtype only (outputs are returned in float32 anyway).
+"""
+from types import SimpleNamespace
+
+import torch
+
+_NO_FP16 = ("v_express_amd computes in bfloat16 (bf16 storage, fp32 accumulation on the gfx950 matrix cores); a float16 "
+            "compute path is not implemented.  Use torch.bfloat16 (reference CLI: --dtype bf16).")
+
+
+class DeviceModule:
+    """Base of every model class.  Subclasses keep raw (reference-layout) tensors in `_raw` and build their device
+    layouts lazily in `_prepared()`; `expected_keys()` (name -> shape) enables strict loading where it is defined."""
+
+    def __init__(self):
+        self._device = torch.device("cpu")
+        self._dtype = torch.bfloat16
+        self._raw = {}
+        self._P = None
+        self._released = False
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    def _invalidate(self):
+        self._P = None
+
+    def to(self, *args, **kwargs):
+        device = self._device
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.dtype):
+                if a == torch.float16:
+                    raise NotImplementedError(_NO_FP16)
+                if a not in (torch.bfloat16, torch.float32):
+                    raise TypeError(f"unsupported dtype {a}")
+                self._dtype = a
+            elif isinstance(a, (torch.device, str, int)):
+                device = torch.device("cuda", a) if isinstance(a, int) else torch.device(a)
+        if device != self._device:
+            if self._released:
+                raise RuntimeError("release_raw_weights() dropped the source-layout weights; this model can no longer "
+                                   "move to another device - load the state dict again first")
+            self._device = device
+            self._invalidate()           # device layouts are rebuilt on the new device at the next call
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", device) if device is not None else "cuda")
+
+    def half(self):
+        raise NotImplementedError(_NO_FP16)
+
+    def bfloat16(self):
+        return self.to(torch.bfloat16)
+
+    def eval(self):
+        return self
+
+    def train(self, mode=False):
+        if mode:
+            raise NotImplementedError("inference only")
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    # ---- weights
+    def expected_keys(self):
+        """{name: shape} of the reference module's state_dict, or None when the schema is open (VAE prefixes)."""
+        return None
+
+    def load_state_dict(self, state_dict, strict=True):
+        expected = self.expected_keys()
+        if expected is None:
+            self._raw.update({k: v.detach() for k, v in state_dict.items()})
+            missing, unexpected = [], []
+        else:
+            unexpected = [k for k in state_dict if k not in expected]
+            for k, v in state_dict.items():
+                if k in expected:
+                    if tuple(v.shape) != tuple(expected[k]):
+                        raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(v.shape)} from "
+                                           f"checkpoint, the shape in current model is {tuple(expected[k])}.")
+                    self._raw[k] = v.detach()
+            missing = [k for k in expected if k not in state_dict]
+            if strict and (missing or unexpected):
+                raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}: missing keys "
+                                   f"{missing[:5]}{'...' if len(missing) > 5 else ''}, unexpected keys "
+                                   f"{unexpected[:5]}{'...' if len(unexpected) > 5 else ''}")
+        self._released = False
+        self._invalidate()
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    def state_dict(self):
+        """The loaded tensors under the reference's key names (what `load_state_dict` received)."""
+        if self._released:
+            raise RuntimeError("release_raw_weights() dropped the source-layout weights")
+        return dict(self._raw)
+
+    def parameters(self):
+        return iter(self.state_dict().values())
+
+    def release_raw_weights(self):
+        """Drop the source-layout copies once the device layouts exist (frees host/device memory)."""
+        self._prepared()
+        self._raw = {}
+        self._released = True
+
+    def _need_gpu(self):
+        if self._device.type != "cuda":
+            raise RuntimeError("v_express_amd models run on an MI355X only: call .to('cuda') (no CPU path exists)")

@@ -150,6 +150,21 @@ _SPLITK_WS = {}
 _FRAME_ROWS = [None]
 
 
+def _stream_key(device):
+    """Persistent scratch buffers (split-K workspace, zero-bordered GroupNorm images) are reused stream-ordered: the
+    consumer of a buffer is enqueued before its next producer ON THE SAME STREAM.  Keying them by the current stream
+    keeps two streams (or two models driven from two streams) from sharing one; work on different streams that must
+    share data is the caller's to order with events, as for any torch tensor."""
+    return torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+
+
+def clear_caches():
+    """Free the persistent scratch buffers (they are re-created on demand).  Call between clips of different geometry
+    to return the memory: one zero-bordered image exists per distinct (frames, H, W, C) seen so far."""
+    _SPLITK_WS.clear()
+    _PADDED.clear()
+
+
 _ITEMS = [None]
 
 
@@ -196,7 +211,7 @@ def _splitk(p, geom, device, plain):
     if s < 2:
         return
     nbytes = int(_lib.vx_gemm_splitk_ws_bytes(p.m, p.n, s))
-    key = (device, nbytes)
+    key = (device, _stream_key(device), nbytes)
     ws = _SPLITK_WS.get(key)
     if ws is None:
         ws = _SPLITK_WS[key] = torch.empty(nbytes, device=device, dtype=torch.uint8)
@@ -294,7 +309,7 @@ def padded_buffer(device, frames, H, W, c):
     """Persistent zero-bordered NHWC image [frames, (H+2)*(W+2), c] per shape.  Only `groupnorm(pad_hw=...)` writes
     into it (interior pixels only), so the border stays zero for the life of the process; the one buffer per shape
     is reused stream-ordered (the conv that reads it is enqueued before the next GroupNorm that refills it)."""
-    key = (device, frames, H, W, c)
+    key = (device, _stream_key(device), frames, H, W, c)
     buf = _PADDED.get(key)
     if buf is None:
         buf = torch.zeros((frames, (H + 2) * (W + 2), c), device=device, dtype=BF16)

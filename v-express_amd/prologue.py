@@ -15,44 +15,22 @@ import torch
 from . import lib as L
 from . import ops
 from . import weights as Wt
+from .module_base import DeviceModule
 from .synth import AudioProjectionConfig, KpsGuiderConfig
 
 
-class _Module:
-    def __init__(self):
-        self._device = torch.device("cpu")
-        self._dtype = torch.bfloat16
-        self._raw = {}
-        self._P = None
+class _Module(DeviceModule):
+    """Prologue models load strictly like the reference does (inference.py:101,127): `_schema()` names the synth
+    generator of the reference module's state_dict, evaluated on the meta device for names and shapes."""
 
-    @property
-    def device(self):
-        return self._device
+    def _schema(self):
+        return None
 
-    @property
-    def dtype(self):
-        return self._dtype
-
-    def to(self, *args, **kwargs):
-        for a in list(args) + list(kwargs.values()):
-            if isinstance(a, torch.dtype):
-                self._dtype = a
-            elif isinstance(a, (torch.device, str)):
-                self._device = torch.device(a)
-        self._P = None
-        return self
-
-    def eval(self):
-        return self
-
-    def load_state_dict(self, sd, strict=True):
-        self._raw = {k: v.detach() for k, v in sd.items()}
-        self._P = None
-        return SimpleNamespace(missing_keys=[], unexpected_keys=[])
-
-    def _need_gpu(self):
-        if self._device.type != "cuda":
-            raise RuntimeError("v_express_amd models run on an MI355X only: call .to('cuda')")
+    def expected_keys(self):
+        if getattr(self, "_expected", None) is None:
+            sd = self._schema()
+            self._expected = None if sd is None else {k: tuple(v.shape) for k, v in sd.items()}
+        return self._expected
 
 
 class VKpsGuider(_Module):
@@ -63,6 +41,10 @@ class VKpsGuider(_Module):
                  block_out_channels=(16, 32, 96, 256)):
         super().__init__()
         self.cfg = KpsGuiderConfig(conditioning_embedding_channels, conditioning_channels, tuple(block_out_channels))
+
+    def _schema(self):
+        from . import synth
+        return synth.kps_guider_state_dict(self.cfg, device="meta")
 
     def _prepared(self):
         if self._P is None:
@@ -106,6 +88,10 @@ class AudioProjection(_Module):
             raise NotImplementedError("num_latents_mean_pooled > 0 is not used by V-Express (inference.py:116-126)")
         self.cfg = AudioProjectionConfig(dim, depth, dim_head, heads, num_queries, embedding_dim, output_dim, ff_mult,
                                          max_seq_len)
+
+    def _schema(self):
+        from . import synth
+        return synth.audio_projection_state_dict(self.cfg, device="meta")
 
     def _prepared(self):
         if self._P is None:

@@ -24,6 +24,7 @@ from . import blocks as B
 from . import lib as L
 from . import ops
 from . import weights as Wt
+from .module_base import DeviceModule
 from .synth import UNetConfig, block_plan
 
 
@@ -49,12 +50,13 @@ def _config_from_dict(d):
                       attn_levels=attn_levels)
 
 
-class _UNetBase:
+class _UNetBase(DeviceModule):
     """State shared by the denoising UNet and the ReferenceNet: config, raw/prepared weights, time embedding."""
 
     THREE_D = True
 
     def __init__(self, cfg: UNetConfig, config_dict=None):
+        super().__init__()
         self.cfg = cfg
         cd = dict(config_dict or {})
         cd.setdefault("cross_attention_dim", cfg.cross_attention_dim)
@@ -63,10 +65,6 @@ class _UNetBase:
         cd.setdefault("class_embed_type", None)
         self.config = SimpleNamespace(**cd)
         self.in_channels = cfg.in_channels
-        self._device = torch.device("cpu")
-        self._dtype = torch.bfloat16
-        self._raw = {}
-        self._P = None
         self._expected = None
         self._temb_cache = {}
         # installed by ReferenceAttentionControl
@@ -75,32 +73,6 @@ class _UNetBase:
         self.audio_attention_weight = 1.0
         self.banks = {}
 
-    # ---- torch-module-like surface
-    @property
-    def device(self):
-        return self._device
-
-    @property
-    def dtype(self):
-        return self._dtype
-
-    def to(self, *args, **kwargs):
-        for a in list(args) + list(kwargs.values()):
-            if isinstance(a, torch.dtype):
-                if a not in (torch.bfloat16, torch.float16, torch.float32):
-                    raise TypeError(a)
-                self._dtype = a        # I/O dtype only: the kernels compute in bf16 with fp32 accumulation
-            elif isinstance(a, (torch.device, str)):
-                self._device = torch.device(a)
-        self._P = None
-        return self
-
-    def eval(self):
-        return self
-
-    def requires_grad_(self, flag=False):
-        return self
-
     def expected_keys(self):
         if self._expected is None:
             from . import synth
@@ -108,20 +80,9 @@ class _UNetBase:
             self._expected = {k: tuple(v.shape) for k, v in sd.items()}
         return self._expected
 
-    def load_state_dict(self, state_dict, strict=True):
-        expected = self.expected_keys()
-        unexpected = [k for k in state_dict if k not in expected]
-        for k, v in state_dict.items():
-            if k in expected:
-                if tuple(v.shape) != expected[k]:
-                    raise RuntimeError(f"size mismatch for {k}: {tuple(v.shape)} vs {expected[k]}")
-                self._raw[k] = v.detach()
-        missing = [k for k in expected if k not in state_dict]
-        if strict and (missing or unexpected):
-            raise RuntimeError(f"load_state_dict(strict=True): missing {missing[:5]}… unexpected {unexpected[:5]}…")
+    def _invalidate(self):
         self._P = None
         self._temb_cache.clear()
-        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
 
     def init_random(self, seed=42):
         """Random-init weights with the reference schema (no checkpoints exist offline)."""
@@ -129,10 +90,6 @@ class _UNetBase:
         gen = synth.unet3d_state_dict if self.THREE_D else synth.refnet_state_dict
         self.load_state_dict(gen(self.cfg, seed=seed), strict=True)
         return self
-
-    def _need_gpu(self):
-        if self._device.type != "cuda":
-            raise RuntimeError("v_express_amd models run on an MI355X only: call .to('cuda') (no CPU path exists)")
 
     # ---- weight preparation
     def _prepared(self):
@@ -185,11 +142,6 @@ class _UNetBase:
         self._P = P
         self._temb_cache.clear()
         return P
-
-    def release_raw_weights(self):
-        """Drop the source-layout copies once the device layouts exist (frees host/device memory)."""
-        self._prepared()
-        self._raw = {}
 
     # ---- time embedding: Timesteps + TimestepEmbedding (modules/unet_3d.py:464-470) and all 22
     #      ResnetBlock3D.time_emb_proj(silu(emb)) rows (modules/resnet.py:225-233), once per timestep value

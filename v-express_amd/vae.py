@@ -14,60 +14,38 @@ import torch
 from . import blocks as B
 from . import ops
 from . import weights as Wt
+from .module_base import DeviceModule
 from .synth import VaeConfig
 
 
-class AutoencoderKLDecoder:
+class AutoencoderKLDecoder(DeviceModule):
     """Decoder half of AutoencoderKL with the reference's `vae.decode(z).sample` / `vae.config` surface."""
 
     def __init__(self, cfg: VaeConfig = None):
+        super().__init__()
         self.cfg = cfg or VaeConfig()
         self.config = SimpleNamespace(block_out_channels=tuple(self.cfg.block_out_channels),
                                       scaling_factor=self.cfg.scaling_factor,
                                       latent_channels=self.cfg.latent_channels)
-        self._device = torch.device("cpu")
-        self._dtype = torch.bfloat16
-        self._raw = {}
-        self._P = None
         self._PE = None
 
-    @property
-    def device(self):
-        return self._device
-
-    @property
-    def dtype(self):
-        return self._dtype
-
-    def to(self, *args, **kwargs):
-        for a in list(args) + list(kwargs.values()):
-            if isinstance(a, torch.dtype):
-                self._dtype = a
-            elif isinstance(a, (torch.device, str)):
-                self._device = torch.device(a)
+    def _invalidate(self):
         self._P = None
-        return self
-
-    def eval(self):
-        return self
+        self._PE = None
 
     _PREFIXES = ("decoder.", "post_quant_conv.")
 
     def load_state_dict(self, sd, strict=False):
         keep = {k: v.detach() for k, v in sd.items() if k.startswith(self._PREFIXES)}
         self._raw.update(keep)
-        self._P = None
-        self._PE = None
+        self._released = False
+        self._invalidate()
         return SimpleNamespace(missing_keys=[], unexpected_keys=[k for k in sd if k not in keep])
 
     def init_random(self, seed=44):
         from . import synth
         self.load_state_dict(synth.vae_decoder_state_dict(self.cfg, seed=seed))
         return self
-
-    def _need_gpu(self):
-        if self._device.type != "cuda":
-            raise RuntimeError("v_express_amd models run on an MI355X only: call .to('cuda')")
 
     def _prepared(self):
         if self._P is not None:

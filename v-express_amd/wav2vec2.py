@@ -82,24 +82,36 @@ class Wav2Vec2Model(_Module):
         model.load_state_dict(sd)
         return model.to(dtype=dtype, device=device)
 
+    def _schema(self):
+        from . import synth
+        sd = synth.wav2vec2_state_dict(self.cfg, device="meta")
+        sd.pop("masked_spec_embed", None)                      # training-time SpecAugment vector: never read
+        return sd
+
     def load_state_dict(self, sd, strict=True):
+        """Accepts the three spellings of the weight-normalised positional conv that transformers / torch versions
+        have written (`weight_g`/`weight_v`, `parametrizations.weight.original0/1`, or a plain materialised `weight`)
+        and stores the parametrized form."""
         out = {}
+        pc = "encoder.pos_conv_embed.conv."
         for k, v in sd.items():
             k = k[len("wav2vec2."):] if k.startswith("wav2vec2.") else k
-            if k.startswith(("lm_head.", "quantizer.", "project_q.", "project_hid.")):
+            if k.startswith(("lm_head.", "quantizer.", "project_q.", "project_hid.")) or k == "masked_spec_embed":
                 continue
+            if k == pc + "weight_g":
+                k = pc + "parametrizations.weight.original0"
+            elif k == pc + "weight_v":
+                k = pc + "parametrizations.weight.original1"
+            elif k == pc + "weight":
+                out[pc + "parametrizations.weight.original0"] = v.float().norm(dim=(0, 1), keepdim=True).to(v.dtype)
+                k = pc + "parametrizations.weight.original1"
             out[k] = v
         return super().load_state_dict(out, strict)
 
     # ------------------------------------------------------------------ weights
     def _pos_conv_weight(self):
         sd, p = self._raw, "encoder.pos_conv_embed.conv."
-        if p + "weight" in sd:
-            return sd[p + "weight"].float()
-        if p + "parametrizations.weight.original0" in sd:
-            g, v = sd[p + "parametrizations.weight.original0"], sd[p + "parametrizations.weight.original1"]
-        else:
-            g, v = sd[p + "weight_g"], sd[p + "weight_v"]
+        g, v = sd[p + "parametrizations.weight.original0"], sd[p + "parametrizations.weight.original1"]
         g, v = g.float(), v.float()
         return g * v / v.norm(dim=(0, 1), keepdim=True)            # weight_norm(dim=2): one norm per tap
 
