@@ -81,6 +81,14 @@ typedef struct {
    * 0 = automatic (ring when eligible and the launch has >= 192 tiles), 1 = ring whenever structurally eligible,
    * -1 = never. */
   int32_t ring_hint;
+  /* FP8 operands (BASELINE.json configs[4]: "fp8 MFMA QKV/out-proj"): a_fp8 = 1 -> a and w hold OCP e4m3 bytes
+   * (v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, fp32 accumulation), row-scaled: the true operands are
+   * a[m, :] * a_scale[m] and w[n, :] * w_scale[n], so out = epilogue(acc * a_scale[m] * w_scale[n]).  Plain linears
+   * only (kh = kw = 1, one source, no padding / upsampling / split-K); k, lda1 count fp8 elements and must be multiples
+   * of 128 / 16 (vx_layernorm_fp8 pads K with zeros); STORE and SPLIT epilogues. */
+  int32_t a_fp8;
+  const float* a_scale;      /* [m] */
+  const float* w_scale;      /* [n] */
 } vx_gemm_params;
 
 int vx_gemm(const vx_gemm_params* p, void* stream);
@@ -112,6 +120,16 @@ int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int frames, int
  * out[r, :] = LN(x[r, :]) * gamma + beta + (add ? add[(r / add_rows_per_entry) % add_entries, :] : 0). */
 int vx_layernorm(const void* x, int ldx, int rows, int c, float eps, const float* gamma, const float* beta,
                  const float* add, int add_rows_per_entry, int add_entries, void* out, int ldo, void* stream);
+
+/* LayerNorm (or, with gamma == NULL, no normalisation) whose result is quantised per row to OCP e4m3 for an fp8
+ * projection GEMM: out8[r, 0:c] = e4m3(y[r, :] / scale[r]) with y as vx_layernorm computes it (incl. the additive
+ * table), scale[r] = max|y[r, :]| / 448 (1 when the row is all zero); columns [c, ldo8) are written as zeros (the K
+ * padding of the fp8 GEMM: ldo8 = c rounded up to 128).  The V-Express reference has no fp8 path (dtypes fp16 / bf16 /
+ * fp32, inference.py:150-157); this is the quantiser in front of attn*.to_q / to_k / to_v / to_out when
+ * UNet3DConditionModel.fp8_projections is on. */
+int vx_layernorm_fp8(const void* x, int ldx, int rows, int c, float eps, const float* gamma, const float* beta,
+                     const float* add, int add_rows_per_entry, int add_entries, void* out8, int ldo8, float* scale,
+                     void* stream);
 
 /* ---- Fused (flash-style) attention, softmax(q k^T * scale) v, per (batch, head) ----------------------------
  * Replaces F.scaled_dot_product_attention via diffusers AttnProcessor2_0 for attn1 / attn1_5

@@ -56,6 +56,40 @@ def layernorm(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_e
     return y
 
 
+def layernorm_fp8(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_entries=1):
+    """vx_layernorm_fp8: (optional) LayerNorm in float64, per-row scale = max|y| / 448, OCP e4m3 round-to-nearest."""
+    from v_express_amd import ops as real_ops
+    x2 = x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x
+    y = x2.double()
+    if gamma is not None:
+        y = F.layer_norm(y, (y.shape[-1],), gamma.double(), beta.double(), eps)
+        if add is not None:
+            idx = (torch.arange(y.shape[0]) // add_rows_per_entry) % add_entries
+            y = y + add.double().reshape(-1, y.shape[-1])[idx]
+    y = y.float()
+    amax = y.abs().amax(dim=1)
+    sc = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    k = y.shape[1]
+    q = torch.zeros((y.shape[0], real_ops.pad128(k)), dtype=torch.uint8)
+    q[:, :k] = (y / sc[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+    return real_ops.Fp8Rows(q, sc, k)
+
+
+def quantize_fp8(x):
+    return layernorm_fp8(x, None, None)
+
+
+def _dequant(a, w):
+    """(Fp8Rows, Fp8Weight) -> float64 operands (the fp8 MFMA is exact on e4m3 products, fp32 accumulation)."""
+    x = a.q.view(torch.float8_e4m3fn).double() * a.scale.double()[:, None]
+    wt = w.w8.view(torch.float8_e4m3fn).double() * w.scale.double()[:, None]
+    return x, wt
+
+
+def _is_fp8(a):
+    return type(a).__name__ == "Fp8Rows"
+
+
 def _conv_rows(a, a2, w, geom):
     """Implicit-GEMM semantics of vx_gemm: rows (frame, y, x) of NHWC sources (channel-concatenated), weight [N, kh*kw*C]
     with (ky, kx, c) column order, nearest-2x upsample before the conv, zero padding `pad` before each spatial axis and
@@ -79,13 +113,18 @@ def _conv_rows(a, a2, w, geom):
 
 def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=0, rowbias=None, rows_per_group=0,
          out=None, out_f32=False):
-    assert a.dtype == BF16 and w.dtype == BF16 and a.stride(-1) == 1 and w.is_contiguous()
-    if geom is None:
+    if _is_fp8(a):
+        assert geom is None and a2 is None
+        x, wt = _dequant(a, w)
+        y = x @ wt.t()
+    elif geom is None:
+        assert a.dtype == BF16 and w.dtype == BF16 and a.stride(-1) == 1 and w.is_contiguous()
         assert a.dim() == 2 and a.stride(0) % 8 == 0
         x = a.double() if a2 is None else torch.cat([a.double(), a2.double()], dim=-1)
         assert x.shape[1] == w.shape[1], (x.shape, w.shape)
         y = x @ w.double().t()
     else:
+        assert a.dtype == BF16 and w.dtype == BF16 and a.stride(-1) == 1 and w.is_contiguous()
         y = _conv_rows(a.reshape(-1, a.shape[-1]), None if a2 is None else a2.reshape(-1, a2.shape[-1]), w, geom)
     if bias is not None:
         assert bias.dtype == torch.float32
@@ -124,7 +163,11 @@ def alloc_vt(seqs, heads, head_dim, n, device):
 
 
 def gemm_split(a, w, bias, parts, *, part_cols, seq_len=0, head_dim=0, geom=None):
-    y = a.double() @ w.double().t()
+    if _is_fp8(a):
+        x, wt = _dequant(a, w)
+        y = x @ wt.t()
+    else:
+        y = a.double() @ w.double().t()
     if bias is not None:
         y = y + bias
     for i, (kind, t) in enumerate(parts):
@@ -243,7 +286,7 @@ def vae_postprocess(x, n, c, h, w):
     return (x[:, :c].float().reshape(n, h, w, c).permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1).contiguous()
 
 
-ALL = ("wave_conv1d", "groupnorm", "layernorm", "gemm", "geglu", "alloc_vt", "gemm_split", "key_norm_max", "attention",
+ALL = ("wave_conv1d", "groupnorm", "layernorm", "layernorm_fp8", "quantize_fp8", "gemm", "geglu", "alloc_vt", "gemm_split", "key_norm_max", "attention",
        "temporal_attention", "small_kv_attention", "add_row_bias", "gather_latents", "cfg_combine", "pack_rows", "combine_units", "overlap_ddim_step",
        "ncfhw_to_nhwc", "nhwc_to_ncfhw", "vae_postprocess")
 

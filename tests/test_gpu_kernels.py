@@ -508,3 +508,82 @@ def test_errors_are_reported_not_fatal(ops):
         ops.gemm(rnd(16, 12), rnd(8, 12))            # K not a multiple of 8
     with pytest.raises(VxError):
         ops.temporal_attention(rnd(33 * 4, 3 * 64), b=1, f=33, hw=4, heads=8, head_dim=8)
+
+
+# ------------------------------------------------------------------------------------- fp8 projections (config 5)
+
+
+def _deq(q8, scale):
+    return q8.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
+@pytest.mark.parametrize("rows,c,norm,pe", [(300, 320, True, False), (257, 640, True, True), (64, 1280, False, False),
+                                            (130, 40, True, False)])
+def test_layernorm_fp8(ops, rows, c, norm, pe):
+    """vx_layernorm_fp8: y = LN(x) (+ table) or x itself, scale[r] = max|y[r]| / 448, q = e4m3(y / scale), K zero-padded
+    to a multiple of 128.  The dequantised row must sit within half an e4m3 ulp of y (3 mantissa bits: 2^-4 relative for
+    normal values, 2^-9 * scale... absolute below 2^-6) and the scale must be the row maximum."""
+    x = rnd(rows, c, scale=2.0, seed=7)
+    g = b = add = None
+    y = x.float()
+    if norm:
+        g, b = 1 + 0.1 * rnd(c, seed=1, dtype=torch.float32), 0.1 * rnd(c, seed=2, dtype=torch.float32)
+        y = F.layer_norm(y, (c,), g, b, 1e-5)
+        if pe:
+            add = rnd(8, c, seed=3, dtype=torch.float32)
+            y = y + add[(torch.arange(rows, device="cuda") // 16) % 8]
+    r = ops.layernorm_fp8(x, g, b, add=add, add_rows_per_entry=16, add_entries=8) if norm else ops.quantize_fp8(x)
+    kp = (c + 127) // 128 * 128
+    assert r.q.shape == (rows, kp) and r.q.dtype == torch.uint8 and r.k == c
+    assert (r.q[:, c:] == 0).all(), "K padding must be zero bytes"
+    amax = y.abs().amax(dim=1)
+    assert torch.allclose(r.scale, amax / 448.0, rtol=2e-3), (r.scale[:4], amax[:4] / 448)
+    deq = _deq(r.q[:, :c], r.scale)
+    err = (deq - y).abs()
+    tol = y.abs() * 2 ** -4 + r.scale[:, None] * 2 ** -6 * 1.01 + 2e-3 * amax[:, None]   # half ulp (+ bf16-level LN noise)
+    assert (err <= tol).all(), (err.max().item(), (err / tol).max().item())
+    assert ((deq - y).pow(2).sum().sqrt() / y.pow(2).sum().sqrt()).item() <= 4e-2
+
+
+@pytest.mark.parametrize("m,n,k", [(65536, 320, 320), (384, 960, 640), (200, 1280, 1280), (4096, 320, 320),
+                                   (256 * 48, 1920, 640)])      # first / last: the 256x320 tile (>= 256 tiles)
+def test_gemm_fp8_store_and_split(ops, m, n, k):
+    """The fp8 GEMM against a float64 product of the DEQUANTISED operands (e4m3 x e4m3 products are exact in fp32, so
+    only the accumulation order and the bf16 output rounding remain): per-kernel tolerance of the bf16 GEMM."""
+    a = rnd(m, k, seed=1)
+    w = rnd(n, k, scale=k ** -0.5, seed=2)
+    a8, w8 = ops.quantize_fp8(a), ops.fp8_weight(w)
+    A = _deq(a8.q, a8.scale).double()
+    W = _deq(w8.w8, w8.scale).double()
+    bias = rnd(n, seed=3, dtype=torch.float32)
+    res = rnd(m, n, seed=4)
+    ref = A @ W.t() + bias.double()
+    out = ops.gemm(a8, w8, bias, residual=res, alpha=0.95)
+    check(out, (res.double() + 0.95 * ref).float(), f"fp8 gemm store {m}x{n}x{k}")
+    # the quantisation itself: against the un-quantised bf16 product, e4m3 operand noise (2^-4 / sqrt(12) per element,
+    # both operands, averaged over K terms)
+    full = a.double() @ w.double().t() + bias.double()
+    rl2 = ((ref - full).norm() / full.norm()).item()
+    assert rl2 <= 4e-2, rl2
+    if n % 3 == 0 and (n // 3) % 16 == 0:
+        c = n // 3
+        heads, seq = 8, 64 if m % 64 == 0 else m
+        if m % seq == 0 and c % heads == 0:
+            d = c // heads
+            q = torch.empty((m, c), device="cuda", dtype=BF)
+            kk = torch.empty((m, c), device="cuda", dtype=BF)
+            vt = ops.alloc_vt(m // seq, heads, d, seq, "cuda")
+            ops.gemm_split(a8, w8, bias, [("rows", q), ("rows", kk), ("vt", vt)], part_cols=c, seq_len=seq, head_dim=d)
+            check(q, ref[:, :c].float(), "fp8 split q")
+            check(kk, ref[:, c:2 * c].float(), "fp8 split k")
+            v_ref = ref[:, 2 * c:].float().view(m // seq, seq, heads, d).permute(0, 2, 3, 1)
+            check(vt[..., :seq], v_ref, "fp8 split v^T")
+
+
+def test_gemm_fp8_rejects_what_it_does_not_support(ops):
+    from v_express_amd import lib as L
+    a8, w8 = ops.quantize_fp8(rnd(64, 320)), ops.fp8_weight(rnd(320, 320, seed=1))
+    with pytest.raises(TypeError):
+        ops.gemm(a8, rnd(320, 320, seed=1))                  # bf16 weight with fp8 activations
+    with pytest.raises(L.VxError):
+        ops.geglu(a8, w8, None)                               # GEGLU epilogue is not built for fp8

@@ -67,10 +67,12 @@ def _self_attention(A, ln, h, *, seqs, n_tok, heads):
     q = torch.empty((m, c), device=ln.device, dtype=ops.BF16)
     k = torch.empty((m, c), device=ln.device, dtype=ops.BF16)
     vt = ops.alloc_vt(seqs, heads, d, n_tok, ln.device)
-    ops.gemm_split(ln, A.wqkv, A.bqkv, [("rows", q), ("rows", k), ("vt", vt)], part_cols=c, seq_len=n_tok,
-                   head_dim=d)
+    ops.gemm_split(ln, ops.proj_weight(ln, A.wqkv), A.bqkv, [("rows", q), ("rows", k), ("vt", vt)], part_cols=c,
+                   seq_len=n_tok, head_dim=d)
     a = ops.attention(q, k, vt, batch=seqs, heads=heads, n_q=n_tok, n_kv=n_tok, head_dim=d)
-    ops.gemm(a, A.out.w, A.out.b, residual=h, out=h)
+    if isinstance(ln, ops.Fp8Rows):
+        a = ops.quantize_fp8(a)
+    ops.gemm(a, ops.proj_weight(a, A.out.w), A.out.b, residual=h, out=h)
 
 
 def _feed_forward(P, h):
@@ -104,7 +106,7 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
     n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
     h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b)
     # 1. self-attention (:177-184)
-    ln = ops.layernorm(h, P.norm1.g, P.norm1.b)
+    ln = ops.proj_layernorm(h, P.norm1.g, P.norm1.b)
     _self_attention(P.attn1, ln, h, seqs=frames, n_tok=hw, heads=heads)
     # 1.5 reference attention (:186-224): K/V = bank of the batch row, shared by its f frames
     d = c // heads
@@ -115,12 +117,12 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
             ops.add_row_bias(hb, P.attn1_5.out.b, w_ref)
         else:
             kref, vtref, kmax = bank[bi]
-            ln = ops.layernorm(hb, P.norm1_5.g, P.norm1_5.b)
+            ln = ops.proj_layernorm(hb, P.norm1_5.g, P.norm1_5.b)
             with ops.frame_rows(hw, items=1):          # these launches cover ONE batch item
-                q = ops.gemm(ln, P.attn1_5.wq)
-                a = ops.attention(q, kref, vtref, batch=f, heads=heads, n_q=hw, n_kv=kref.shape[0], head_dim=d,
-                                  q_per_kv=f, kmax=kmax)
-                ops.gemm(a, P.attn1_5.out.w, P.attn1_5.out.b, residual=hb, alpha=w_ref, out=hb)
+                q = ops.gemm(ln, ops.proj_weight(ln, P.attn1_5.wq))
+                a = ops.proj_input(ops.attention(q, kref, vtref, batch=f, heads=heads, n_q=hw, n_kv=kref.shape[0],
+                                                 head_dim=d, q_per_kv=f, kmax=kmax))
+                ops.gemm(a, ops.proj_weight(a, P.attn1_5.out.w), P.attn1_5.out.b, residual=hb, alpha=w_ref, out=hb)
     # 2. audio cross-attention (:227-244).  A batch row whose audio tokens are ALL ZERO (the unconditional CFG half:
     # torch.zeros_like, pipelines/v_express_pipeline.py:403-405) has K = V = 0 (to_k / to_v carry no bias): every
     # score is 0, the softmax is uniform, the weighted sum of V is exactly 0 and the block adds exactly
@@ -129,10 +131,10 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
     if kv is None:
         kv = audio_kv(P, ehs)
     if audio_zero is None or not any(audio_zero):
-        ln = ops.layernorm(h, P.norm2.g, P.norm2.b)
-        q = ops.gemm(ln, P.attn2.wq)
-        a = ops.small_kv_attention(q, kv, batch=frames, n_q=hw, n_kv=n_ctx, heads=heads, head_dim=d)
-        ops.gemm(a, P.attn2.out.w, P.attn2.out.b, residual=h, alpha=w_aud, out=h)
+        ln = ops.proj_layernorm(h, P.norm2.g, P.norm2.b)
+        q = ops.gemm(ln, ops.proj_weight(ln, P.attn2.wq))
+        a = ops.proj_input(ops.small_kv_attention(q, kv, batch=frames, n_q=hw, n_kv=n_ctx, heads=heads, head_dim=d))
+        ops.gemm(a, ops.proj_weight(a, P.attn2.out.w), P.attn2.out.b, residual=h, alpha=w_aud, out=h)
     else:
         kvr = f * n_ctx
         for bi in range(b):
@@ -140,12 +142,12 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
             if audio_zero[bi]:
                 ops.add_row_bias(hb, P.attn2.out.b, w_aud)
                 continue
-            ln = ops.layernorm(hb, P.norm2.g, P.norm2.b)
+            ln = ops.proj_layernorm(hb, P.norm2.g, P.norm2.b)
             with ops.frame_rows(hw, items=1):
-                q = ops.gemm(ln, P.attn2.wq)
-                a = ops.small_kv_attention(q, kv[bi * kvr:(bi + 1) * kvr], batch=f, n_q=hw, n_kv=n_ctx, heads=heads,
-                                           head_dim=d)
-                ops.gemm(a, P.attn2.out.w, P.attn2.out.b, residual=hb, alpha=w_aud, out=hb)
+                q = ops.gemm(ln, ops.proj_weight(ln, P.attn2.wq))
+                a = ops.proj_input(ops.small_kv_attention(q, kv[bi * kvr:(bi + 1) * kvr], batch=f, n_q=hw, n_kv=n_ctx,
+                                                          heads=heads, head_dim=d))
+                ops.gemm(a, ops.proj_weight(a, P.attn2.out.w), P.attn2.out.b, residual=hb, alpha=w_aud, out=hb)
     # 3. feed-forward (:247)
     _feed_forward(P, h)
     out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x2d)
@@ -202,10 +204,10 @@ def _motion_module(P, x, *, b, f, H, W, heads, groups, shard=None):
     m = b * f_all * hw_t
     h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b)
     for A in P.attn:
-        ln = ops.layernorm(h, A.norm.g, A.norm.b, add=A.pe, add_rows_per_entry=hw_t, add_entries=f_all)
-        qkv = ops.gemm(ln, A.attn.wqkv, A.attn.bqkv)
-        a = ops.temporal_attention(qkv, b=b, f=f_all, hw=hw_t, heads=heads, head_dim=d)
-        ops.gemm(a, A.attn.out.w, A.attn.out.b, residual=h, out=h)
+        ln = ops.proj_layernorm(h, A.norm.g, A.norm.b, add=A.pe, add_rows_per_entry=hw_t, add_entries=f_all)
+        qkv = ops.gemm(ln, ops.proj_weight(ln, A.attn.wqkv), A.attn.bqkv)
+        a = ops.proj_input(ops.temporal_attention(qkv, b=b, f=f_all, hw=hw_t, heads=heads, head_dim=d))
+        ops.gemm(a, ops.proj_weight(a, A.attn.out.w), A.attn.out.b, residual=h, out=h)
     _feed_forward(P, h)
     if shard is not None:
         h = shard.to_frame_shard(h.view(b * f_all, hw_t, c), b, f).view(frames * hw, c)

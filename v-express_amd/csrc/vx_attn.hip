@@ -880,6 +880,12 @@ int attention_impl(const void* q, int ldq, const void* k, int ldk, const void* v
 
 }  // namespace
 
+// vx_attn3.hip: the DMA-ring kernel for d = 40 with a key-norm table
+int vx_attn3_variant();
+int vx_attn3_launch(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_pitch, void* out, int ldo,
+                    int batch, int heads, int n_q, int n_kv, int q_per_kv, float c, const float* kmax,
+                    hipStream_t stream);
+
 extern "C" int vx_key_norm_max(const void* k, int ldk, int kv_batches, int heads, int n_kv, int head_dim, float* out,
                                void* stream) {
   VX_REQUIRE(k && out, "vx_key_norm_max: null pointer");
@@ -925,6 +931,10 @@ int attention_impl(const void* q, int ldq, const void* k, int ldk, const void* v
   // attn2: the software-pipelined kernel; instantiated for the head dims whose register budget fits two S tiles
   // (d = 40: the 64x64 level, 85 % of the attention time).  Other head dims keep the plain kernel.
   // With a key-norm table the bounded-softmax body runs (exact fallback inside the kernel); other head dims ignore it.
+  if (!v1 && d == 40 && key_norm_max && vx_attn3_variant() > 0 && ((size_t)n_kv * ldk * 2) < (1ull << 31) &&
+      ((size_t)d * vt_pitch * 2) < (1ull << 31))
+    return vx_attn3_launch(q, ldq, k, ldk, vt, vt_pitch, out, ldo, batch, heads, n_q, n_kv, q_per_kv, p.c, key_norm_max,
+                           stream);
   if (!v1 && d > 32 && d <= 48 && (d % 16) != 0)
     return key_norm_max ? launch_attn2<2, 3, 2, true, true>(p, stream) : launch_attn2<2, 3, 2, true, false>(p, stream);
   if (d <= 32) return launch_attn<1, 2, 4, true>(p, stream);

@@ -56,13 +56,28 @@ __device__ __forceinline__ void wait_vmcnt() {
 // pre-padded input), cin, c1 and K are multiples of 64 and both operands span < 4 GiB.  Then the per-thread part
 // of every DMA address is a loop-invariant 32-bit byte offset and the per-tile part is wave-uniform (SGPRs):
 // the K loop spends no VALU instructions on addressing (a wave64 VALU op costs 4 cycles = 1/8 of an MFMA).
-template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST>
+// F8: both operands are OCP e4m3 bytes (a K-tile row is still 128 B = 128 elements = ONE v_mfma_scale_f32_16x16x128_f8f6f4
+// with unit block scales per fragment pair instead of two bf16 MFMAs); the accumulators are multiplied by the row scale of
+// A and the row scale of W before the epilogue.  FAST addressing only (plain linears over zero-padded K).
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4_t mfma16_f8(const uint4& a_lo, const uint4& a_hi, const uint4& b_lo, const uint4& b_hi,
+                                             f32x4_t c) {
+  const i32x8_t a = {(int)a_lo.x, (int)a_lo.y, (int)a_lo.z, (int)a_lo.w, (int)a_hi.x, (int)a_hi.y, (int)a_hi.z, (int)a_hi.w};
+  const i32x8_t b = {(int)b_lo.x, (int)b_lo.y, (int)b_lo.z, (int)b_lo.w, (int)b_hi.x, (int)b_hi.y, (int)b_hi.z, (int)b_hi.w};
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST, bool F8 = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const vx_gemm_params p) {
+  static_assert(!F8 || FAST, "fp8 operands use the FAST addressing only");
+  constexpr int ES = F8 ? 1 : 2;            // bytes per operand element
+  constexpr int BKE = 128 / ES;             // elements per K-tile (one 128-byte LDS row)
+  constexpr int CE = 16 / ES;               // elements per 16-byte chunk
   constexpr int NTHREADS = 64 * WARPS_M * WARPS_N;
   constexpr int RPP = NTHREADS / 8;   // tile rows staged per pass of the whole block
   constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
   constexpr int MI = WM / 16, NI = WN / 16;
-  constexpr int NJ = NI <= 5 ? NI : NI / 2;   // B fragments live at once
+  constexpr int NJ = F8 ? (NI % 2 == 0 ? 2 : 1) : (NI <= 5 ? NI : NI / 2);   // B fragments live at once (fp8: 2 x 16 B each)
   constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
   constexpr int G = A_IT + B_IT;              // DMA instructions per thread per K-tile
   constexpr int STAGE_BYTES = (BM + BN) * 128;
@@ -100,12 +115,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
   // ---- FAST path state
   uint32_t aoff1[A_IT], aoff2[A_IT], boff[B_IT];
   // this block's K-tile range (the whole K loop unless split-K)
-  const int nk_total = (p.k + BK - 1) / BK;
+  const int nk_total = (p.k + BKE - 1) / BKE;
   const int kt_begin = (int)((long)split * nk_total / nsplit), kt_end = (int)((long)(split + 1) * nk_total / nsplit);
   int s_kt = kt_begin, s_ci, s_kx, s_ky;   // wave-uniform K position of the next tile to issue
   {
-    const int tap0 = (kt_begin * BK) / cin;
-    s_ci = kt_begin * BK - tap0 * cin;
+    const int tap0 = (kt_begin * BKE) / cin;
+    s_ci = kt_begin * BKE - tap0 * cin;
     s_ky = tap0 / kw;
     s_kx = tap0 - s_ky * kw;
   }
@@ -126,13 +141,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
       int oy = rem / p.w_out;
       int ox = rem - oy * p.w_out;
       uint32_t pix = (uint32_t)(fr * p.h_in * p.w_in + oy * p.stride * w_in + ox * p.stride);
-      aoff1[i] = (pix * (uint32_t)lda1 + (uint32_t)(cc * 8)) * 2u;
-      aoff2[i] = (pix * (uint32_t)lda2 + (uint32_t)(cc * 8)) * 2u;
+      aoff1[i] = (pix * (uint32_t)lda1 + (uint32_t)(cc * CE)) * (uint32_t)ES;
+      aoff2[i] = (pix * (uint32_t)lda2 + (uint32_t)(cc * CE)) * (uint32_t)ES;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
       int n = min(n0 + r0 + RPP * i, p.n - 1);
-      boff[i] = ((uint32_t)n * (uint32_t)p.k + (uint32_t)(cc * 8)) * 2u;
+      boff[i] = ((uint32_t)n * (uint32_t)p.k + (uint32_t)(cc * CE)) * (uint32_t)ES;
     }
   } else {
 #pragma unroll
@@ -169,15 +184,15 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
     if constexpr (FAST) {
       // wave-uniform: source, its row stride and the tap's byte offset
       const bool first = s_ci < c1;
-      const char* abase = first ? (const char*)(A1 + s_ci) + (long)(s_ky * w_in + s_kx) * lda1 * 2
-                                : (const char*)(A2 + (s_ci - c1)) + (long)(s_ky * w_in + s_kx) * lda2 * 2;
-      const char* bbase = (const char*)Wt + (long)s_kt * (BK * 2);
+      const char* abase = first ? (const char*)A1 + ((long)s_ci + (long)(s_ky * w_in + s_kx) * lda1) * ES
+                                : (const char*)A2 + ((long)(s_ci - c1) + (long)(s_ky * w_in + s_kx) * lda2) * ES;
+      const char* bbase = (const char*)Wt + (long)s_kt * 128;
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) glds16_s(abase, first ? aoff1[i] : aoff2[i], sa + i * RPP * 128);
 #pragma unroll
       for (int i = 0; i < B_IT; ++i) glds16_s(bbase, boff[i], sb + i * RPP * 128);
       ++s_kt;
-      s_ci += BK;
+      s_ci += BKE;
       if (s_ci >= cin) {
         s_ci = 0;
         if (++s_kx == kw) { s_kx = 0; ++s_ky; }
@@ -236,6 +251,31 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
     if (kt + STAGES - 1 < nk && !ABL(4)) issue_tile(fill);
     const char* sa = smem + stage * STAGE_BYTES;
     const char* sb = sa + BM * 128;
+    if constexpr (F8) {
+      // lane (row, fgrp) contracts chunks fgrp and 4 + fgrp of the 128-byte row on BOTH operands (the order of the
+      // 128 k-values inside the MFMA is free as long as A and B agree): the same two conflict-free ds_read_b128
+      // patterns as the bf16 loop's kk = 0 / 1
+      uint4 af[MI][2];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        af[i][0] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * WM + i * 16 + frow, fgrp));
+        af[i][1] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * WM + i * 16 + frow, 4 + fgrp));
+      }
+#pragma unroll
+      for (int j0 = 0; j0 < NI; j0 += NJ) {
+        uint4 bfr[NJ][2];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          bfr[j][0] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * WN + (j0 + j) * 16 + frow, fgrp));
+          bfr[j][1] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * WN + (j0 + j) * 16 + frow, 4 + fgrp));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j0 + j] = mfma16_f8(bfr[j][0], bfr[j][1], af[i][0], af[i][1], acc[i][j0 + j]);   // D = C^T fragment
+      }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       if (ABL(16)) continue;
@@ -261,6 +301,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
           }
       }
     }
+    }   // !F8
     stage = stage + 1 == STAGES ? 0 : stage + 1;
     fill = fill + 1 == STAGES ? 0 : fill + 1;
   }
@@ -274,6 +315,24 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
   const float* __restrict__ bias = p.bias;
   const int lrow = lane & 15, lq = lane >> 4;
   const int wrow0 = m0 + wm * WM, wcol0 = n0 + wn * WN;
+
+  if constexpr (F8) {
+    // dequantise: acc[m][n] *= a_scale[m] * w_scale[n] (rows / columns beyond M / N clamped: never stored)
+    const float* __restrict__ asc = p.a_scale;
+    const float* __restrict__ wsc = p.w_scale;
+    float sa_[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) sa_[i] = asc[min(wrow0 + i * 16 + lrow, p.m - 1)];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const float4 sw = *reinterpret_cast<const float4*>(wsc + min(wcol0 + j * 16 + lq * 4, p.n - 4));
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        acc[i][j][0] *= sa_[i] * sw.x; acc[i][j][1] *= sa_[i] * sw.y;
+        acc[i][j][2] *= sa_[i] * sw.z; acc[i][j][3] *= sa_[i] * sw.w;
+      }
+    }
+  }
 
   if (EPI == VX_EPI_STORE && nsplit > 1) {
     // split-K slice: raw fp32 partial sums to the workspace, 16 bytes (4 columns) per lane
@@ -533,14 +592,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vx_gemm_params
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST, bool F8 = false>
 int launch_impl(const vx_gemm_params& p, hipStream_t stream) {
   constexpr int stage_bytes = STAGES * (BM + BN) * 128;
   constexpr int epi_bytes = (EPI == VX_EPI_SPLIT) ? BN * (64 + 4) * 4 : 0;   // V^T transposition slab
   constexpr int smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
   constexpr int nthreads = 64 * WARPS_M * WARPS_N;
   static bool attr_set = false;
-  auto kern = gemm_kernel<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, FAST>;
+  auto kern = gemm_kernel<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, FAST, F8>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
@@ -622,6 +681,12 @@ extern "C" const char* vx_gemm_config_name(const vx_gemm_params* pp) {
   const bool fast = fast_ok(p);
   const char* epi = p.epi == VX_EPI_STORE ? "STORE" : (p.epi == VX_EPI_GEGLU ? "GEGLU" : "SPLIT");
   const char* tile;
+  if (p.a_fp8) {
+    static thread_local char b8[96];
+    const bool big8 = (p.n % 320) == 0 && (long)ceil_div(p.m, 256) * (p.n / 320) >= 256;
+    snprintf(b8, sizeof(b8), "gemm_kernel<%s,%s,fast,fp8>", big8 ? "256x320x128,8w" : "128x160x128,4w", epi);
+    return b8;
+  }
   if (vx_gemm_ring_eligible(p))
     return p.epi == VX_EPI_GEGLU ? "gemm_ring_kernel<256x320x64,8w,GEGLU,fast>" : "gemm_ring_kernel<256x320x64,8w,STORE,fast>";
   if (p.epi == VX_EPI_STORE && p.n <= 32) tile = "256x32x64,4w";
@@ -654,6 +719,26 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
   VX_REQUIRE(p.splitk <= 1 || (p.epi == VX_EPI_STORE && p.splitk_ws != nullptr && p.splitk <= 16 &&
                                p.splitk <= (p.k + BK - 1) / BK),
              "vx_gemm: split-K needs the STORE epilogue, a workspace and splitk <= min(16, K/64)");
+  if (p.a_fp8) {
+    // fp8 projections: plain linears over zero-padded K (see vx_gemm_params.a_fp8)
+    VX_REQUIRE(p.a_scale != nullptr && p.w_scale != nullptr, "vx_gemm(fp8): null scale table");
+    VX_REQUIRE(p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad == 0 && p.upsample == 0 && p.a2 == nullptr &&
+                   p.splitk <= 1 && p.h_out == p.h_in && p.w_out == p.w_in,
+               "vx_gemm(fp8): plain linears only");
+    VX_REQUIRE((p.k % 128) == 0 && (p.lda1 % 16) == 0 && p.c1 == p.k && (p.n % 4) == 0,
+               "vx_gemm(fp8): k=%d must be a multiple of 128 (zero-padded), lda1=%d of 16", p.k, p.lda1);
+    VX_REQUIRE((unsigned long long)p.m * p.lda1 < (1ull << 32) && (unsigned long long)p.n * p.k < (1ull << 32),
+               "vx_gemm(fp8): operand spans 4 GiB");
+    VX_REQUIRE(p.epi == VX_EPI_STORE || p.epi == VX_EPI_SPLIT, "vx_gemm(fp8): STORE / SPLIT epilogues only");
+    const bool big = (p.n % 320) == 0 && (long)ceil_div(p.m, 256) * (p.n / 320) >= 256;
+    if (p.epi == VX_EPI_STORE) {
+      VX_REQUIRE(p.out != nullptr && (p.ldc % 8) == 0, "vx_gemm: STORE needs out and ldc%%8==0");
+      VX_REQUIRE(p.residual == nullptr || (p.ldr % 8) == 0, "vx_gemm: ldr%%8");
+      VX_REQUIRE(p.rowbias == nullptr || p.rows_per_group > 0, "vx_gemm: rows_per_group");
+      if (big) return launch_impl<256, 320, 4, 2, 2, VX_EPI_STORE, true, true>(p, stream);
+      return launch_impl<128, 160, 2, 2, 2, VX_EPI_STORE, true, true>(p, stream);
+    }
+  }
   if (p.epi == VX_EPI_STORE) {
     VX_REQUIRE(p.out != nullptr && (p.ldc % 8) == 0, "vx_gemm: STORE needs out and ldc%%8==0");
     VX_REQUIRE(p.residual == nullptr || (p.ldr % 8) == 0, "vx_gemm: ldr%%8");
@@ -681,6 +766,11 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
                    "vx_gemm: bad V^T geometry seq_len=%d head_dim=%d pitch=%d", p.seq_len, p.head_dim, p.vt_pitch);
       else
         VX_REQUIRE((p.part_ld[i] % 8) == 0, "vx_gemm: part_ld%%8");
+    }
+    if (p.a_fp8) {
+      if ((p.n % 320) == 0 && (long)ceil_div(p.m, 256) * (p.n / 320) >= 256)
+        return launch_impl<256, 320, 4, 2, 2, VX_EPI_SPLIT, true, true>(p, stream);
+      return launch_impl<128, 160, 2, 2, 2, VX_EPI_SPLIT, true, true>(p, stream);
     }
     if (use_big(p)) return launch<256, 320, 4, 2, 2, VX_EPI_SPLIT>(p, stream);
     if (prefer160(p.n)) return launch<128, 160, 2, 2, 2, VX_EPI_SPLIT>(p, stream);

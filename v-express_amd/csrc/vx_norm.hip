@@ -366,6 +366,93 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   }
 }
 
+// LayerNorm (NORM) or identity whose output is quantised per row to OCP e4m3 (vx_layernorm_fp8): same row-in-registers
+// structure as layernorm_kernel; the normalised row stays in registers, its max |y| is reduced over the wave,
+// scale = max / 448 and the row is written as 8 bytes per 8-channel chunk; chunks between c and ldo8 are zero-filled
+// (the K padding of the fp8 GEMM).
+template <int MAXC, bool NORM>
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const bf16_t* __restrict__ x, int ldx, int rows, int c,
+                                                            float eps, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ add, int add_rows_per_entry,
+                                                            int add_entries, uint8_t* __restrict__ out8, int ldo8,
+                                                            float* __restrict__ scale) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const int nchunks = c >> 3, ochunks = ldo8 >> 3;
+  const float inv_c = 1.0f / (float)c;
+  for (int row = wave; row < rows; row += nwaves) {
+    float y[MAXC][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXC; ++u) {
+      const int chunk = lane + u * 64;
+      if (chunk < nchunks) {
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(x + (size_t)row * ldx + chunk * 8), y[u]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[u][e] = 0.f;
+      }
+      sum += ((y[u][0] + y[u][1]) + (y[u][2] + y[u][3])) + ((y[u][4] + y[u][5]) + (y[u][6] + y[u][7]));
+    }
+    if (NORM) {
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) sum = wave_xor_sum(sum, m);
+      const float mean = sum * inv_c;
+      float sq = 0.f;
+#pragma unroll
+      for (int u = 0; u < MAXC; ++u) {
+        if (lane + u * 64 < nchunks) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = y[u][e] - mean;
+            sq += d * d;
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) sq = wave_xor_sum(sq, m);
+      const float rstd = rsqrtf(sq * inv_c + eps);
+      const float* addrow = add != nullptr ? add + (size_t)((row / add_rows_per_entry) % add_entries) * c : nullptr;
+#pragma unroll
+      for (int u = 0; u < MAXC; ++u) {
+        const int chunk = lane + u * 64;
+        if (chunk < nchunks) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float o = (y[u][e] - mean) * rstd * gamma[chunk * 8 + e] + beta[chunk * 8 + e];
+            if (addrow != nullptr) o += addrow[chunk * 8 + e];
+            y[u][e] = o;
+          }
+        }
+      }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXC; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(y[u][e]));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) amax = wave_xor_max(amax, m);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+#pragma unroll
+    for (int u = 0; u < MAXC; ++u) {
+      const int chunk = lane + u * 64;
+      if (chunk < ochunks) {
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[u][0] * inv, y[u][1] * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[u][2] * inv, y[u][3] * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[u][4] * inv, y[u][5] * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[u][6] * inv, y[u][7] * inv, w1, true);
+        *reinterpret_cast<uint2*>(out8 + (size_t)row * ldo8 + chunk * 8) = make_uint2((uint32_t)w0, (uint32_t)w1);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t vx_groupnorm_ws_floats(int frames, int slices, int groups) {
@@ -434,4 +521,39 @@ extern "C" int vx_layernorm(const void* x, int ldx, int rows, int c, float eps, 
   }
 #undef VX_LN
   return vx_check_launch("vx_layernorm");
+}
+
+extern "C" int vx_layernorm_fp8(const void* x, int ldx, int rows, int c, float eps, const float* gamma,
+                                const float* beta, const float* add, int add_rows_per_entry, int add_entries,
+                                void* out8, int ldo8, float* scale, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(x != nullptr && out8 != nullptr && scale != nullptr, "vx_layernorm_fp8: null pointer");
+  VX_REQUIRE((gamma == nullptr) == (beta == nullptr), "vx_layernorm_fp8: gamma and beta come together");
+  VX_REQUIRE(rows > 0 && c > 0 && (c % 8) == 0 && (ldx % 8) == 0 && (ldo8 % 16) == 0 && ldo8 >= c,
+             "vx_layernorm_fp8: bad shape (c=%d ldx=%d ldo8=%d)", c, ldx, ldo8);
+  VX_REQUIRE(add == nullptr || (gamma != nullptr && add_rows_per_entry > 0 && add_entries > 0),
+             "vx_layernorm_fp8: bad add table");
+  const int ochunks = ldo8 / 8;
+  int nblk = ceil_div(rows, 4);
+  if (nblk > 8192) nblk = 8192;
+  dim3 grid(nblk), block(256);
+#define VX_LN8(MAXC)                                                                                                  \
+  do {                                                                                                                \
+    if (gamma != nullptr)                                                                                             \
+      hipLaunchKernelGGL((layernorm_fp8_kernel<MAXC, true>), grid, block, 0, stream, (const bf16_t*)x, ldx, rows, c,  \
+                         eps, gamma, beta, add, add_rows_per_entry, add_entries, (uint8_t*)out8, ldo8, scale);        \
+    else                                                                                                              \
+      hipLaunchKernelGGL((layernorm_fp8_kernel<MAXC, false>), grid, block, 0, stream, (const bf16_t*)x, ldx, rows, c, \
+                         eps, gamma, beta, add, add_rows_per_entry, add_entries, (uint8_t*)out8, ldo8, scale);        \
+  } while (0)
+  if (ochunks <= 64) VX_LN8(1);
+  else if (ochunks <= 128) VX_LN8(2);
+  else if (ochunks <= 192) VX_LN8(3);
+  else if (ochunks <= 256) VX_LN8(4);
+  else {
+    vx_set_error("vx_layernorm_fp8: c=%d exceeds 2048", c);
+    return VX_ERR_UNSUPPORTED;
+  }
+#undef VX_LN8
+  return vx_check_launch("vx_layernorm_fp8");
 }

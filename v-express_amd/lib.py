@@ -42,6 +42,7 @@ class GemmParams(C.Structure):
         ("seq_len", C.c_int32), ("head_dim", C.c_int32), ("vt_pitch", C.c_int32),
         ("splitk", C.c_int32), ("splitk_ws", C.c_void_p),
         ("ring_hint", C.c_int32),
+        ("a_fp8", C.c_int32), ("a_scale", C.c_void_p), ("w_scale", C.c_void_p),
     ]
 
 
@@ -84,6 +85,7 @@ def _load():
     lib.vx_groupnorm_ws_floats.argtypes = [i32, i32, i32]
     lib.vx_groupnorm.argtypes = [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, i32, i32, i32, vp]
     lib.vx_layernorm.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp]
+    lib.vx_layernorm_fp8.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp, vp]
     lib.vx_attention.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp]
     lib.vx_attention_bounded.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
     lib.vx_key_norm_max.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]

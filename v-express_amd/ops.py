@@ -71,7 +71,7 @@ def _launch_gemm(p, what):
     s.record()
     L.check(_lib.vx_gemm(C.byref(p), _stream()), what)
     e.record()
-    prof.records.append((s, e, 2.0 * p.m * p.n * p.k, _tile_key(p), (p.m, p.n, p.k)))
+    prof.records.append((s, e, 2.0 * p.m * p.n * p.k, _tile_key(p), (p.m, p.n, p.k)))   # fp8: k incl. the zero padding
     # algorithmic bytes: every input row once (c1 + c2 channels), the weights once, the output once, residual once
     rows_in = p.nb * p.h_in * p.w_in
     n_out = p.n // 2 if p.epi == L.VX_EPI_GEGLU else p.n
@@ -117,8 +117,125 @@ class ConvGeom:
         return self.nb * self.h_out * self.w_out
 
 
+FP8_PROJ = [False]
+
+
+class fp8_projections:
+    """`with ops.fp8_projections(True):` - the attention q/k/v/out projections of the blocks run on the fp8 GEMM
+    (BASELINE.json configs[4]); set by UNet3DConditionModel.fp8_projections around its forward."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = FP8_PROJ[0]
+        FP8_PROJ[0] = self.on
+
+    def __exit__(self, *a):
+        FP8_PROJ[0] = self.prev
+
+
+def proj_layernorm(x, gamma, beta, eps=1e-5, **kw):
+    """LayerNorm in front of an attention projection: Fp8Rows under fp8_projections, bf16 otherwise."""
+    return layernorm_fp8(x, gamma, beta, eps, **kw) if FP8_PROJ[0] else layernorm(x, gamma, beta, eps, **kw)
+
+
+def proj_input(a):
+    """An attention output about to enter its out-projection."""
+    return quantize_fp8(a) if FP8_PROJ[0] else a
+
+
+def proj_weight(a, w):
+    """The weight operand matching the activation operand."""
+    return fp8_weight(w) if isinstance(a, Fp8Rows) else w
+
+
+class Fp8Rows:
+    """Row-quantised activations for the fp8 projection GEMMs: q uint8 [rows, Kp] (OCP e4m3 bytes, K zero-padded to a
+    multiple of 128), scale float32 [rows] (true value = q * scale), k = the unpadded width."""
+
+    def __init__(self, q, scale, k):
+        self.q, self.scale, self.k = q, scale, k
+
+    @property
+    def shape(self):
+        return (self.q.shape[0], self.k)
+
+    @property
+    def device(self):
+        return self.q.device
+
+
+class Fp8Weight:
+    """Per-output-row quantised weight: w8 uint8 [N, Kp] e4m3, scale float32 [N]."""
+
+    def __init__(self, w8, scale, k):
+        self.w8, self.scale, self.k = w8, scale, k
+
+    @property
+    def shape(self):
+        return (self.w8.shape[0], self.k)
+
+
+def pad128(k):
+    return (k + 127) // 128 * 128
+
+
+_FP8_W = {}
+
+
+def fp8_weight(w):
+    """bf16 [N, K] weight -> Fp8Weight (scale[n] = max|w[n, :]| / 448, round-to-nearest-even e4m3), cached per tensor."""
+    key = (w.data_ptr(), tuple(w.shape))
+    hit = _FP8_W.get(key)
+    if hit is None:
+        n, k = w.shape
+        wf = w.float()
+        sc = wf.abs().amax(dim=1).clamp_min(1e-30) / 448.0
+        w8 = torch.zeros((n, pad128(k)), device=w.device, dtype=torch.uint8)
+        w8[:, :k] = (wf / sc[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+        hit = _FP8_W[key] = (w, Fp8Weight(w8, sc.contiguous(), k))        # keep `w` alive: the key is its address
+    return hit[1]
+
+
+def layernorm_fp8(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_entries=1):
+    """LayerNorm (gamma=None: no normalisation, plain row quantisation) -> Fp8Rows."""
+    _chk_bf16(x, "x")
+    ldx, rows = _row_stride(x)
+    c = x.shape[-1]
+    kp = pad128(c)
+    q = torch.empty((rows, kp), device=x.device, dtype=torch.uint8)
+    sc = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    L.check(_lib.vx_layernorm_fp8(_ptr(x), ldx, rows, c, float(eps), _ptr(gamma), _ptr(beta), _ptr(add),
+                                  add_rows_per_entry, add_entries, _ptr(q), kp, _ptr(sc), _stream()),
+            "vx_layernorm_fp8")
+    return Fp8Rows(q, sc, c)
+
+
+def quantize_fp8(x):
+    return layernorm_fp8(x, None, None)
+
+
 def _base_params(a, w, geom, a2=None):
-    """a: [rows, C1] view (row stride allowed); a2 likewise; w: [N, K] bf16 contiguous."""
+    """a: [rows, C1] view (row stride allowed); a2 likewise; w: [N, K] bf16 contiguous.
+    a: Fp8Rows + w: Fp8Weight -> the fp8 GEMM (plain linears)."""
+    if isinstance(a, Fp8Rows):
+        if not isinstance(w, Fp8Weight) or a2 is not None or geom is not None:
+            raise TypeError("fp8 activations need an Fp8Weight and a plain linear (no conv geometry, one source)")
+        if a.q.shape[1] != w.w8.shape[1]:
+            raise ValueError(f"fp8 K mismatch: {a.q.shape[1]} vs {w.w8.shape[1]}")
+        p = L.GemmParams()
+        rows, kp = a.q.shape
+        p.a, p.c1, p.lda1 = a.q.data_ptr(), kp, a.q.stride(0)
+        p.a2, p.c2, p.lda2 = None, 0, 0
+        geom = ConvGeom(1, rows, 1)
+        p.nb, p.h_in, p.w_in = 1, rows, 1
+        p.kh, p.kw, p.stride, p.pad, p.upsample = 1, 1, 1, 0, 0
+        p.h_out, p.w_out = rows, 1
+        p.w, p.n, p.k, p.m = w.w8.data_ptr(), w.w8.shape[0], kp, rows
+        p.alpha = 1.0
+        p.a_fp8, p.a_scale, p.w_scale = 1, a.scale.data_ptr(), w.scale.data_ptr()
+        return p, geom
     _chk_bf16(a, "a")
     _chk_bf16(w, "w")
     p = L.GemmParams()
@@ -163,6 +280,7 @@ def clear_caches():
     to return the memory: one zero-bordered image exists per distinct (frames, H, W, C) seen so far."""
     _SPLITK_WS.clear()
     _PADDED.clear()
+    _FP8_W.clear()
 
 
 _ITEMS = [None]
@@ -241,8 +359,9 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
     p.out, p.ldc, p.out_f32 = out.data_ptr(), ldc, int(out_f32)
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be float32")
-    _splitk(p, geom, a.device, plain)
-    p.ring_hint = _ring_hint(p)
+    if not p.a_fp8:
+        _splitk(p, geom, a.device, plain)
+        p.ring_hint = _ring_hint(p)
     _launch_gemm(p, "vx_gemm")
     return out
 

@@ -183,6 +183,7 @@ class UNet3DConditionModel(_UNetBase):
             if unet_additional_kwargs.get("unet_use_temporal_attention", False):
                 raise NotImplementedError("unet_use_temporal_attention=True is dead in the reference config")
         self._kps_cache = None
+        self.fp8_projections = False
 
     @classmethod
     def from_config_2d(cls, unet_config_path, unet_additional_kwargs=None):
@@ -215,8 +216,15 @@ class UNet3DConditionModel(_UNetBase):
         out["mid_block.attentions.0"] = B.audio_kv(P["mid_block.attentions.0"], ehs)
         return out
 
-    def forward_tokens(self, x_in, timestep, ehs, kps, *, b, f, H, W, batch_rows=None, audio_kv=None,
-                       audio_zero=None, frame_shard=None):
+    def forward_tokens(self, *args, **kwargs):
+        """`_forward_tokens` under the model's fp8 switch: with `self.fp8_projections = True` the q / k / v / out
+        projections of every attention (attn1, attn1_5, attn2, both temporal attentions) run on the fp8 MFMA GEMM with
+        per-row e4m3 operands (BASELINE.json configs[4]); everything else stays bf16."""
+        with ops.fp8_projections(self.fp8_projections):
+            return self._forward_tokens(*args, **kwargs)
+
+    def _forward_tokens(self, x_in, timestep, ehs, kps, *, b, f, H, W, batch_rows=None, audio_kv=None,
+                        audio_zero=None, frame_shard=None):
         """x_in: bf16 [b*f, HW, 8] (latent channels zero-padded), ehs: bf16 [b*f*n_ctx, 768],
         kps: bf16 [b*f, HW, C0] or None -> fp32 [b*f*HW, 8] (columns >= out_channels are zero).
         batch_rows: which rows of the installed banks the b batch rows use (default 0..b-1; a lone CFG half
