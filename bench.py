@@ -42,6 +42,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0           # dense fp8 (MX K=128 forms)
 UNET_TFLOP_PER_FRAME_FWD = 1.277   # 40.86 TFLOP per CFG forward of 2x16 frames at 512^2
 VAE_TFLOP_PER_FRAME = 2.515
 
@@ -180,6 +181,8 @@ def main():
                     help="N>1: strong = the F=124 clip of BASELINE configs[3] for every N; weak = F = 12*N+4")
     ap.add_argument("--no-same-clip-1gpu", action="store_true",
                     help="N>1: skip rank 0's single-GPU run of the same clip after the timed region")
+    ap.add_argument("--fp8", action="store_true",
+                    help="BASELINE configs[4]: attention q/k/v/out projections on the fp8 (e4m3) MFMA GEMM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-shapes", default="", help="write the per-shape vx_gemm timing table of the roofline leg here")
@@ -240,6 +243,7 @@ def main():
     vae = vx.AutoencoderKLDecoder(vcfg).to(dev)
     unet.load_state_dict(synth.unet3d_state_dict(cfg, seed=42, device=dev, dtype=torch.bfloat16, draw_on_device=True))
     unet.release_raw_weights()
+    unet.fp8_projections = bool(args.fp8)
     refnet.load_state_dict(synth.refnet_state_dict(cfg, seed=43, device=dev, dtype=torch.bfloat16, draw_on_device=True))
     refnet.release_raw_weights()
     vae.load_state_dict(synth.vae_decoder_state_dict(vcfg, seed=44, device=dev, dtype=torch.bfloat16,
@@ -307,7 +311,7 @@ def main():
         "metric": f"decoded frames/sec at {args.size}x{args.size}, {args.ddim_steps} DDIM steps", "value": fps, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "fp8-proj/bf16" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": (f"{args.size}x{args.size}, {F} frames ({len(windows)} window(s) of {ctx}, overlap {ovl}), "
                                 f"{args.ddim_steps} DDIM steps, CFG 3.5, random-init UNet3D + ReferenceNet banks + "
                                 "sd-vae-ft-mse decode"),
@@ -347,7 +351,10 @@ def main():
             "avg_launch_us": 1e6 * dom[1]["seconds"] / dom[1]["launches"], "launches": dom[1]["launches"],
             "all_gemm_tflops": tot_f / tot_s / 1e12,
             "per_kernel": {k: {"launches": v["launches"], "avg_us": 1e6 * v["seconds"] / v["launches"],
-                               "tflops": v["flops"] / v["seconds"] / 1e12} for k, v in summ.items()},
+                               "tflops": v["flops"] / v["seconds"] / 1e12,
+                               # fp8 launches are priced against the dense fp8 MFMA peak (K incl. the zero padding)
+                               "frac_of_peak": v["flops"] / v["seconds"] / 1e12 /
+                               (PEAK_FP8_TFLOPS if "fp8" in k else PEAK_BF16_TFLOPS)} for k, v in summ.items()},
             "whole_path": {"tflop_per_frame": fpf, "achieved": fps * fpf / world, "frac": fps * fpf / world / PEAK_BF16_TFLOPS,
                            "note": "fps x algorithmic TFLOP/frame (SURVEY.md 8d) per GPU / 2.5 PFLOP/s"},
         }

@@ -85,6 +85,36 @@ def test_unet_forward_vs_oracle_and_golden(name):
         assert torch.equal(y[0].cpu(), got[half].float().cpu()), f"CFG half {half} is not bit-identical when run alone"
 
 
+@pytest.mark.parametrize("name", ["small_f4_8x8", "full_f4_8x8"])
+def test_unet_forward_fp8_projections_vs_golden(name):
+    """BASELINE.json configs[4] ("fp8 MFMA QKV/out-proj"): `unet.fp8_projections = True` sends the q / k / v / out
+    projections of attn1, attn1_5, attn2 and both temporal attentions through per-row e4m3 operands on
+    v_mfma_scale_f32_16x16x128_f8f6f4 (fp32 accumulation, bf16 results).  The reference has no fp8 mode; the stated
+    tolerance of this mode against the fp32 reference golden is rel-L2 <= 6e-2, cosine >= 0.998 for one CFG forward
+    (bf16 mode: 3e-2 / 0.999), and it must actually differ from the bf16 path."""
+    _need_gpu()
+    from v_express_amd import ReferenceAttentionControl, synth
+    kw, F, h, w, t = cases.FORWARD_CASES[name]
+    cfg = cases.unet_cfg(kw)
+    unet, refnet = build_models(kw, synth.unet3d_state_dict(cfg), synth.refnet_state_dict(cfg))
+    inp = synth.synthetic_inputs(cfg, F, h, w)
+    writer = ReferenceAttentionControl(refnet, do_classifier_free_guidance=True, mode="write", fusion_blocks="full")
+    reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", fusion_blocks="full",
+                                       reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD)
+    refnet(inp["ref_latents"], timestep=0, encoder_hidden_states=torch.zeros(1, 1, 768), return_dict=False)
+    reader.update(writer, True)
+    x = inp["latents"].repeat(2, 1, 1, 1, 1)
+    ehs = inp["audio_embeddings"].reshape(-1, 5, 768)
+    bf = unet(x, t, encoder_hidden_states=ehs, kps_features=inp["kps_features"], return_dict=False)[0]
+    unet.fp8_projections = True
+    got = unet(x, t, encoder_hidden_states=ehs, kps_features=inp["kps_features"], return_dict=False)[0]
+    gold = torch.load(os.path.join(GOLD, f"forward_{name}.pt"), weights_only=False)["pred"]
+    r, c = rel_l2(got, gold), cosine(got, gold)
+    print(f"[{name}] fp8 projections: relL2={r:.4g} cosine={c:.6f}   (bf16: relL2={rel_l2(bf, gold):.4g})")
+    assert torch.isfinite(got).all() and not torch.equal(got, bf)
+    assert r <= 6e-2 and c >= 0.998, (r, c)
+
+
 def test_full_size_unet_forward_vs_oracle():
     """BASELINE.json configs[1] geometry against the oracle DIRECTLY: SD-1.5 widths, 512x512 (64x64 latents: 4096 tokens,
     head dims 40 / 80 / 160), CFG batch of 2 - the shapes on which the ring GEMM, the pre-padded convs, attn2 and the
