@@ -320,3 +320,30 @@ def test_audio_encoder_directory_loader(tmp_path, monkeypatch):
     with pytest.raises(FileNotFoundError):
         (d / "model.safetensors").unlink()
         checkpoints.load_audio_encoder(str(d), device="cpu")
+
+
+def test_ring_dma_schedule_is_race_free():
+    """tools/ring_schedule_check.py replays gemm_ring_kernel's LDS-DMA issue / vmcnt / barrier schedule for both wave
+    rows and proves read-after-write and write-after-read ordering for every block length; the vmcnt immediates are
+    tight, so bumping any of them by one must be caught."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ring_schedule_check.py")
+    spec = importlib.util.spec_from_file_location("ring_schedule_check", path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for nk in (1, 2, 3, 5, 9, 10, 45, 90):
+        for tiles in (1, 2, 3, 4):
+            assert m.check(nk * tiles, nk) is None, (nk, tiles)
+    orig = m.program
+    for old, new in ((13, 14), (11, 12), (15, 16), (9, 10), (3, 4)):
+        m.program = lambda g, S, nk, o=old, n=new: [("wait", n) if e == ("wait", o) else e for e in orig(g, S, nk)]
+        assert m.check(10, 5) is not None, f"vmcnt({old}) -> vmcnt({new}) went unnoticed"
+    m.program = orig
+    # the immediates of the kernel source are the ones the checker replays
+    src = open(os.path.join(os.path.dirname(path), "..", "v-express_amd", "csrc", "vx_gemm_ring.hip")).read()
+    import re
+    in_kernel = sorted({int(v) for v in re.findall(r"RING_WAIT_VM\((\d+)\)", src)} |
+                       {int(v) for v in re.findall(r"ring_wait_vm<(\d+)>\(\)", src)})
+    in_checker = sorted({e[1] for g in (0, 1) for S, nk in ((1, 1), (2, 1), (10, 5)) for e in orig(g, S, nk)
+                         if e[0] == "wait"})
+    assert in_kernel == in_checker, (in_kernel, in_checker)

@@ -22,8 +22,9 @@
 //         L(t,2): A3(t)          -> vmcnt(9 e1 + 6 e2)       L(t,3): g0, g1 of t+1  -> vmcnt(3 e1 + 8 e2)
 //     A piece is read one L slot after the wait that retires it (wait -> barrier -> read), never in the same slot;
 //     an LDS slot is refilled at the earliest one L slot after its last read, and every L slot drains its own
-//     LDS reads (lgkmcnt(0)) before its barrier.  tools/ring_schedule_sim.cpp replays this schedule with random DMA
-//     latencies and checks every read / refill against these rules.
+//     LDS reads (lgkmcnt(0)) before its barrier.  tools/ring_schedule_check.py replays this schedule for both wave rows
+//     and proves every read / refill against these rules by barrier happens-before (CPU test
+//     tests/test_host_logic.py::test_ring_dma_schedule_is_race_free; the counts are tight: +1 on any of them fails).
 //   * epilogue: both wave rows re-align (one extra barrier each), then every lane exchanges accumulator columns with
 //     its 16-lane neighbour (v_permlane16_swap) so that it owns 8 consecutive output columns: bias / residual loads
 //     and the output stores are 16 bytes per lane.
