@@ -135,7 +135,9 @@ int vx_layernorm_fp8(const void* x, int ldx, int rows, int c, float eps, const f
  * Replaces F.scaled_dot_product_attention via diffusers AttnProcessor2_0 for attn1 / attn1_5
  * (modules/mutual_self_attention.py:177-224) and the sd-vae-ft-mse mid-block attention.
  * q: bf16 rows [batch*n_q] with row stride ldq, head h at column h*head_dim; k likewise (kv batch = batch / q_per_kv);
- * vt: bf16 [kv_batches, heads, head_dim, vt_pitch] (keys contiguous); out: bf16 rows, stride ldo. */
+ * vt: bf16 [kv_batches, heads, head_dim, vt_pitch] (keys contiguous); out: bf16 rows, stride ldo.
+ * scale = 0: K already carries scale * log2(e) (the model folds it into the to_k weights at load time, so neither
+ * operand is rounded twice): softmax_j 2^(q . k_j), no multiply in the kernel. */
 int vx_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_pitch, void* out, int ldo,
                  int batch, int heads, int n_q, int n_kv, int head_dim, int q_per_kv, float scale, void* stream);
 

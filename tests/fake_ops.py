@@ -184,11 +184,13 @@ def key_norm_max(k, *, kv_batches, heads, n_kv, head_dim):
         kv_batches, n_kv, heads, head_dim).norm(dim=-1).amax(dim=1).reshape(-1).float()
 
 
-def attention(q, k, vt, *, batch, heads, n_q, n_kv, head_dim, q_per_kv=1, out=None, kmax=None):
+def attention(q, k, vt, *, batch, heads, n_q, n_kv, head_dim, q_per_kv=1, out=None, kmax=None, k_prescaled=False):
     c = heads * head_dim
     kvb = batch // q_per_kv
     qh = q.double().reshape(batch, n_q, heads, head_dim).transpose(1, 2)
     kh = k.double().reshape(kvb, n_kv, heads, head_dim).transpose(1, 2).repeat_interleave(q_per_kv, dim=0)
+    if k_prescaled:      # k carries d^-1/2 log2(e): softmax_j 2^(q.k_j)  ==  SDPA on k * sqrt(d) * ln 2
+        kh = kh * (head_dim ** 0.5 * 0.6931471805599453)
     vh = vt[..., :n_kv].double().transpose(-1, -2).repeat_interleave(q_per_kv, dim=0)
     o = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(batch * n_q, c).to(BF16)
     if out is not None:

@@ -365,6 +365,25 @@ def test_flash_attention_softmax_rescale_path(ops):
     check(out, ref, "attention with late max spike", rel=1e-2, mx=2 ** -6)
 
 
+def test_flash_attention_prescaled_keys(ops):
+    """`k_prescaled` (vx_attention scale = 0): K carries d^-1/2 log2(e), folded into the to_k weights by
+    weights.key_fold so that neither operand is rounded twice; the kernels take q . k as the base-2 logit.  d = 40 runs
+    attn3's unit-scale body, d = 80 the plain kernel.  Reference: fp32 SDPA on the keys divided by the fold."""
+    for heads, n, d, qs in ((8, 300, 40, 1.0), (8, 300, 40, 8.0), (8, 256, 80, 1.0)):
+        c = heads * d
+        fold = d ** -0.5 * 1.4426950408889634
+        q = (rnd(2 * n, c).float() * qs).to(BF)
+        kt = (rnd(2 * n, c, seed=1).float() * qs * fold).to(BF)          # what the key projection would emit
+        v = rnd(2 * n, c, seed=2)
+        vt = ops.alloc_vt(2, heads, d, n, "cuda")
+        vt[..., :n] = v.view(2, n, heads, d).permute(0, 2, 3, 1)
+        out = ops.attention(q, kt, vt, batch=2, heads=heads, n_q=n, n_kv=n, head_dim=d, k_prescaled=True)
+        k_eff = kt.float() / fold
+        ref = _sdpa_ref(q.view(2, n, heads, d).transpose(1, 2), k_eff.view(2, n, heads, d).transpose(1, 2),
+                        v.view(2, n, heads, d).transpose(1, 2)).transpose(1, 2).reshape(2 * n, c)
+        check(out, ref, f"attention with prescaled keys d={d} qs={qs}", rel=1e-2, mx=2 ** -6)
+
+
 def test_key_norm_max(ops):
     for kvb, heads, n, d in ((3, 8, 100, 40), (1, 8, 4096, 40), (2, 4, 7, 64)):
         k = rnd(kvb * n, heads * d, seed=n)

@@ -329,9 +329,11 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, VX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
-           "--warmup", "0", "--ddim-steps", "1", "--no-cpu-baseline"]
+    # started the way the driver may start it - plain `python bench.py --gpus 2`: bench.py re-launches itself under
+    # torch.distributed.run with one rank per --gpus
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--ddim-steps", "1", "--no-cpu-baseline", "--scaling", "weak"]
+    env.pop("WORLD_SIZE", None)
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -339,6 +341,8 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["windows"] == 2 and d["config"]["frames"] == 28
     assert d["value"] > 0 and d["scaling"] == "weak" and d["roofline"]["achieved"] > 0
+    # the same clip on one rank alone, for a like-for-like multi-GPU ratio
+    assert d["same_clip_1gpu_fps"] > 0 and d["speedup_vs_1gpu_same_clip"] > 0
 
 
 @pytest.mark.parametrize("world,S,F,cf,co", [(2, 2, 8, 8, 2), (4, 0, 8, 8, 2), (4, 2, 14, 8, 2)])

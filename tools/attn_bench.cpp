@@ -106,7 +106,14 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dk, hk.data(), nk * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dvt, hvt.data(), nvt * 2, hipMemcpyHostToDevice));
     CK(hipMemset(dout, 0, nq * 2));
-    const float scale = 1.0f / sqrtf((float)s.d);
+    // ATTN_PRESCALED=1: the keys carry scale * log2(e) (what the model folds into to_k) and the kernels get scale = 0
+    const bool pre = getenv("ATTN_PRESCALED") && atoi(getenv("ATTN_PRESCALED"));
+    const float scale_true = 1.0f / sqrtf((float)s.d);
+    if (pre)
+      for (size_t i = 0; i < nk; ++i) hk[i] = f2bf(bf2f(hk[i]) * scale_true * 1.4426950408889634f);
+    if (pre) CK(hipMemcpy(dk, hk.data(), nk * 2, hipMemcpyHostToDevice));
+    const float scale = pre ? 0.0f : scale_true;
+    const double scale_ref = pre ? 0.6931471805599453 : (double)scale_true;
     float* dkm = nullptr;
     CK(hipMalloc(&dkm, sizeof(float) * kvb * s.heads));
     auto run = [&]() -> int {
@@ -136,7 +143,7 @@ int main(int argc, char** argv) {
         for (int dd = 0; dd < s.d; ++dd)
           a += (double)bf2f(hq[((size_t)b * s.nq + qi) * C + h * s.d + dd]) *
                (double)bf2f(hk[((size_t)kb * s.nkv + t) * C + h * s.d + dd]);
-        sc[t] = a * scale;
+        sc[t] = a * scale_ref;
         mx = fmax(mx, sc[t]);
       }
       double den = 0;

@@ -293,6 +293,12 @@ int main(int argc, char** argv) {
         p.residual = res; p.ldr = N;
       }
     }
+    void* skws = nullptr;
+    if (getenv("SPLITK") && atoi(getenv("SPLITK")) > 1 && p.epi == VX_EPI_STORE && K / 64 >= atoi(getenv("SPLITK"))) {
+      p.splitk = atoi(getenv("SPLITK"));   // two-launch deterministic split-K (the 8x8-level policy of ops._splitk)
+      CK(hipMalloc(&skws, (size_t)p.splitk * M * N * 4));
+      p.splitk_ws = skws;
+    }
     int rc = gemm(&p, st);
     if (rc != 0) {
       printf("%-30s launch error %d: %s\n", s.name, rc, lasterr());

@@ -69,7 +69,8 @@ def _self_attention(A, ln, h, *, seqs, n_tok, heads):
     vt = ops.alloc_vt(seqs, heads, d, n_tok, ln.device)
     ops.gemm_split(ln, ops.proj_weight(ln, A.wqkv), A.bqkv, [("rows", q), ("rows", k), ("vt", vt)], part_cols=c,
                    seq_len=n_tok, head_dim=d)
-    a = ops.attention(q, k, vt, batch=seqs, heads=heads, n_q=n_tok, n_kv=n_tok, head_dim=d)
+    a = ops.attention(q, k, vt, batch=seqs, heads=heads, n_q=n_tok, n_kv=n_tok, head_dim=d,
+                      k_prescaled=bool(A.get("k_prescaled")))
     if isinstance(ln, ops.Fp8Rows):
         a = ops.quantize_fp8(a)
     ops.gemm(a, ops.proj_weight(a, A.out.w), A.out.b, residual=h, out=h)
@@ -121,7 +122,8 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
             with ops.frame_rows(hw, items=1):          # these launches cover ONE batch item
                 q = ops.gemm(ln, ops.proj_weight(ln, P.attn1_5.wq))
                 a = ops.proj_input(ops.attention(q, kref, vtref, batch=f, heads=heads, n_q=hw, n_kv=kref.shape[0],
-                                                 head_dim=d, q_per_kv=f, kmax=kmax))
+                                                 head_dim=d, q_per_kv=f, kmax=kmax,
+                                                 k_prescaled=bool(P.attn1_5.get("k_prescaled"))))
                 ops.gemm(a, ops.proj_weight(a, P.attn1_5.out.w), P.attn1_5.out.b, residual=hb, alpha=w_ref, out=hb)
     # 2. audio cross-attention (:227-244).  A batch row whose audio tokens are ALL ZERO (the unconditional CFG half:
     # torch.zeros_like, pipelines/v_express_pipeline.py:403-405) has K = V = 0 (to_k / to_v carry no bias): every

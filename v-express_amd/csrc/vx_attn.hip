@@ -922,9 +922,11 @@ int attention_impl(const void* q, int ldq, const void* k, int ldk, const void* v
                  vt_pitch >= n_kv,
              "vx_attention: alignment (head_dim=%d ldq=%d ldk=%d pitch=%d ldo=%d)", head_dim, ldq, ldk, vt_pitch, ldo);
   VX_REQUIRE((long)batch * heads <= 65535, "vx_attention: batch*heads too large for grid.y");
+  // scale == 0: the caller folded scale * log2(e) into K - the scores are base-2 logits already (c = 1 exactly)
   AttnParams p{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)vt, vt_pitch, (bf16_t*)out, ldo,
-               batch, heads, n_q, n_kv, head_dim, q_per_kv, scale * 1.4426950408889634f, key_norm_max};
-  VX_REQUIRE(scale > 0.f, "vx_attention: scale must be positive");
+               batch, heads, n_q, n_kv, head_dim, q_per_kv, scale == 0.f ? 1.0f : scale * 1.4426950408889634f,
+               key_norm_max};
+  VX_REQUIRE(scale >= 0.f, "vx_attention: scale must be positive (or 0: K carries scale * log2 e)");
   const int d = head_dim;
   static int v1 = -1;
   if (v1 < 0) v1 = getenv("VX_ATTN_V1") != nullptr;

@@ -5,11 +5,14 @@
 //
 //   * K / V^T tiles arrive by LDS-DMA (global_load_lds_dwordx4, 10 one-KiB pieces per tile shared by the 4 waves) into a
 //     ring of NBUF stages: no staging registers, no ds_write, no address arithmetic in the loop, ONE barrier per tile.
-//   * The softmax shift is the fixed Cauchy-Schwarz bound of vx_attention_bounded, but it now rides in the MFMA: Q is
-//     pre-multiplied by scale*log2(e) and carries -m_q in the (otherwise zero) padding column d = 40, the K tile has a
-//     constant 1.0 there, so the QK^T accumulator already holds s*c - m.  Per score: one v_exp_f32 and half a
-//     v_cvt_pk_bf16_f32 - nothing else.  (m_q is rounded to bf16: a per-query constant factor on every probability of
-//     the row, which the normalisation removes; row sums come from the ones row of V^T as in attn2.)
+//   * The softmax shift is the fixed Cauchy-Schwarz bound of vx_attention_bounded, but it now rides in the MFMA: Q
+//     carries -m_q in the (otherwise zero) padding column d = 40 and the K tile has a constant 1.0 there, so the QK^T
+//     accumulator already holds s - m.  When the caller has folded scale*log2(e) into K (vx_attention scale = 0: the
+//     model folds it into the key projection weights, so no operand is rounded twice) a score costs one v_exp_f32 and
+//     half a v_cvt_pk_bf16_f32 - nothing else; otherwise one v_mul_f32 more (Q is NOT pre-multiplied in bf16: that
+//     second rounding of q costs ~0.1 log2 units per score at |logit| ~ 50 and showed in the large-logit tests).
+//     (m_q is rounded to bf16: a per-query constant factor on every probability of the row, which the normalisation
+//     removes; row sums come from the ones row of V^T as in attn2.)
 //   * Keys are permuted inside a tile on the DMA source side (LDS row r holds key pi(r) = 32(r>>5) + 8((r>>2)&3) +
 //     4((r>>4)&1) + (r&3)) so that the 8 P^T values a lane owns after two S^T tiles are 8 CONSECUTIVE keys: the V^T
 //     A-operand is one ds_read_b128 per MFMA instead of two ds_read_b64.
@@ -23,6 +26,15 @@
 #include <stdlib.h>
 
 #include <type_traits>
+
+// Compile-time ablation switches (tools/exp_attn3_ablate.sh builds one library per mask with -DVX_ATTN3_ABLATE=mask;
+// never defined for the product library): 1 no exponentials, 2 no PV MFMAs, 4 no QK^T MFMAs, 8 no DMA after the
+// prologue (and no waits), 16 no barriers in the key loop, 32 LDS fragment reads hoisted out (one stage-0 read).
+#ifdef VX_ATTN3_ABLATE
+#define A3ABL(bit) (((VX_ATTN3_ABLATE) & (bit)) != 0)
+#else
+#define A3ABL(bit) false
+#endif
 
 namespace {
 
@@ -45,7 +57,7 @@ constexpr int A3_QT = 2;                  // 16-query tiles per wave (32 queries
 
 __device__ __forceinline__ int a3_pi(int r) { return 32 * (r >> 5) + 8 * ((r >> 2) & 3) + 4 * ((r >> 4) & 1) + (r & 3); }
 
-template <int NBUF, bool PIPE>
+template <int NBUF, bool PIPE, bool UNIT>   // UNIT: p.c == 1 (K already carries scale * log2 e)
 __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Params p) {
   static_assert(!PIPE || NBUF == 3, "the pipelined loop needs three stages");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -116,6 +128,7 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
   }
   const uint32_t lds0 = lds_addr_of(smem);
   auto issue = [&](int t) {
+    if (A3ABL(8) && t >= NBUF) return;
     const uint32_t so = lds0 + (uint32_t)(t % NBUF) * A3_STAGE;
     const bool edge = ragged && t == n_tiles - 1;
 #pragma unroll
@@ -128,6 +141,7 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
   };
   // all of this wave's pieces except those of the newest `keep` tiles have landed
   auto wait_dma = [&](bool keep_newest) {
+    if (A3ABL(8)) return;
     if (!keep_newest) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (wave < 2) {
@@ -137,7 +151,8 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
     }
   };
 
-  // ---- Q fragments, pre-multiplied by c; kk = 1 holds d 32..39 (g = 0), the shift column (g = 1), zeros (g >= 2)
+  // ---- Q fragments (raw); kk = 1 holds d 32..39 (g = 0), the shift column (g = 1), zeros (g >= 2).  The shift and
+  // the accumulators are in units of q.k; the exponent is c * (q.k - m)
   uint4 qf[A3_QT][2];
   float mfix[A3_QT];
 #pragma unroll
@@ -152,10 +167,6 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
         v = *reinterpret_cast<const uint4*>(p.q + (size_t)(b * p.n_q + qrow) * p.ldq + h * A3_D + dcol);
         float f[8];
         unpack_bf16x8(v, f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] *= p.c;
-        v = pack_bf16x8(f);
-        unpack_bf16x8(v, f);          // the norm of the values the MFMA will actually see
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
       }
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
 
   // S^T (already shifted) of key tile t
   auto qk = [&](f32x4_t (&s_)[4][A3_QT], int t) {
-    const int so = (t % NBUF) * A3_STAGE;
+    const int so = A3ABL(32) ? 0 : (t % NBUF) * A3_STAGE;
     const char* k0 = smem + a_k0 + so;
     const char* k1 = smem + a_k1 + so * k1_stage;
 #pragma unroll
@@ -198,6 +209,11 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
       const uint4 kf1 = *reinterpret_cast<const uint4*>(k1 + kt * 256);
 #pragma unroll
       for (int qt = 0; qt < A3_QT; ++qt) {
+        if (A3ABL(4)) {
+          s_[kt][qt] = f32x4_t{-1.f, -2.f, -3.f, -4.f};
+          asm volatile("" ::"v"(kf0.x), "v"(kf1.x));
+          continue;
+        }
         s_[kt][qt] = mfma16(kf0, qf[qt][0], f32x4_t{0.f, 0.f, 0.f, 0.f});
         s_[kt][qt] = mfma16(kf1, qf[qt][1], s_[kt][qt]);
       }
@@ -220,11 +236,14 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
 #pragma unroll
       for (int qt = 0; qt < A3_QT; ++qt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_[kt][qt][r] = __builtin_amdgcn_exp2f(s_[kt][qt][r]);
+        for (int r = 0; r < 4; ++r) {
+          if (A3ABL(1)) continue;
+          s_[kt][qt][r] = __builtin_amdgcn_exp2f(UNIT ? s_[kt][qt][r] : s_[kt][qt][r] * p.c);
+        }
   };
   // O^T += V^T(t) P^T
   auto pv = [&](const f32x4_t (&s_)[4][A3_QT], int t) {
-    const int so = (t % NBUF) * A3_STAGE;
+    const int so = A3ABL(32) ? 0 : (t % NBUF) * A3_STAGE;
 #pragma unroll
     for (int ks_ = 0; ks_ < 2; ++ks_) {
       uint4 pb[A3_QT];
@@ -240,7 +259,13 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
       for (int dt = 0; dt < 3; ++dt) {
         const uint4 vf = *reinterpret_cast<const uint4*>(vp + dt * 2048);
 #pragma unroll
-        for (int qt = 0; qt < A3_QT; ++qt) o[dt][qt] = mfma16(vf, pb[qt], o[dt][qt]);
+        for (int qt = 0; qt < A3_QT; ++qt) {
+          if (A3ABL(2)) {
+            asm volatile("" ::"v"(vf.x), "v"(pb[qt].x), "v"(pb[qt].w));
+            continue;
+          }
+          o[dt][qt] = mfma16(vf, pb[qt], o[dt][qt]);
+        }
       }
     }
   };
@@ -264,7 +289,7 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
         if (ragged && t == n_tiles - 1) mask(cur, t);
         if (HAS_NEXT) {
           wait_dma(false);
-          __syncthreads();                 // tile t+1 landed; every wave is done with tile t-1 (= the stage of tile t+2)
+          if (!A3ABL(16)) __syncthreads(); // tile t+1 landed; every wave is done with tile t-1 (= the stage of tile t+2)
           if (t + 2 < n_tiles) issue(t + 2);
           qk(nxt, t + 1);
         }
@@ -285,7 +310,7 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
     } else {
       for (int t = 0; t < n_tiles; ++t) {
         wait_dma(NBUF == 3 && t + 1 < n_tiles);
-        __syncthreads();                   // tile t landed for everyone; everyone is done with tile t-1
+        if (!A3ABL(16)) __syncthreads();   // tile t landed for everyone; everyone is done with tile t-1
         if (t + NBUF - 1 < n_tiles) issue(t + NBUF - 1);
         f32x4_t cur[4][A3_QT];
         qk(cur, t);
@@ -351,10 +376,10 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
   }
 }
 
-template <int NBUF, bool PIPE>
+template <int NBUF, bool PIPE, bool UNIT>
 int launch_attn3(const Attn3Params& p, hipStream_t stream) {
   constexpr int smem = NBUF * A3_STAGE + 2048;
-  auto kern = attn3_kernel<NBUF, PIPE>;
+  auto kern = attn3_kernel<NBUF, PIPE, UNIT>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -386,9 +411,10 @@ int vx_attn3_launch(const void* q, int ldq, const void* k, int ldk, const void* 
                     hipStream_t stream) {
   Attn3Params p{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)vt, vt_pitch, (bf16_t*)out, ldo,
                 batch, heads, n_q, n_kv, q_per_kv, c, kmax};
+  const bool unit = c == 1.0f;
   switch (vx_attn3_variant()) {
-    case 1: return launch_attn3<2, false>(p, stream);
-    case 3: return launch_attn3<3, true>(p, stream);
-    default: return launch_attn3<3, false>(p, stream);
+    case 1: return unit ? launch_attn3<2, false, true>(p, stream) : launch_attn3<2, false, false>(p, stream);
+    case 3: return unit ? launch_attn3<3, true, true>(p, stream) : launch_attn3<3, true, false>(p, stream);
+    default: return unit ? launch_attn3<3, false, true>(p, stream) : launch_attn3<3, false, false>(p, stream);
   }
 }

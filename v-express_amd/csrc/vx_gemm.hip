@@ -670,6 +670,21 @@ bool use_big(const vx_gemm_params& p) {
   return tiles >= 256;
 }
 
+// 64 x 160 tile, 2 waves, 3 stages: launches whose 128-row tiling would leave CUs without a block (the 8x8 level of a
+// 16-frame window: M = 2048 -> 128 tiles of 128 x 160 for N = 1280).  Which tile a launch gets never changes its
+// results: every tile shape accumulates an output element over the K-tiles in the same order with the same MFMA.
+// VX_GEMM_SMALL64=0 disables (A/B measurements).
+bool use_small64(const vx_gemm_params& p) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("VX_GEMM_SMALL64");
+    on = !(e && !strcmp(e, "0"));
+  }
+  if (!on || !prefer160(p.n) || p.out_f32) return false;
+  const long tiles128 = (long)ceil_div(p.m, 128) * ceil_div(p.n, 160) * (p.splitk > 1 ? p.splitk : 1);
+  return tiles128 < 256 && fast_ok(p);
+}
+
 }  // namespace
 
 extern "C" int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk) {
@@ -691,6 +706,7 @@ extern "C" const char* vx_gemm_config_name(const vx_gemm_params* pp) {
     return p.epi == VX_EPI_GEGLU ? "gemm_ring_kernel<256x320x64,8w,GEGLU,fast>" : "gemm_ring_kernel<256x320x64,8w,STORE,fast>";
   if (p.epi == VX_EPI_STORE && p.n <= 32) tile = "256x32x64,4w";
   else if (use_big(p)) tile = "256x320x64,8w";
+  else if (p.epi == VX_EPI_STORE && use_small64(p)) tile = "64x160x64,2w";
   else if (p.epi != VX_EPI_GEGLU && prefer160(p.n)) tile = "128x160x64,4w";
   else tile = "128x128x64,4w";
   static thread_local char buf[96];
@@ -746,6 +762,7 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
     if (vx_gemm_ring_eligible(p)) return vx_gemm_ring_launch(p, stream);
     if (p.n <= 32) return launch<256, 32, 4, 1, 2, VX_EPI_STORE>(p, stream);
     if (use_big(p)) return launch<256, 320, 4, 2, 2, VX_EPI_STORE>(p, stream);
+    if (use_small64(p)) return launch<64, 160, 1, 2, 3, VX_EPI_STORE>(p, stream);
     if (prefer160(p.n)) return launch<128, 160, 2, 2, 2, VX_EPI_STORE>(p, stream);
     return launch<128, 128, 2, 2, 2, VX_EPI_STORE>(p, stream);
   } else if (p.epi == VX_EPI_GEGLU) {

@@ -264,6 +264,9 @@ def _base_params(a, w, geom, a2=None):
 
 
 _SPLITK_WS = {}
+# split-K policy knobs (A/B measurements): rows of the tile the launch will get and the block count to aim for
+_SPLITK_ROWS = int(os.environ.get("VX_SPLITK_ROWS", "128"))
+_SPLITK_TARGET = int(os.environ.get("VX_SPLITK_TARGET", "512"))
 _FRAME_ROWS = [None]
 
 
@@ -324,8 +327,8 @@ def _splitk(p, geom, device, plain):
     hw = _FRAME_ROWS[0] if plain else geom.h_out * geom.w_out
     if hw is None or hw > 64 or p.k < 1024:
         return
-    tiles = 16 * -(-p.n // 160)                      # nominal 32-frame launch
-    s = min(-(-512 // tiles), 8, nk // 4)
+    tiles = (2048 // _SPLITK_ROWS) * -(-p.n // 160)    # nominal 32-frame launch (2048 rows at the 8x8 level)
+    s = min(-(-_SPLITK_TARGET // tiles), 8, nk // 4)
     if s < 2:
         return
     nbytes = int(_lib.vx_gemm_splitk_ws_bytes(p.m, p.n, s))
@@ -486,23 +489,26 @@ def key_norm_max(k, *, kv_batches, heads, n_kv, head_dim):
     return out
 
 
-def attention(q, k, vt, *, batch, heads, n_q, n_kv, head_dim, q_per_kv=1, out=None, kmax=None):
+def attention(q, k, vt, *, batch, heads, n_q, n_kv, head_dim, q_per_kv=1, out=None, kmax=None, k_prescaled=False):
     """q: [batch*n_q, *] view; k: [kv_batches*n_kv, *] view; vt: [kv_batches, heads, head_dim, pitch].
+    k_prescaled: k already carries head_dim^-1/2 * log2(e) (weights.key_fold): the kernels take q . k as the base-2
+    logit (vx_attention scale = 0).
     The 64x64 level's head dim (32 < d <= 48, not a multiple of 16: SD-1.5's d = 40) runs the bounded-softmax kernel
     (vx_attention_bounded; `kmax` = a precomputed key_norm_max of k, e.g. of a step-invariant reference bank)."""
     ldq, _ = _row_stride(q)
     ldk, _ = _row_stride(k)
     if out is None:
         out = torch.empty((batch * n_q, heads * head_dim), device=q.device, dtype=BF16)
+    scale = 0.0 if k_prescaled else head_dim ** -0.5
     if _BOUNDED_SOFTMAX[0] and 32 < head_dim <= 48 and head_dim % 16:
         if kmax is None:
             kmax = key_norm_max(k, kv_batches=batch // q_per_kv, heads=heads, n_kv=n_kv, head_dim=head_dim)
         L.check(_lib.vx_attention_bounded(_ptr(q), ldq, _ptr(k), ldk, _ptr(vt), vt.shape[-1], _ptr(out),
                                           _row_stride(out)[0], batch, heads, n_q, n_kv, head_dim, q_per_kv,
-                                          head_dim ** -0.5, _ptr(kmax), _stream()), "vx_attention_bounded")
+                                          scale, _ptr(kmax), _stream()), "vx_attention_bounded")
         return out
     L.check(_lib.vx_attention(_ptr(q), ldq, _ptr(k), ldk, _ptr(vt), vt.shape[-1], _ptr(out), _row_stride(out)[0],
-                              batch, heads, n_q, n_kv, head_dim, q_per_kv, head_dim ** -0.5, _stream()),
+                              batch, heads, n_q, n_kv, head_dim, q_per_kv, scale, _stream()),
             "vx_attention")
     return out
 

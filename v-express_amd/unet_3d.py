@@ -123,14 +123,14 @@ class _UNetBase(DeviceModule):
             for j, _ in enumerate(blk["layers"]):
                 add_resnet(f"{p}.resnets.{j}")
                 if blk["attn"]:
-                    P[f"{p}.attentions.{j}"] = spatial(sd, f"{p}.attentions.{j}", dev)
+                    P[f"{p}.attentions.{j}"] = spatial(sd, f"{p}.attentions.{j}", dev, cfg.heads)
                 if self.THREE_D:
                     P[f"{p}.motion_modules.{j}"] = Wt.prep_motion(sd, f"{p}.motion_modules.{j}", dev)
             if blk["sampler"]:
                 name = "downsamplers" if p.startswith("down") else "upsamplers"
                 P[f"{p}.{name}.0"] = Wt.prep_conv(sd, f"{p}.{name}.0.conv", dev)
         add_resnet("mid_block.resnets.0")
-        P["mid_block.attentions.0"] = spatial(sd, "mid_block.attentions.0", dev)
+        P["mid_block.attentions.0"] = spatial(sd, "mid_block.attentions.0", dev, cfg.heads)
         if self.THREE_D:
             P["mid_block.motion_modules.0"] = Wt.prep_motion(sd, "mid_block.motion_modules.0", dev)
         add_resnet("mid_block.resnets.1")

@@ -58,30 +58,55 @@ def prep_norm(sd, p, device):
     return Prepared(g=_dev(sd[p + ".weight"], device, torch.float32), b=_dev(sd[p + ".bias"], device, torch.float32))
 
 
-def _cat_w(sd, keys, device):
-    return torch.cat([sd[k].detach().to(device=device, dtype=BF16) for k in keys], dim=0).contiguous()
+LOG2E = 1.4426950408889634
 
 
-def _cat_b(sd, keys, device):
+def _cat_w(sd, keys, device, scales=None):
+    """Row-concatenated bf16 weight; scales[i] (optional) multiplies tensor i in float32 BEFORE the one bf16 rounding."""
+    parts = []
+    for i, k in enumerate(keys):
+        w = sd[k].detach().to(device=device, dtype=torch.float32)
+        if scales is not None and scales[i] != 1.0:
+            w = w * scales[i]
+        parts.append(w.to(BF16))
+    return torch.cat(parts, dim=0).contiguous()
+
+
+def _cat_b(sd, keys, device, scales=None):
     if keys[0] not in sd:
         return None
-    return torch.cat([sd[k].detach().to(device=device, dtype=torch.float32) for k in keys], dim=0).contiguous()
+    parts = [sd[k].detach().to(device=device, dtype=torch.float32) * (1.0 if scales is None else scales[i])
+             for i, k in enumerate(keys)]
+    return torch.cat(parts, dim=0).contiguous()
 
 
-def prep_self_attn(sd, p, device):
-    """diffusers Attention used as self-attention: fused QKV + out projection."""
+def key_fold(c, heads):
+    """Factor folded into the to_k weights of an attention with `heads` heads over `c` channels: softmax scale
+    d^-1/2 times log2(e), so that the kernels take q . k as the base-2 logit (vx_attention scale = 0) and neither
+    operand is rounded to bf16 twice."""
+    return (c // heads) ** -0.5 * LOG2E
+
+
+def prep_self_attn(sd, p, device, heads=None):
+    """diffusers Attention used as self-attention: fused QKV + out projection.  heads: fold the softmax scale into the
+    key rows (`k_prescaled`)."""
     names = ["to_q", "to_k", "to_v"]
-    return Prepared(wqkv=_cat_w(sd, [f"{p}.{n}.weight" for n in names], device),
-                    bqkv=_cat_b(sd, [f"{p}.{n}.bias" for n in names], device),
-                    out=prep_linear(sd, p + ".to_out.0", device))
+    scales = None
+    if heads is not None:
+        scales = [1.0, key_fold(sd[f"{p}.to_k.weight"].shape[0], heads), 1.0]
+    return Prepared(wqkv=_cat_w(sd, [f"{p}.{n}.weight" for n in names], device, scales),
+                    bqkv=_cat_b(sd, [f"{p}.{n}.bias" for n in names], device, scales),
+                    out=prep_linear(sd, p + ".to_out.0", device), k_prescaled=heads is not None)
 
 
-def prep_cross_attn(sd, p, device):
-    """Attention whose K/V come from another sequence: Q alone, fused KV, out projection."""
+def prep_cross_attn(sd, p, device, heads=None):
+    """Attention whose K/V come from another sequence: Q alone, fused KV, out projection.  heads: as prep_self_attn
+    (the fused K | V weight only; `wk` stays unscaled)."""
+    scales = None if heads is None else [key_fold(sd[p + ".to_k.weight"].shape[0], heads), 1.0]
     return Prepared(wq=_dev(sd[p + ".to_q.weight"], device, BF16),
                     wk=_dev(sd[p + ".to_k.weight"], device, BF16),
-                    wkv=_cat_w(sd, [p + ".to_k.weight", p + ".to_v.weight"], device),
-                    out=prep_linear(sd, p + ".to_out.0", device))
+                    wkv=_cat_w(sd, [p + ".to_k.weight", p + ".to_v.weight"], device, scales),
+                    out=prep_linear(sd, p + ".to_out.0", device), k_prescaled=heads is not None)
 
 
 GEGLU_BLOCK = 8   # one 16-column MFMA fragment = 8 value columns + their 8 gate columns (vx_gemm GEGLU epilogue)
@@ -112,23 +137,25 @@ def prep_resnet(sd, p, device):
     return r
 
 
-def prep_spatial_read(sd, p, device):
-    """Transformer3DModel + TemporalBasicTransformerBlock (attn1, attn1_5, attn2, ff)."""
+def prep_spatial_read(sd, p, device, heads=None):
+    """Transformer3DModel + TemporalBasicTransformerBlock (attn1, attn1_5, attn2, ff).  heads: fold the softmax scale
+    into the key weights of the two flash-attention users (attn1, attn1_5)."""
     t = p + ".transformer_blocks.0"
     return Prepared(norm=prep_norm(sd, p + ".norm", device), proj_in=prep_linear(sd, p + ".proj_in", device),
                     proj_out=prep_linear(sd, p + ".proj_out", device),
-                    norm1=prep_norm(sd, t + ".norm1", device), attn1=prep_self_attn(sd, t + ".attn1", device),
-                    norm1_5=prep_norm(sd, t + ".norm1_5", device), attn1_5=prep_cross_attn(sd, t + ".attn1_5", device),
+                    norm1=prep_norm(sd, t + ".norm1", device), attn1=prep_self_attn(sd, t + ".attn1", device, heads),
+                    norm1_5=prep_norm(sd, t + ".norm1_5", device),
+                    attn1_5=prep_cross_attn(sd, t + ".attn1_5", device, heads),
                     norm2=prep_norm(sd, t + ".norm2", device), attn2=prep_cross_attn(sd, t + ".attn2", device),
                     norm3=prep_norm(sd, t + ".norm3", device), ff=prep_ff(sd, t + ".ff", device))
 
 
-def prep_spatial_write(sd, p, device):
+def prep_spatial_write(sd, p, device, heads=None):
     """Transformer2DModel + BasicTransformerBlock of the ReferenceNet (attn1, attn2, ff)."""
     t = p + ".transformer_blocks.0"
     return Prepared(norm=prep_norm(sd, p + ".norm", device), proj_in=prep_linear(sd, p + ".proj_in", device),
                     proj_out=prep_linear(sd, p + ".proj_out", device),
-                    norm1=prep_norm(sd, t + ".norm1", device), attn1=prep_self_attn(sd, t + ".attn1", device),
+                    norm1=prep_norm(sd, t + ".norm1", device), attn1=prep_self_attn(sd, t + ".attn1", device, heads),
                     norm2=prep_norm(sd, t + ".norm2", device), attn2=prep_cross_attn(sd, t + ".attn2", device),
                     norm3=prep_norm(sd, t + ".norm3", device), ff=prep_ff(sd, t + ".ff", device))
 
