@@ -396,12 +396,15 @@ int launch_attn3(const Attn3Params& p, hipStream_t stream) {
 
 }  // namespace
 
-// variant: 0 = off (attn2), 1 = NBUF 2, 2 = NBUF 3, 3 = NBUF 3 + in-wave pipeline.  Default from VX_ATTN3 (else 2).
+// variant: 0 = off (attn2), 1 = NBUF 2 (default), 2 = NBUF 3, 3 = NBUF 3 + in-wave pipeline; VX_ATTN3 overrides.
+// The three variants measure within 3 % of each other (profiles/r02a_attn_bench.txt, r02b_attn3_ablation.txt): the
+// kernel is matrix-pipe / power bound (SQ_VALU_MFMA_BUSY_CYCLES = 61 % of the SIMD cycles at an effective 1.66 GHz,
+// profiles/r02b_attn3_pmc.txt), so neither the ring depth nor the in-wave overlap of exp and MFMA moves it.
 int vx_attn3_variant() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("VX_ATTN3");
-    v = e ? atoi(e) : 2;
+    v = e ? atoi(e) : 1;
   }
   return v;
 }
@@ -413,8 +416,8 @@ int vx_attn3_launch(const void* q, int ldq, const void* k, int ldk, const void* 
                 batch, heads, n_q, n_kv, q_per_kv, c, kmax};
   const bool unit = c == 1.0f;
   switch (vx_attn3_variant()) {
-    case 1: return unit ? launch_attn3<2, false, true>(p, stream) : launch_attn3<2, false, false>(p, stream);
+    case 2: return unit ? launch_attn3<3, false, true>(p, stream) : launch_attn3<3, false, false>(p, stream);
     case 3: return unit ? launch_attn3<3, true, true>(p, stream) : launch_attn3<3, true, false>(p, stream);
-    default: return unit ? launch_attn3<3, false, true>(p, stream) : launch_attn3<3, false, false>(p, stream);
+    default: return unit ? launch_attn3<2, false, true>(p, stream) : launch_attn3<2, false, false>(p, stream);
   }
 }

@@ -325,7 +325,10 @@ def _splitk(p, geom, device, plain):
     sums in the same order as the batched call (bit-identical)."""
     nk = -(-p.k // 64)
     hw = _FRAME_ROWS[0] if plain else geom.h_out * geom.w_out
-    if hw is None or hw > 64 or p.k < 1024:
+    # K < 2560 (the 1x1 / linear layers of the 8x8 level): one launch on the 64 x 160 tile (vx_gemm picks it when the
+    # 128-row tiling leaves CUs idle) beats split-K + reduce: 21.1 vs 27.4 us at 2048 x 1280 x 1280
+    # (profiles/r02b_gemm_small.txt); the long-K 3x3 convs keep the split (77.7 vs 122.7 us)
+    if hw is None or hw > 64 or p.k < 2560:
         return
     tiles = (2048 // _SPLITK_ROWS) * -(-p.n // 160)    # nominal 32-frame launch (2048 rows at the 8x8 level)
     s = min(-(-_SPLITK_TARGET // tiles), 8, nk // 4)
