@@ -72,12 +72,22 @@ def test_gemm_split_k(ops):
     half = ops.gemm(x[:3].reshape(-1, cin), w2d, bias, geom=ops.ConvGeom(3, H + 2, W + 2, 3, 3, 1, 0),
                     residual=res[:3 * H * W], alpha=0.9, act=L.VX_ACT_SILU)
     assert torch.equal(half, out[:3 * H * W])
-    # plain linear under the frame_rows hint, f32 output
-    a, w = rnd(2 * 64, 1280), rnd(320, 1280, scale=1280 ** -0.5, seed=4)
+    # plain linear under the frame_rows hint, f32 output: K >= 2560 splits ...
+    a, w = rnd(2 * 64, 2560), rnd(320, 2560, scale=2560 ** -0.5, seed=4)
     with ops.frame_rows(64), ops.GemmProfile() as prof:
         o2 = ops.gemm(a, w, bias, out_f32=True)
     assert "splitk" in prof.records[0][3]
     check(o2, a.float() @ w.float().t() + bias, "split-K linear f32", rel=1e-4, mx=1e-4)
+    # ... K < 2560 runs unsplit on the 64 x 160 two-wave tile (bf16 output; f32 output keeps the 128-row tiles)
+    a, w = rnd(32 * 64, 1280), rnd(1280, 1280, scale=1280 ** -0.5, seed=5)
+    b2, r2 = rnd(1280, seed=6, dtype=torch.float32), rnd(32 * 64, 1280, seed=7)
+    with ops.frame_rows(64), ops.GemmProfile() as prof:
+        o3 = ops.gemm(a, w, b2, residual=r2)
+    assert "splitk" not in prof.records[0][3] and "64x160" in prof.records[0][3], prof.records[0][3]
+    check(o3, r2.float() + a.float() @ w.float().t() + b2, "8x8-level linear on the 64x160 tile")
+    with ops.frame_rows(64):
+        half3 = ops.gemm(a[:16 * 64], w, b2, residual=r2[:16 * 64])
+    assert torch.equal(half3, o3[:16 * 64])
 
 
 def _ring_used(prof):
@@ -597,6 +607,27 @@ def test_gemm_fp8_store_and_split(ops, m, n, k):
             check(kk, ref[:, c:2 * c].float(), "fp8 split k")
             v_ref = ref[:, 2 * c:].float().view(m // seq, seq, heads, d).permute(0, 2, 3, 1)
             check(vt[..., :seq], v_ref, "fp8 split v^T")
+
+
+def test_gemm_fp8_ring_vs_classic_tiles(ops):
+    """The persistent ring kernel's fp8 instantiation (default for eligible STORE launches) against the classic fp8 tiles
+    (ring mode 0) and the float64 reference of the dequantised operands, with and without a residual."""
+    from v_express_amd import lib as L
+    m, n, k = 256 * 200, 640, 640
+    a8, w8 = ops.quantize_fp8(rnd(m, k, seed=1)), ops.fp8_weight(rnd(n, k, scale=k ** -0.5, seed=2))
+    bias, res = rnd(n, seed=3, dtype=torch.float32), rnd(m, n, seed=4)
+    ref = _deq(a8.q, a8.scale).double() @ _deq(w8.w8, w8.scale).double().t() + bias.double()
+    outs = {}
+    try:
+        for mode in (2, 0):
+            L.check(L.lib.vx_gemm_set_ring_mode(mode), "ring mode")
+            outs[mode] = (ops.gemm(a8, w8, bias), ops.gemm(a8, w8, bias, residual=res, alpha=0.5))
+    finally:
+        L.check(L.lib.vx_gemm_set_ring_mode(2), "ring mode")
+    for mode, (plain, with_res) in outs.items():
+        check(plain, ref.float(), f"fp8 gemm ring mode {mode}")
+        check(with_res, (res.double() + 0.5 * ref).float(), f"fp8 gemm + residual, ring mode {mode}")
+    assert torch.allclose(outs[2][0].float(), outs[0][0].float(), rtol=2e-2, atol=1e-3)
 
 
 def test_gemm_fp8_rejects_what_it_does_not_support(ops):

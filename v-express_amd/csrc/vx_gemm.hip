@@ -698,6 +698,7 @@ extern "C" const char* vx_gemm_config_name(const vx_gemm_params* pp) {
   const char* tile;
   if (p.a_fp8) {
     static thread_local char b8[96];
+    if (p.epi == VX_EPI_STORE && vx_gemm_ring_eligible(p)) return "gemm_ring_kernel<256x320x128,8w,STORE,fast,fp8>";
     const bool big8 = (p.n % 320) == 0 && (long)ceil_div(p.m, 256) * (p.n / 320) >= 256;
     snprintf(b8, sizeof(b8), "gemm_kernel<%s,%s,fast,fp8>", big8 ? "256x320x128,8w" : "128x160x128,4w", epi);
     return b8;
@@ -751,6 +752,7 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
       VX_REQUIRE(p.out != nullptr && (p.ldc % 8) == 0, "vx_gemm: STORE needs out and ldc%%8==0");
       VX_REQUIRE(p.residual == nullptr || (p.ldr % 8) == 0, "vx_gemm: ldr%%8");
       VX_REQUIRE(p.rowbias == nullptr || p.rows_per_group > 0, "vx_gemm: rows_per_group");
+      if (vx_gemm_ring_eligible(p)) return vx_gemm_ring_launch(p, stream);
       if (big) return launch_impl<256, 320, 4, 2, 2, VX_EPI_STORE, true, true>(p, stream);
       return launch_impl<128, 160, 2, 2, 2, VX_EPI_STORE, true, true>(p, stream);
     }

@@ -93,8 +93,22 @@ __device__ __forceinline__ void swap16(float& x, float& y) {
   y = __uint_as_float(r[1]);
 }
 
-template <int EPI, bool RES>   // RES: STORE epilogue with a residual addend
+// F8 (round 2): e4m3 operands of the fp8 projection GEMMs (vx_gemm_params.a_fp8): a K-tile is still one 128-byte LDS
+// row per operand row = 128 elements, the two 16-byte fragment reads of a lane form ONE K = 128
+// v_mfma_scale_f32_16x16x128_f8f6f4 operand (unit block scales) instead of feeding two bf16 MFMAs, so the M slots
+// halve while the DMA schedule, the stagger and every vmcnt count stay what tools/ring_schedule_check.py proves.
+typedef int ring_i32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4_t ring_mfma_f8(const uint4& a_lo, const uint4& a_hi, const uint4& b_lo, const uint4& b_hi,
+                                                f32x4_t c) {
+  const ring_i32x8_t a = {(int)a_lo.x, (int)a_lo.y, (int)a_lo.z, (int)a_lo.w, (int)a_hi.x, (int)a_hi.y, (int)a_hi.z, (int)a_hi.w};
+  const ring_i32x8_t b = {(int)b_lo.x, (int)b_lo.y, (int)b_lo.z, (int)b_lo.w, (int)b_hi.x, (int)b_hi.y, (int)b_hi.z, (int)b_hi.w};
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+template <int EPI, bool RES, bool F8 = false>   // RES: STORE epilogue with a residual addend
 __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params p) {
+  constexpr int ES = F8 ? 1 : 2;      // bytes per operand element
+  constexpr int BKE = 128 / ES;       // elements per K-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
   const int G = gridDim.x;
   const int lb = xcd_remap(blockIdx.x, G);
   const int my_tiles = (total_tiles - lb + G - 1) / G;
-  const int nk = p.k >> 6;
+  const int nk = p.k / BKE;
   const int S = my_tiles * nk;   // K-tile sequence length of this block
 
   const char* __restrict__ A1 = (const char*)p.a;
@@ -122,7 +136,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
   const int cin = p.c1 + p.c2, c1 = p.c1;
   const int kw = p.kw, kh = p.kh, w_in = p.w_in;
   const int hw_out = p.h_out * p.w_out;
-  const uint32_t lda1b = (uint32_t)p.lda1 * 2u, lda2b = (uint32_t)p.lda2 * 2u;
+  const uint32_t lda1b = (uint32_t)p.lda1 * (uint32_t)ES, lda2b = (uint32_t)p.lda2 * (uint32_t)ES;
   const bool is_conv = !(kh == 1 && kw == 1 && p.stride == 1 && p.h_in == p.h_out && p.w_in == p.w_out);
 
   // ---- DMA coordinates: thread (r0, slot) of a piece; the LDS image is lane-linear, so the XOR swizzle is applied to
@@ -130,8 +144,8 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
   const int r0 = tid >> 3;
   const int cc = (tid & 7) ^ ((r0 >> 1) & 7);
   const uint32_t lds_wave = lds_addr_of(smem) + wave * 1024;
-  const uint32_t boff = (uint32_t)r0 * (uint32_t)p.k * 2u + (uint32_t)cc * 16u;   // + q * 64 rows (wave-uniform)
-  const long b_piece_stride = (long)p.k * 128;                                       // 64 weight rows
+  const uint32_t boff = (uint32_t)r0 * (uint32_t)p.k * (uint32_t)ES + (uint32_t)cc * 16u;   // + q * 64 rows (wave-uniform)
+  const long b_piece_stride = (long)p.k * 64 * ES;                                   // 64 weight rows
   // Input pixel of this thread's row in A piece q, RELATIVE to the first row of the output tile.  The eligibility
   // test guarantees that a 256-row tile is either a whole number of frames or a whole number of image rows of one
   // frame, so the relative pixel is the same for every tile and only a wave-uniform base changes per tile.
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
   auto setup_issue_tile = [&]() {
     const int tile_m = iss_lid / n_tiles, tile_n = iss_lid - tile_m * n_tiles;
     const int m0 = tile_m * R_BM;
-    bbase_tile = Wt + (long)(tile_n * R_BN) * p.k * 2;
+    bbase_tile = Wt + (long)(tile_n * R_BN) * p.k * ES;
     if (is_conv) {
       const int fr = m0 / hw_out;
       const int rem = m0 - fr * hw_out;
@@ -181,9 +195,9 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
   auto refresh_issue_bases = [&]() {
     const bool first = s_ci < c1;
     a_ld = first ? lda1b : lda2b;
-    a_cur = (first ? A1 + (long)s_ci * 2 : A2 + (long)(s_ci - c1) * 2) +
+    a_cur = (first ? A1 + (long)s_ci * ES : A2 + (long)(s_ci - c1) * ES) +
             ((RABL(4) ? 0 : pix0) + s_ky * w_in + s_kx) * (long)a_ld;
-    b_cur = bbase_tile + ((long)(s_ky * kw + s_kx) * cin + s_ci) * 2;
+    b_cur = bbase_tile + ((long)(s_ky * kw + s_kx) * cin + s_ci) * ES;
   };
   const uint32_t bq1 = (uint32_t)b_piece_stride, bq2 = 2u * bq1, bq3 = 3u * bq1, bq4 = 4u * bq1;   // < 4 GiB (fast_ok)
 
@@ -214,7 +228,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
   auto advance_issue = [&](bool more) {
     ++iss_kt;
 #ifdef VX_RING_TAP_OUTER
-    s_ci += BK;
+    s_ci += BKE;
     if (s_ci >= cin) {
       s_ci = 0;
       if (++s_kx == kw) { s_kx = 0; ++s_ky; }
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
 #else
     if (++s_kx == kw) {
       s_kx = 0;
-      if (++s_ky == kh) { s_ky = 0; s_ci += BK; }
+      if (++s_ky == kh) { s_ky = 0; s_ci += BKE; }
     }
 #endif
     if (iss_kt == nk) {
@@ -323,6 +337,13 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
       RING_STAMP();
       // ---------------- M slot
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (F8) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            acc[2 * ph + s][j] = ring_mfma_f8(bfr[j][0], bfr[j][1], af[s][0], af[s][1], acc[2 * ph + s][j]);
+      } else {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -335,6 +356,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
             }
             acc[2 * ph + s][j] = mfma16(bfr[j][kk], af[s][kk], acc[2 * ph + s][j]);
           }
+      }
       __builtin_amdgcn_s_setprio(0);
       RING_STAMP();
       ring_barrier();
@@ -366,6 +388,21 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
     // acc[i][j][r] = C[m0 + 128 grp + 16 i + lrow][n0 + 80 wc + 16 j + 4 lq + r].
     const int tile_m = cmp_lid / n_tiles, tile_n = cmp_lid - tile_m * n_tiles;
     const int row_base = tile_m * R_BM + 128 * grp + lrow;
+    if constexpr (F8) {
+      // dequantise: acc[m][n] *= a_scale[m] * w_scale[n]
+      const float* __restrict__ asc = p.a_scale;
+      const float* __restrict__ wsc = p.w_scale;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float sa_ = asc[row_base + 16 * i];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const float4 sw4 = *reinterpret_cast<const float4*>(wsc + tile_n * R_BN + 80 * wc + 16 * j + 4 * lq);
+          acc[i][j][0] *= sa_ * sw4.x; acc[i][j][1] *= sa_ * sw4.y;
+          acc[i][j][2] *= sa_ * sw4.z; acc[i][j][3] *= sa_ * sw4.w;
+        }
+      }
+    }
     if constexpr (EPI == VX_EPI_STORE) {
       // Pairing fragments (j, j+1) and swapping the odd 16-lane rows of the first with the even rows of the second
       // gives every lane 8 consecutive columns of one fragment: [x0..x3 y0..y3] = fragment j + (lq & 1), columns
@@ -566,6 +603,16 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
     mode = (e && !strcmp(e, "0")) ? 0 : ((e && !strcmp(e, "1")) ? 1 : 2);
   }
   if (!mode || p.ring_hint < 0) return false;
+  if (p.a_fp8) {
+    // fp8 operands on the ring kernel: correct (tests/test_gpu_kernels.py::test_gemm_fp8_ring), but its 8-register MFMA
+    // operand tuples push the 256-VGPR budget over (67-72 spilled registers in the K loop); on unless VX_FP8_RING=0
+    static int on = -1;
+    if (on < 0) {
+      const char* e = getenv("VX_FP8_RING");
+      on = !(e && !strcmp(e, "0"));
+    }
+    if (!on || p.epi != VX_EPI_STORE || (p.k % 128) != 0 || p.kh != 1 || p.kw != 1 || p.a2 != nullptr) return false;
+  }
   if ((p.epi != VX_EPI_STORE && p.epi != VX_EPI_GEGLU) || p.out_f32 || p.splitk > 1 || p.act == VX_ACT_GELU) return false;
   if ((p.m % R_BM) != 0 || (p.n % R_BN) != 0) return false;
   if ((p.ldc % 8) != 0 || (p.residual != nullptr && (p.ldr % 8) != 0)) return false;
@@ -591,10 +638,10 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
   return mode == 2 || p.k <= 1280;
 }
 
-template <int EPI, bool RES>
+template <int EPI, bool RES, bool F8 = false>
 static int ring_launch(const vx_gemm_params& p, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = gemm_ring_kernel<EPI, RES>;
+  auto kern = gemm_ring_kernel<EPI, RES, F8>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
     if (e != hipSuccess) {
@@ -615,6 +662,9 @@ static int ring_launch(const vx_gemm_params& p, hipStream_t stream) {
 }
 
 int vx_gemm_ring_launch(const vx_gemm_params& p, hipStream_t stream) {
+  if (p.a_fp8)
+    return p.residual != nullptr ? ring_launch<VX_EPI_STORE, true, true>(p, stream)
+                                 : ring_launch<VX_EPI_STORE, false, true>(p, stream);
   if (p.epi == VX_EPI_GEGLU) return ring_launch<VX_EPI_GEGLU, false>(p, stream);
   return p.residual != nullptr ? ring_launch<VX_EPI_STORE, true>(p, stream) : ring_launch<VX_EPI_STORE, false>(p, stream);
 }
