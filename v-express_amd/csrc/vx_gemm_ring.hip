@@ -604,12 +604,14 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
   }
   if (!mode || p.ring_hint < 0) return false;
   if (p.a_fp8) {
-    // fp8 operands on the ring kernel: correct (tests/test_gpu_kernels.py::test_gemm_fp8_ring), but its 8-register MFMA
-    // operand tuples push the 256-VGPR budget over (67-72 spilled registers in the K loop); on unless VX_FP8_RING=0
+    // fp8 operands on the ring kernel: correct (tests/test_gpu_kernels.py::test_gemm_fp8_ring_vs_classic_tiles), but
+    // its 8-register MFMA operand tuples push the 256-VGPR budget over (67-72 spilled registers in the K loop) and it
+    // measures SLOWER than the classic fp8 tiles (287 vs 207 us at 294912 x 320 x 384; 768^2 clip 3.59 vs 3.92
+    // frames/s, profiles/r02d_*): off unless VX_FP8_RING=1
     static int on = -1;
     if (on < 0) {
       const char* e = getenv("VX_FP8_RING");
-      on = !(e && !strcmp(e, "0"));
+      on = e && !strcmp(e, "1");
     }
     if (!on || p.epi != VX_EPI_STORE || (p.k % 128) != 0 || p.kh != 1 || p.kw != 1 || p.a2 != nullptr) return false;
   }
