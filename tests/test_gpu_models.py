@@ -115,8 +115,11 @@ def test_unet_forward_fp8_projections_vs_golden(name):
     assert r <= 6e-2 and c >= 0.998, (r, c)
 
 
-def test_full_size_unet_forward_vs_oracle():
-    """BASELINE.json configs[1] geometry against the oracle DIRECTLY: SD-1.5 widths, 512x512 (64x64 latents: 4096 tokens,
+@pytest.mark.parametrize("latent", [64, 96])
+def test_full_size_unet_forward_vs_oracle(latent):
+    """latent = 96: the 768x768 geometry of BASELINE.json configs[4] (9216 / 2304 / 576 / 144 tokens per level: the
+    pre-padded convs leave the ring kernel there, the attention kernels run ragged query blocks), same check.
+    latent = 64: BASELINE.json configs[1] geometry against the oracle DIRECTLY: SD-1.5 widths, 512x512 (64x64 latents: 4096 tokens,
     head dims 40 / 80 / 160), CFG batch of 2 - the shapes on which the ring GEMM, the pre-padded convs, attn2 and the
     split-K path actually run - at f = 2 frames, the sample bench.py's cpu_baseline leg times (the fp32 oracle needs
     ~20 s per forward on the host cores; 16 frames would take minutes).  ReferenceNet banks and one UNet3D CFG forward,
@@ -127,7 +130,7 @@ def test_full_size_unet_forward_vs_oracle():
     nthreads = torch.get_num_threads()
     torch.set_num_threads(min(64, os.cpu_count() or 1))           # the oracle is slower on all 256 hardware threads
     try:
-        kw, F, h, w, t = cases.FULL, 2, 64, 64, 519
+        kw, F, h, w, t = cases.FULL, 2, latent, latent, 519
         cfg, ocfg = cases.unet_cfg(kw), cases.oracle_cfg(kw)
         sd3, sd2 = synth.unet3d_state_dict(cfg), synth.refnet_state_dict(cfg)
         inp = synth.synthetic_inputs(cfg, F, h, w)
@@ -139,7 +142,7 @@ def test_full_size_unet_forward_vs_oracle():
         with torch.no_grad():
             obanks = OU.refnet_banks(sd2, ocfg, inp["ref_latents"])
         worst = max((rel_l2(refnet.banks[k].view_as(obanks[k][0]), obanks[k][0]), k) for k in obanks)
-        assert worst[0] <= 3e-2, f"bank parity at 64x64 latents: worst relL2 {worst}"
+        assert worst[0] <= 3e-2, f"bank parity at {latent}x{latent} latents: worst relL2 {worst}"
         reader.update(writer, True)
         x = inp["latents"].repeat(2, 1, 1, 1, 1)
         ehs = inp["audio_embeddings"].reshape(-1, 5, 768)
@@ -148,7 +151,8 @@ def test_full_size_unet_forward_vs_oracle():
             ref = OU.unet3d_forward(sd3, ocfg, x, t, ehs, inp["kps_features"], OU.reader_banks(obanks), cases.W_REF,
                                     cases.W_AUD)
         r, c = rel_l2(got, ref), cosine(got, ref)
-        print(f"[full 512x512 f=2] worst bank relL2={worst[0]:.4g} ({worst[1]}); forward relL2={r:.4g} cosine={c:.6f}")
+        print(f"[full {8 * latent}x{8 * latent} f=2] worst bank relL2={worst[0]:.4g} ({worst[1]}); forward relL2={r:.4g} "
+              f"cosine={c:.6f}")
         assert torch.isfinite(got).all() and r <= 3e-2 and c >= 0.999, (r, c)
     finally:
         torch.set_num_threads(nthreads)
@@ -187,6 +191,32 @@ def test_pipeline_vs_reference_golden(name):
     assert r0 <= 3e-2 and r1 <= 5e-2 and c1 >= 0.998, (r0, r1, c1)
     assert mae <= 2e-2 and psnr >= 30.0, (mae, psnr)
     assert video.min().item() >= 0.0 and video.max().item() <= 1.0
+
+
+def test_merged_unet_calls_are_bit_identical_on_the_gpu():
+    """`VExpressPipeline.units_per_call`: 2 (one window per UNet call) vs the default 4 vs 6 (consecutive windows merged
+    into one batch) on the real kernels: batch rows never influence each other, so the clips must be bit-identical."""
+    _need_gpu()
+    from v_express_amd import AutoencoderKLDecoder, DDIMScheduler, VExpressPipeline, synth
+    import ref_import as R
+    cfg = cases.unet_cfg(cases.SMALL)
+    vcfg = synth.VaeConfig(**cases.SMALL_VAE)
+    unet, refnet = build_models(cases.SMALL, synth.unet3d_state_dict(cfg), synth.refnet_state_dict(cfg))
+    vae = AutoencoderKLDecoder(vcfg).to("cuda")
+    vae.load_state_dict(synth.vae_decoder_state_dict(vcfg))
+    pipe = VExpressPipeline(vae=vae, reference_net=refnet, denoising_unet=unet,
+                            scheduler=DDIMScheduler(**R.NOISE_SCHEDULER_KWARGS))
+    Fn, cf, co, steps = 14, 4, 2, 2                       # 6 windows
+    inp = synth.synthetic_inputs(cfg, Fn, 8, 8)
+    outs = {}
+    for upc in (2, 4, 6):
+        pipe.units_per_call = upc
+        outs[upc] = pipe(None, None, None, 64, 64, Fn, steps, cases.GUIDANCE, context_frames=cf, context_overlap=co,
+                         reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD,
+                         reference_latents=inp["ref_latents"], kps_features=inp["kps_features"],
+                         audio_embeddings=inp["audio_embeddings"], latents=inp["latents"], decode=False).cpu()
+    assert torch.isfinite(outs[2]).all()
+    assert torch.equal(outs[2], outs[4]) and torch.equal(outs[2], outs[6])
 
 
 def test_pipeline_without_cfg_vs_reference_golden():

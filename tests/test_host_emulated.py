@@ -262,15 +262,23 @@ def test_pipeline_call_end_to_end_host_composition_vs_oracle(emulated):
 
 
 def test_merging_windows_into_one_unet_call_changes_nothing(emulated):
-    """`VExpressPipeline.units_per_call = 4`: two windows (4 CFG rows) per UNet call instead of one.  Batch rows are
+    """`VExpressPipeline.units_per_call`: one window per UNet call (2) vs up to three (6); the default is 4.  Batch rows are
     independent in every kernel, so the clip must be bit-identical to the default one-window-per-call loop."""
     import v_express_amd as vx
-    ref = W.run(14, 8, 2, 2, 0, device="cpu")
     orig = vx.VExpressPipeline.__init__
+
+    def unmerged(self, *a, **k):
+        orig(self, *a, **k)
+        self.units_per_call = 2
+    vx.VExpressPipeline.__init__ = unmerged
+    try:
+        ref = W.run(14, 8, 2, 2, 0, device="cpu")
+    finally:
+        vx.VExpressPipeline.__init__ = orig
 
     def patched(self, *a, **k):
         orig(self, *a, **k)
-        self.units_per_call = 4
+        self.units_per_call = 6
     vx.VExpressPipeline.__init__ = patched
     try:
         got = W.run(14, 8, 2, 2, 0, device="cpu")

@@ -41,6 +41,8 @@ class DeviceModule:
     def to(self, *args, **kwargs):
         device = self._device
         for a in list(args) + list(kwargs.values()):
+            if isinstance(a, bool) or a is None:          # non_blocking= / copy= flags of torch's signature
+                continue
             if isinstance(a, torch.dtype):
                 if a == torch.float16:
                     raise NotImplementedError(_NO_FP16)

@@ -44,9 +44,12 @@ class VExpressPipeline:
         # ranks per (window, CFG-half) unit, each holding 1/S of the window's frames; None = automatic (S > 1 only
         # when the clip has fewer units than ranks, distributed.choose_frame_shards)
         self.frame_shards = None
-        # batch rows per UNet call: 2 = the two CFG halves of one window (default); 4, 6, ... also merge consecutive
-        # windows of this rank into one call
-        self.units_per_call = 2
+        # batch rows per UNet call: 2 = the two CFG halves of one window; 4 (default), 6, ... also merge consecutive
+        # windows of this rank into one call.  Every kernel is batch-invariant, so the rows come out bit-identical;
+        # merged calls measure 4-5 % faster (profiles/r02e_host_overhead.json: b = 3 74.0 ms vs 49.2 + 28.2 ms,
+        # b = 4 94.1 vs 2 x 49.2 ms at 512x512, f = 16), which is what the 3-unit ranks of the 8-GPU config-4 run and
+        # the multi-window single-GPU clips execute
+        self.units_per_call = 4
         self.last_timing = {}
 
     # ------------------------------------------------------------------ plumbing
