@@ -89,6 +89,14 @@ typedef struct {
   int32_t a_fp8;
   const float* a_scale;      /* [m] */
   const float* w_scale;      /* [n] */
+  /* LayerNorm folded into the GEMM (round 2): with W' = gamma (.) W (columns scaled), s[n] = sum_k W'[n, k] and
+   * b' = b + W beta prepared at load time, LN(x) W^T + b == rstd[m] * (x W'^T - mean[m] * s[n]) + b'.  ln_stats != NULL:
+   * the raw accumulators are transformed acc <- rstd[m] * (acc - mean[m] * ln_colsum[n]) before the epilogue (any
+   * epilogue; not with split-K), so the LayerNorm output is never written or re-read: the caller passes the UN-normalised
+   * rows as A, the folded weight as w, b' as bias and the row statistics of vx_row_stats.  Replaces the F.layer_norm +
+   * F.linear pairs of modules/mutual_self_attention.py:177-247 and modules/motion_module.py:243-256. */
+  const float* ln_stats;     /* [m][2] = (mean, rstd) per row, or NULL */
+  const float* ln_colsum;    /* [n] */
 } vx_gemm_params;
 
 int vx_gemm(const vx_gemm_params* p, void* stream);
@@ -120,6 +128,10 @@ int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int frames, int
  * out[r, :] = LN(x[r, :]) * gamma + beta + (add ? add[(r / add_rows_per_entry) % add_entries, :] : 0). */
 int vx_layernorm(const void* x, int ldx, int rows, int c, float eps, const float* gamma, const float* beta,
                  const float* add, int add_rows_per_entry, int add_entries, void* out, int ldo, void* stream);
+
+/* Row statistics of a LayerNorm that is folded into the consuming GEMM (vx_gemm_params.ln_stats): stats[r] = (mean,
+ * 1 / sqrt(var + eps)) of x[r, 0:c], two-pass variance in registers exactly as vx_layernorm computes it. */
+int vx_row_stats(const void* x, int ldx, int rows, int c, float eps, float* stats, void* stream);
 
 /* LayerNorm (or, with gamma == NULL, no normalisation) whose result is quantised per row to OCP e4m3 for an fp8
  * projection GEMM: out8[r, 0:c] = e4m3(y[r, :] / scale[r]) with y as vx_layernorm computes it (incl. the additive

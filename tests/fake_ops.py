@@ -56,6 +56,21 @@ def layernorm(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_e
     return y
 
 
+def row_stats(x, eps=1e-5):
+    x2 = (x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x).double()
+    mean = x2.mean(dim=1)
+    var = x2.var(dim=1, unbiased=False)
+    return torch.stack([mean, torch.rsqrt(var + eps)], dim=1).float()
+
+
+def _apply_ln(y, ln):
+    """vx_gemm_params.ln_stats: acc <- rstd[m] * (acc - mean[m] * colsum[n])"""
+    if ln is None:
+        return y
+    stats, colsum = ln
+    return stats[:, 1:2].double() * (y - stats[:, 0:1].double() * colsum.double()[None, :])
+
+
 def layernorm_fp8(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_entries=1):
     """vx_layernorm_fp8: (optional) LayerNorm in float64, per-row scale = max|y| / 448, OCP e4m3 round-to-nearest."""
     from v_express_amd import ops as real_ops
@@ -112,7 +127,7 @@ def _conv_rows(a, a2, w, geom):
 
 
 def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=0, rowbias=None, rows_per_group=0,
-         out=None, out_f32=False):
+         out=None, out_f32=False, ln=None):
     if _is_fp8(a):
         assert geom is None and a2 is None
         x, wt = _dequant(a, w)
@@ -126,6 +141,7 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=0
     else:
         assert a.dtype == BF16 and w.dtype == BF16 and a.stride(-1) == 1 and w.is_contiguous()
         y = _conv_rows(a.reshape(-1, a.shape[-1]), None if a2 is None else a2.reshape(-1, a2.shape[-1]), w, geom)
+    y = _apply_ln(y, ln)
     if bias is not None:
         assert bias.dtype == torch.float32
         y = y + bias
@@ -146,8 +162,8 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=0
     return y
 
 
-def geglu(a, w_interleaved, bias_interleaved, out=None):
-    y = a.double() @ w_interleaved.double().t()
+def geglu(a, w_interleaved, bias_interleaved, out=None, ln=None):
+    y = _apply_ln(a.double() @ w_interleaved.double().t(), ln)
     if bias_interleaved is not None:
         y = y + bias_interleaved
     blk = y.view(y.shape[0], -1, 2, 8)                      # blocks of 8 value columns followed by their 8 gates
@@ -162,12 +178,12 @@ def alloc_vt(seqs, heads, head_dim, n, device):
     return torch.zeros((seqs, heads, head_dim, (n + 7) // 8 * 8), device=device, dtype=BF16)
 
 
-def gemm_split(a, w, bias, parts, *, part_cols, seq_len=0, head_dim=0, geom=None):
+def gemm_split(a, w, bias, parts, *, part_cols, seq_len=0, head_dim=0, geom=None, ln=None):
     if _is_fp8(a):
         x, wt = _dequant(a, w)
         y = x @ wt.t()
     else:
-        y = a.double() @ w.double().t()
+        y = _apply_ln(a.double() @ w.double().t(), ln)
     if bias is not None:
         y = y + bias
     for i, (kind, t) in enumerate(parts):
@@ -288,7 +304,7 @@ def vae_postprocess(x, n, c, h, w):
     return (x[:, :c].float().reshape(n, h, w, c).permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1).contiguous()
 
 
-ALL = ("wave_conv1d", "groupnorm", "layernorm", "layernorm_fp8", "quantize_fp8", "gemm", "geglu", "alloc_vt", "gemm_split", "key_norm_max", "attention",
+ALL = ("wave_conv1d", "groupnorm", "layernorm", "row_stats", "layernorm_fp8", "quantize_fp8", "gemm", "geglu", "alloc_vt", "gemm_split", "key_norm_max", "attention",
        "temporal_attention", "small_kv_attention", "add_row_bias", "gather_latents", "cfg_combine", "pack_rows", "combine_units", "overlap_ddim_step",
        "ncfhw_to_nhwc", "nhwc_to_ncfhw", "vae_postprocess")
 

@@ -638,3 +638,71 @@ def test_gemm_fp8_rejects_what_it_does_not_support(ops):
         ops.gemm(a8, rnd(320, 320, seed=1))                  # bf16 weight with fp8 activations
     with pytest.raises(L.VxError):
         ops.geglu(a8, w8, None)                               # GEGLU epilogue is not built for fp8
+
+
+# --------------------------------------------------------------------------- LayerNorm folded into the consumer GEMM
+
+
+def _folded(ops, w, bias, gamma, beta, interleave=False):
+    from v_express_amd import weights as Wt
+    return Wt.fold_layernorm(w.float(), bias, gamma, beta, "cuda", interleave=interleave)
+
+
+def test_row_stats(ops):
+    for rows, c in ((300, 320), (257, 640), (64, 1280), (33, 40)):
+        x = (rnd(rows, c, seed=c).float() * 1.5 + 0.7).to(BF)
+        st = ops.row_stats(x, 1e-5)
+        xf = x.float()
+        assert torch.allclose(st[:, 0], xf.mean(dim=1), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(st[:, 1], torch.rsqrt(xf.var(dim=1, unbiased=False) + 1e-5), rtol=1e-5)
+
+
+@pytest.mark.parametrize("m,n,k,offset", [(256 * 96, 640, 320, 0.0), (256 * 96, 640, 320, 3.0), (300, 320, 640, 0.5),
+                                          (2048, 1280, 1280, 1.0), (256 * 200, 320, 320, 0.5)])
+def test_gemm_with_folded_layernorm(ops, m, n, k, offset):
+    """vx_gemm_params.ln_stats: x W'^T transformed to rstd (acc - mean colsum) + b' must equal LN(x) W^T + b computed in
+    fp32 - on the ring kernel (first / last case) and the classic tiles, with a row mean of up to 3 standard deviations
+    (the cancellation the algebra introduces), residual + alpha + row-bias epilogue options included."""
+    x = (rnd(m, k, seed=1).float() + offset).to(BF)
+    w = rnd(n, k, scale=k ** -0.5, seed=2)
+    bias = rnd(n, seed=3, dtype=torch.float32)
+    gamma, beta = 1 + 0.1 * rnd(k, seed=4, dtype=torch.float32), 0.1 * rnd(k, seed=5, dtype=torch.float32)
+    Fd = _folded(ops, w, bias, gamma, beta)
+    ref = F.layer_norm(x.float(), (k,), gamma, beta, 1e-5) @ w.float().t() + bias
+    st = ops.row_stats(x)
+    out = ops.gemm(x, Fd.w, Fd.b, ln=(st, Fd.s))
+    check(out, ref, f"folded LN gemm {m}x{n}x{k} offset {offset}", rel=8e-3, mx=2 ** -6)
+    res = rnd(m, n, seed=6)
+    grp = 256 if m % 256 == 0 else m
+    rowbias = rnd(m // grp, n, seed=7, dtype=torch.float32)
+    out2 = ops.gemm(x, Fd.w, Fd.b, ln=(st, Fd.s), residual=res, alpha=0.9, rowbias=rowbias, rows_per_group=grp)
+    check(out2, res.float() + 0.9 * (ref + rowbias.repeat_interleave(grp, 0)), "folded LN gemm + epilogue options",
+          rel=8e-3, mx=2 ** -6)
+
+
+def test_geglu_and_split_with_folded_layernorm(ops):
+    m, c, heads = 256 * 24, 320, 8
+    x = (rnd(m, c, seed=1).float() * 1.3 + 0.4).to(BF)
+    gamma, beta = 1 + 0.1 * rnd(c, seed=4, dtype=torch.float32), 0.1 * rnd(c, seed=5, dtype=torch.float32)
+    ln = F.layer_norm(x.float(), (c,), gamma, beta, 1e-5)
+    st = ops.row_stats(x)
+    # GEGLU: value rows then gate rows in the source layout; fold_layernorm interleaves them for the kernel
+    w1, b1 = rnd(8 * c, c, scale=c ** -0.5, seed=2), rnd(8 * c, seed=3, dtype=torch.float32)
+    Fd = _folded(ops, w1, b1, gamma, beta, interleave=True)
+    y = ln @ w1.float().t() + b1
+    ref = y[:, :4 * c] * F.gelu(y[:, 4 * c:])
+    check(ops.geglu(x, Fd.w, Fd.b, ln=(st, Fd.s)), ref, "folded LN geglu", rel=8e-3, mx=2 ** -6)
+    # fused QKV with the V^T part
+    wq = rnd(3 * c, c, scale=c ** -0.5, seed=6)
+    Fq = _folded(ops, wq, None, gamma, beta)
+    d, seq = c // heads, 64
+    q = torch.empty((m, c), device="cuda", dtype=BF)
+    kk = torch.empty((m, c), device="cuda", dtype=BF)
+    vt = ops.alloc_vt(m // seq, heads, d, seq, "cuda")
+    ops.gemm_split(x, Fq.w, Fq.b, [("rows", q), ("rows", kk), ("vt", vt)], part_cols=c, seq_len=seq, head_dim=d,
+                   ln=(st, Fq.s))
+    r = ln @ wq.float().t()
+    check(q, r[:, :c], "folded LN split q", rel=8e-3, mx=2 ** -6)
+    check(kk, r[:, c:2 * c], "folded LN split k", rel=8e-3, mx=2 ** -6)
+    check(vt[..., :seq], r[:, 2 * c:].view(m // seq, seq, heads, d).permute(0, 2, 3, 1), "folded LN split v^T", rel=8e-3,
+          mx=2 ** -6)

@@ -59,16 +59,28 @@ def upsample(P, x, frames, H, W):
     return out.view(frames, g.h_out * g.w_out, -1), g.h_out, g.w_out
 
 
-def _self_attention(A, ln, h, *, seqs, n_tok, heads):
+def _fold_on(F):
+    """A folded LayerNorm is used when the weights carry one, the switch is on and the projections are not in fp8 mode
+    (whose quantiser is fused with its own LayerNorm)."""
+    return F is not None and ops.LN_FOLD[0] and not ops.FP8_PROJ[0]
+
+
+def _self_attention(A, ln, h, *, seqs, n_tok, heads, fold=None):
     """diffusers Attention as self-attention: fused QKV GEMM whose epilogue also emits V^T, flash attention,
     out-projection with the residual add fused (in place on h)."""
+    """fold = (folded weights, row statistics): `ln` is then the UN-normalised h and the LayerNorm runs inside the GEMM."""
     m, c = ln.shape
     d = c // heads
     q = torch.empty((m, c), device=ln.device, dtype=ops.BF16)
     k = torch.empty((m, c), device=ln.device, dtype=ops.BF16)
     vt = ops.alloc_vt(seqs, heads, d, n_tok, ln.device)
-    ops.gemm_split(ln, ops.proj_weight(ln, A.wqkv), A.bqkv, [("rows", q), ("rows", k), ("vt", vt)], part_cols=c,
-                   seq_len=n_tok, head_dim=d)
+    if fold is not None:
+        F, stats = fold
+        ops.gemm_split(ln, F.w, F.b, [("rows", q), ("rows", k), ("vt", vt)], part_cols=c, seq_len=n_tok, head_dim=d,
+                       ln=(stats, F.s))
+    else:
+        ops.gemm_split(ln, ops.proj_weight(ln, A.wqkv), A.bqkv, [("rows", q), ("rows", k), ("vt", vt)], part_cols=c,
+                       seq_len=n_tok, head_dim=d)
     a = ops.attention(q, k, vt, batch=seqs, heads=heads, n_q=n_tok, n_kv=n_tok, head_dim=d,
                       k_prescaled=bool(A.get("k_prescaled")))
     if isinstance(ln, ops.Fp8Rows):
@@ -77,9 +89,14 @@ def _self_attention(A, ln, h, *, seqs, n_tok, heads):
 
 
 def _feed_forward(P, h):
-    """h += FF(LN(h)): GEGLU fused in the first GEMM's epilogue, residual in the second's."""
-    ln = ops.layernorm(h, P.norm3.g if "norm3" in P else P.ff_norm.g, P.norm3.b if "norm3" in P else P.ff_norm.b)
-    g = ops.geglu(ln, P.ff.w1, P.ff.b1)
+    """h += FF(LN(h)): GEGLU fused in the first GEMM's epilogue (with the LayerNorm folded into that GEMM when the
+    weights carry the fold), residual in the second's."""
+    F = P.get("ln_ff")
+    if F is not None and ops.LN_FOLD[0]:
+        g = ops.geglu(h, F.w, F.b, ln=(ops.row_stats(h), F.s))
+    else:
+        ln = ops.layernorm(h, P.norm3.g if "norm3" in P else P.ff_norm.g, P.norm3.b if "norm3" in P else P.ff_norm.b)
+        g = ops.geglu(ln, P.ff.w1, P.ff.b1)
     ops.gemm(g, P.ff.out.w, P.ff.out.b, residual=h, out=h)
 
 
@@ -107,8 +124,11 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
     n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
     h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b)
     # 1. self-attention (:177-184)
-    ln = ops.proj_layernorm(h, P.norm1.g, P.norm1.b)
-    _self_attention(P.attn1, ln, h, seqs=frames, n_tok=hw, heads=heads)
+    if _fold_on(P.get("ln_qkv")):
+        _self_attention(P.attn1, h, h, seqs=frames, n_tok=hw, heads=heads, fold=(P.ln_qkv, ops.row_stats(h)))
+    else:
+        ln = ops.proj_layernorm(h, P.norm1.g, P.norm1.b)
+        _self_attention(P.attn1, ln, h, seqs=frames, n_tok=hw, heads=heads)
     # 1.5 reference attention (:186-224): K/V = bank of the batch row, shared by its f frames
     d = c // heads
     rows = f * hw
@@ -118,9 +138,12 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
             ops.add_row_bias(hb, P.attn1_5.out.b, w_ref)
         else:
             kref, vtref, kmax = bank[bi]
-            ln = ops.proj_layernorm(hb, P.norm1_5.g, P.norm1_5.b)
             with ops.frame_rows(hw, items=1):          # these launches cover ONE batch item
-                q = ops.gemm(ln, ops.proj_weight(ln, P.attn1_5.wq))
+                if _fold_on(P.get("ln_q15")):
+                    q = ops.gemm(hb, P.ln_q15.w, P.ln_q15.b, ln=(ops.row_stats(hb), P.ln_q15.s))
+                else:
+                    ln = ops.proj_layernorm(hb, P.norm1_5.g, P.norm1_5.b)
+                    q = ops.gemm(ln, ops.proj_weight(ln, P.attn1_5.wq))
                 a = ops.proj_input(ops.attention(q, kref, vtref, batch=f, heads=heads, n_q=hw, n_kv=kref.shape[0],
                                                  head_dim=d, q_per_kv=f, kmax=kmax,
                                                  k_prescaled=bool(P.attn1_5.get("k_prescaled"))))
@@ -133,8 +156,11 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
     if kv is None:
         kv = audio_kv(P, ehs)
     if audio_zero is None or not any(audio_zero):
-        ln = ops.proj_layernorm(h, P.norm2.g, P.norm2.b)
-        q = ops.gemm(ln, ops.proj_weight(ln, P.attn2.wq))
+        if _fold_on(P.get("ln_q2")):
+            q = ops.gemm(h, P.ln_q2.w, P.ln_q2.b, ln=(ops.row_stats(h), P.ln_q2.s))
+        else:
+            ln = ops.proj_layernorm(h, P.norm2.g, P.norm2.b)
+            q = ops.gemm(ln, ops.proj_weight(ln, P.attn2.wq))
         a = ops.proj_input(ops.small_kv_attention(q, kv, batch=frames, n_q=hw, n_kv=n_ctx, heads=heads, head_dim=d))
         ops.gemm(a, ops.proj_weight(a, P.attn2.out.w), P.attn2.out.b, residual=h, alpha=w_aud, out=h)
     else:
@@ -144,9 +170,12 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
             if audio_zero[bi]:
                 ops.add_row_bias(hb, P.attn2.out.b, w_aud)
                 continue
-            ln = ops.proj_layernorm(hb, P.norm2.g, P.norm2.b)
             with ops.frame_rows(hw, items=1):
-                q = ops.gemm(ln, ops.proj_weight(ln, P.attn2.wq))
+                if _fold_on(P.get("ln_q2")):
+                    q = ops.gemm(hb, P.ln_q2.w, P.ln_q2.b, ln=(ops.row_stats(hb), P.ln_q2.s))
+                else:
+                    ln = ops.proj_layernorm(hb, P.norm2.g, P.norm2.b)
+                    q = ops.gemm(ln, ops.proj_weight(ln, P.attn2.wq))
                 a = ops.proj_input(ops.small_kv_attention(q, kv[bi * kvr:(bi + 1) * kvr], batch=f, n_q=hw, n_kv=n_ctx,
                                                           heads=heads, head_dim=d))
                 ops.gemm(a, ops.proj_weight(a, P.attn2.out.w), P.attn2.out.b, residual=hb, alpha=w_aud, out=hb)
@@ -206,8 +235,15 @@ def _motion_module(P, x, *, b, f, H, W, heads, groups, shard=None):
     m = b * f_all * hw_t
     h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b)
     for A in P.attn:
-        ln = ops.proj_layernorm(h, A.norm.g, A.norm.b, add=A.pe, add_rows_per_entry=hw_t, add_entries=f_all)
-        qkv = ops.gemm(ln, ops.proj_weight(ln, A.attn.wqkv), A.attn.bqkv)
+        if _fold_on(A.get("ln_qkv")):
+            key = ("pe_rows_tiled", b, f_all)
+            if key not in A:                   # [b * f_all, 3C] float32: frame (m // hw_t) % f_all of the table
+                A[key] = A.pe_rows[:f_all].repeat(b, 1).contiguous()
+            qkv = ops.gemm(h, A.ln_qkv.w, A.ln_qkv.b, rowbias=A[key], rows_per_group=hw_t,
+                           ln=(ops.row_stats(h), A.ln_qkv.s))
+        else:
+            ln = ops.proj_layernorm(h, A.norm.g, A.norm.b, add=A.pe, add_rows_per_entry=hw_t, add_entries=f_all)
+            qkv = ops.gemm(ln, ops.proj_weight(ln, A.attn.wqkv), A.attn.bqkv)
         a = ops.proj_input(ops.temporal_attention(qkv, b=b, f=f_all, hw=hw_t, heads=heads, head_dim=d))
         ops.gemm(a, ops.proj_weight(a, A.attn.out.w), A.attn.out.b, residual=h, out=h)
     _feed_forward(P, h)

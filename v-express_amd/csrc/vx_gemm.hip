@@ -334,6 +334,28 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
     }
   }
 
+  if (p.ln_stats != nullptr) {
+    // folded LayerNorm: acc <- rstd[m] * (acc - mean[m] * colsum[n])   (see vx_gemm_params.ln_stats)
+    const float2* __restrict__ st = reinterpret_cast<const float2*>(p.ln_stats);
+    const float* __restrict__ cs = p.ln_colsum;
+    float mu[MI], rs[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const float2 t = st[min(wrow0 + i * 16 + lrow, p.m - 1)];
+      mu[i] = t.x;
+      rs[i] = t.y;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const float4 s4 = *reinterpret_cast<const float4*>(cs + min(wcol0 + j * 16 + lq * 4, p.n - 4));
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        acc[i][j][0] = rs[i] * (acc[i][j][0] - mu[i] * s4.x); acc[i][j][1] = rs[i] * (acc[i][j][1] - mu[i] * s4.y);
+        acc[i][j][2] = rs[i] * (acc[i][j][2] - mu[i] * s4.z); acc[i][j][3] = rs[i] * (acc[i][j][3] - mu[i] * s4.w);
+      }
+    }
+  }
+
   if (EPI == VX_EPI_STORE && nsplit > 1) {
     // split-K slice: raw fp32 partial sums to the workspace, 16 bytes (4 columns) per lane
     float* ws = (float*)p.splitk_ws + (size_t)split * p.m * p.n;
@@ -733,6 +755,8 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
   VX_REQUIRE((p.lda1 % 8) == 0 && (p.c2 == 0 || (p.lda2 % 8) == 0), "vx_gemm: lda must be a multiple of 8");
   VX_REQUIRE(p.upsample == 0 || p.upsample == 1, "vx_gemm: upsample must be 0/1");
   VX_REQUIRE(p.stride >= 1 && p.kh >= 1 && p.kw >= 1, "vx_gemm: bad conv geometry");
+  VX_REQUIRE(p.ln_stats == nullptr || (p.ln_colsum != nullptr && p.splitk <= 1 && !p.a_fp8),
+             "vx_gemm: a folded LayerNorm needs ln_colsum and excludes split-K / fp8 operands");
   VX_REQUIRE(p.splitk <= 1 || (p.epi == VX_EPI_STORE && p.splitk_ws != nullptr && p.splitk <= 16 &&
                                p.splitk <= (p.k + BK - 1) / BK),
              "vx_gemm: split-K needs the STORE epilogue, a workspace and splitk <= min(16, K/64)");

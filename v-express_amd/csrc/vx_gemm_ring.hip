@@ -403,6 +403,21 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
         }
       }
     }
+    if (p.ln_stats != nullptr) {
+      // folded LayerNorm: acc <- rstd[m] * (acc - mean[m] * colsum[n])   (see vx_gemm_params.ln_stats)
+      const float2* __restrict__ st = reinterpret_cast<const float2*>(p.ln_stats);
+      const float* __restrict__ cs = p.ln_colsum;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float2 t = st[row_base + 16 * i];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const float4 s4 = *reinterpret_cast<const float4*>(cs + tile_n * R_BN + 80 * wc + 16 * j + 4 * lq);
+          acc[i][j][0] = t.y * (acc[i][j][0] - t.x * s4.x); acc[i][j][1] = t.y * (acc[i][j][1] - t.x * s4.y);
+          acc[i][j][2] = t.y * (acc[i][j][2] - t.x * s4.z); acc[i][j][3] = t.y * (acc[i][j][3] - t.x * s4.w);
+        }
+      }
+    }
     if constexpr (EPI == VX_EPI_STORE) {
       // Pairing fragments (j, j+1) and swapping the odd 16-lane rows of the first with the even rows of the second
       // gives every lane 8 consecutive columns of one fragment: [x0..x3 y0..y3] = fragment j + (lq & 1), columns

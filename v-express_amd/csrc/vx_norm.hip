@@ -366,6 +366,78 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   }
 }
 
+// Row statistics for a LayerNorm folded into its consumer GEMM (vx_row_stats): the read half of layernorm_kernel -
+// LN_R rows per wave pass, two-pass variance in registers - writing (mean, rstd) per row instead of the normalised row.
+template <int MAXC>
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ x, int ldx, int rows, int c, float eps,
+                                                        float2* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const int nchunks = c >> 3;
+  const float inv_c = 1.0f / (float)c;
+  for (int row0 = wave * LN_R; row0 < rows; row0 += nwaves * LN_R) {
+    uint4 raw[LN_R][MAXC];
+#pragma unroll
+    for (int r = 0; r < LN_R; ++r) {
+      const int row = min(row0 + r, rows - 1);
+#pragma unroll
+      for (int u = 0; u < MAXC; ++u) {
+        const int chunk = lane + u * 64 < nchunks ? lane + u * 64 : 0;
+        raw[r][u] = *reinterpret_cast<const uint4*>(x + (size_t)row * ldx + chunk * 8);
+      }
+    }
+    float sum[LN_R];
+#pragma unroll
+    for (int r = 0; r < LN_R; ++r) {
+      sum[r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < MAXC; ++u) {
+        float v[8];
+        unpack_bf16x8(raw[r][u], v);
+        const float t = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        sum[r] += lane + u * 64 < nchunks ? t : 0.f;
+      }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+      for (int r = 0; r < LN_R; ++r) sum[r] = wave_xor_sum(sum[r], m);
+    float sq[LN_R];
+#pragma unroll
+    for (int r = 0; r < LN_R; ++r) {
+      const float mean = sum[r] * inv_c;
+      sq[r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < MAXC; ++u) {
+        float v[8];
+        unpack_bf16x8(raw[r][u], v);
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[e] - mean;
+          t += d * d;
+        }
+        sq[r] += lane + u * 64 < nchunks ? t : 0.f;
+      }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+      for (int r = 0; r < LN_R; ++r) sq[r] = wave_xor_sum(sq[r], m);
+    if (lane < LN_R && row0 + lane < rows) {
+      float mean = 0.f, var = 0.f;
+#pragma unroll
+      for (int r = 0; r < LN_R; ++r)
+        if (lane == r) {
+          mean = sum[r] * inv_c;
+          var = sq[r] * inv_c;
+        }
+      stats[row0 + lane] = make_float2(mean, rsqrtf(var + eps));
+    }
+  }
+}
+
 // LayerNorm (NORM) or identity whose output is quantised per row to OCP e4m3 (vx_layernorm_fp8): same row-in-registers
 // structure as layernorm_kernel; the normalised row stays in registers, its max |y| is reduced over the wave,
 // scale = max / 448 and the row is written as 8 bytes per 8-channel chunk; chunks between c and ldo8 are zero-filled
@@ -556,4 +628,27 @@ extern "C" int vx_layernorm_fp8(const void* x, int ldx, int rows, int c, float e
   }
 #undef VX_LN8
   return vx_check_launch("vx_layernorm_fp8");
+}
+
+extern "C" int vx_row_stats(const void* x, int ldx, int rows, int c, float eps, float* stats, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(x != nullptr && stats != nullptr, "vx_row_stats: null pointer");
+  VX_REQUIRE(rows > 0 && c > 0 && (c % 8) == 0 && (ldx % 8) == 0, "vx_row_stats: bad shape");
+  const int nchunks = c / 8;
+  int nblk = ceil_div(rows, 4 * LN_R);
+  if (nblk > 4096) nblk = 4096;
+  dim3 grid(nblk), block(256);
+#define VX_RS(MAXC)                                                                                        \
+  hipLaunchKernelGGL(row_stats_kernel<MAXC>, grid, block, 0, stream, (const bf16_t*)x, ldx, rows, c, eps, \
+                     reinterpret_cast<float2*>(stats))
+  if (nchunks <= 64) VX_RS(1);
+  else if (nchunks <= 128) VX_RS(2);
+  else if (nchunks <= 192) VX_RS(3);
+  else if (nchunks <= 256) VX_RS(4);
+  else {
+    vx_set_error("vx_row_stats: c=%d exceeds 2048", c);
+    return VX_ERR_UNSUPPORTED;
+  }
+#undef VX_RS
+  return vx_check_launch("vx_row_stats");
 }

@@ -43,6 +43,7 @@ class GemmParams(C.Structure):
         ("splitk", C.c_int32), ("splitk_ws", C.c_void_p),
         ("ring_hint", C.c_int32),
         ("a_fp8", C.c_int32), ("a_scale", C.c_void_p), ("w_scale", C.c_void_p),
+        ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p),
     ]
 
 
@@ -85,6 +86,7 @@ def _load():
     lib.vx_groupnorm_ws_floats.argtypes = [i32, i32, i32]
     lib.vx_groupnorm.argtypes = [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, i32, i32, i32, vp]
     lib.vx_layernorm.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp]
+    lib.vx_row_stats.argtypes = [vp, i32, i32, i32, f32, vp, vp]
     lib.vx_layernorm_fp8.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp, vp]
     lib.vx_attention.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp]
     lib.vx_attention_bounded.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]

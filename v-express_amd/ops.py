@@ -198,6 +198,29 @@ def fp8_weight(w):
     return hit[1]
 
 
+LN_FOLD = [os.environ.get("VX_LN_FOLD", "1") != "0"]
+
+
+def row_stats(x, eps=1e-5):
+    """float32 [rows, 2] = (mean, rstd) of every row: the statistics of a LayerNorm folded into its consumer GEMM
+    (`gemm(..., ln=(stats, colsum))`, weights.fold_layernorm)."""
+    _chk_bf16(x, "x")
+    ldx, rows = _row_stride(x)
+    out = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    L.check(_lib.vx_row_stats(_ptr(x), ldx, rows, x.shape[-1], float(eps), _ptr(out), _stream()), "vx_row_stats")
+    return out
+
+
+def _set_ln(p, ln):
+    if ln is None:
+        return
+    stats, colsum = ln
+    if stats.dtype != torch.float32 or colsum.dtype != torch.float32 or not stats.is_contiguous() or \
+            stats.shape != (p.m, 2) or colsum.numel() != p.n:
+        raise ValueError("ln=(stats [m, 2] float32, colsum [n] float32) expected")
+    p.ln_stats, p.ln_colsum = stats.data_ptr(), colsum.data_ptr()
+
+
 def layernorm_fp8(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_entries=1):
     """LayerNorm (gamma=None: no normalisation, plain row quantisation) -> Fp8Rows."""
     _chk_bf16(x, "x")
@@ -343,8 +366,10 @@ def _splitk(p, geom, device, plain):
 
 
 def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L.VX_ACT_NONE, rowbias=None,
-         rows_per_group=0, out=None, out_f32=False):
-    """out[m, n] = residual + alpha * act(sum_k A[m,k] W[n,k] + bias[n] + rowbias[m // rows_per_group, n])."""
+         rows_per_group=0, out=None, out_f32=False, ln=None):
+    """out[m, n] = residual + alpha * act(sum_k A[m,k] W[n,k] + bias[n] + rowbias[m // rows_per_group, n]).
+    ln=(stats, colsum): a LayerNorm folded into this GEMM - the sum is replaced by rstd[m] * (sum - mean[m] * colsum[n])
+    with `w`, `bias` the folded weight / bias of weights.fold_layernorm and `a` the un-normalised rows."""
     plain = geom is None
     p, geom = _base_params(a, w, geom, a2)
     n = p.n
@@ -366,14 +391,16 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
     if bias is not None and bias.dtype != torch.float32:
         raise TypeError("bias must be float32")
     if not p.a_fp8:
-        _splitk(p, geom, a.device, plain)
+        if ln is None:
+            _splitk(p, geom, a.device, plain)
         p.ring_hint = _ring_hint(p)
+    _set_ln(p, ln)
     _launch_gemm(p, "vx_gemm")
     return out
 
 
-def geglu(a, w_interleaved, bias_interleaved, out=None):
-    """FeedForward first half: h * gelu(g) with value/gate weight rows interleaved in blocks of 8."""
+def geglu(a, w_interleaved, bias_interleaved, out=None, ln=None):
+    """FeedForward first half: h * gelu(g) with value/gate weight rows interleaved in blocks of 8 (ln: as in gemm)."""
     p, geom = _base_params(a, w_interleaved, None)
     if out is None:
         out = torch.empty((geom.m, p.n // 2), device=a.device, dtype=BF16)
@@ -381,6 +408,7 @@ def geglu(a, w_interleaved, bias_interleaved, out=None):
     p.bias = bias_interleaved.data_ptr() if bias_interleaved is not None else None
     p.out, p.ldc = out.data_ptr(), _row_stride(out)[0]
     p.ring_hint = _ring_hint(p)
+    _set_ln(p, ln)
     _launch_gemm(p, "vx_gemm(geglu)")
     return out
 
@@ -389,10 +417,11 @@ def vt_pitch(n):
     return (n + 7) // 8 * 8
 
 
-def gemm_split(a, w, bias, parts, *, part_cols, seq_len=0, head_dim=0, geom=None):
-    """One GEMM whose column ranges go to different destinations.
+def gemm_split(a, w, bias, parts, *, part_cols, seq_len=0, head_dim=0, geom=None, ln=None):
+    """One GEMM whose column ranges go to different destinations (ln: as in gemm).
     parts: list of ("rows", tensor[m, part_cols]) or ("vt", tensor[seqs, heads, head_dim, pitch])."""
     p, geom = _base_params(a, w, geom)
+    _set_ln(p, ln)
     p.epi = L.VX_EPI_SPLIT
     p.bias = bias.data_ptr() if bias is not None else None
     p.part_cols, p.n_parts = part_cols, len(parts)

@@ -87,6 +87,41 @@ def key_fold(c, heads):
     return (c // heads) ** -0.5 * LOG2E
 
 
+def fold_layernorm(w_src, bias, gamma, beta, device, row_scale=None, interleave=False):
+    """LayerNorm folded into the linear that consumes it (vx_gemm_params.ln_stats): from the fp32 source weight
+    [N, K] (rows optionally scaled: the key fold), its bias (or None) and the norm's affine parameters build
+      w = bf16(gamma (.) W)  (ONE rounding),  colsum[n] = sum_k float(w[n, k])  (of the rounded values the MFMA sees),
+      b = bias + W beta  (fp32),
+    so that LN(x) W^T + bias == rstd * (x w^T - mean * colsum) + b.  interleave: GEGLU row order for all three."""
+    w32 = w_src.detach().to(device=device, dtype=torch.float32)
+    if row_scale is not None:
+        w32 = w32 * row_scale.to(device=device, dtype=torch.float32)[:, None]
+    g = gamma.detach().to(device=device, dtype=torch.float32)
+    bt = beta.detach().to(device=device, dtype=torch.float32)
+    w = (w32 * g[None, :]).to(BF16)
+    colsum = w.float().sum(dim=1)
+    b = w32 @ bt
+    if bias is not None:
+        b = b + bias.detach().to(device=device, dtype=torch.float32)
+    if interleave:
+        w, colsum, b = geglu_interleave(w), geglu_interleave(colsum), geglu_interleave(b)
+    return Prepared(w=w.contiguous(), s=colsum.contiguous(), b=b.contiguous())
+
+
+def _qkv_rows(sd, p, device, heads, names):
+    """fp32 row-concatenated source weight, bias (or None) and the per-row key-fold scale of a fused projection."""
+    ws = [sd[f"{p}.{n}.weight"].detach().to(device=device, dtype=torch.float32) for n in names]
+    scale = []
+    for n, w in zip(names, ws):
+        f = key_fold(w.shape[0], heads) if (heads is not None and n == "to_k") else 1.0
+        scale.append(torch.full((w.shape[0],), f, device=device, dtype=torch.float32))
+    bias = None
+    if f"{p}.{names[0]}.bias" in sd:
+        bias = torch.cat([sd[f"{p}.{n}.bias"].detach().to(device=device, dtype=torch.float32) * sc[0]
+                          for n, sc in zip(names, scale)])
+    return torch.cat(ws, dim=0), bias, torch.cat(scale)
+
+
 def prep_self_attn(sd, p, device, heads=None):
     """diffusers Attention used as self-attention: fused QKV + out projection.  heads: fold the softmax scale into the
     key rows (`k_prescaled`)."""
@@ -141,13 +176,23 @@ def prep_spatial_read(sd, p, device, heads=None):
     """Transformer3DModel + TemporalBasicTransformerBlock (attn1, attn1_5, attn2, ff).  heads: fold the softmax scale
     into the key weights of the two flash-attention users (attn1, attn1_5)."""
     t = p + ".transformer_blocks.0"
-    return Prepared(norm=prep_norm(sd, p + ".norm", device), proj_in=prep_linear(sd, p + ".proj_in", device),
-                    proj_out=prep_linear(sd, p + ".proj_out", device),
-                    norm1=prep_norm(sd, t + ".norm1", device), attn1=prep_self_attn(sd, t + ".attn1", device, heads),
-                    norm1_5=prep_norm(sd, t + ".norm1_5", device),
-                    attn1_5=prep_cross_attn(sd, t + ".attn1_5", device, heads),
-                    norm2=prep_norm(sd, t + ".norm2", device), attn2=prep_cross_attn(sd, t + ".attn2", device),
-                    norm3=prep_norm(sd, t + ".norm3", device), ff=prep_ff(sd, t + ".ff", device))
+    P = Prepared(norm=prep_norm(sd, p + ".norm", device), proj_in=prep_linear(sd, p + ".proj_in", device),
+                 proj_out=prep_linear(sd, p + ".proj_out", device),
+                 norm1=prep_norm(sd, t + ".norm1", device), attn1=prep_self_attn(sd, t + ".attn1", device, heads),
+                 norm1_5=prep_norm(sd, t + ".norm1_5", device),
+                 attn1_5=prep_cross_attn(sd, t + ".attn1_5", device, heads),
+                 norm2=prep_norm(sd, t + ".norm2", device), attn2=prep_cross_attn(sd, t + ".attn2", device),
+                 norm3=prep_norm(sd, t + ".norm3", device), ff=prep_ff(sd, t + ".ff", device))
+    # the four LayerNorms folded into their consumer GEMMs (qkv, the two q projections, the GEGLU projection)
+    w, b, rs = _qkv_rows(sd, t + ".attn1", device, heads, ["to_q", "to_k", "to_v"])
+    P["ln_qkv"] = fold_layernorm(w, b, sd[t + ".norm1.weight"], sd[t + ".norm1.bias"], device, row_scale=rs)
+    P["ln_q15"] = fold_layernorm(sd[t + ".attn1_5.to_q.weight"], None, sd[t + ".norm1_5.weight"],
+                                 sd[t + ".norm1_5.bias"], device)
+    P["ln_q2"] = fold_layernorm(sd[t + ".attn2.to_q.weight"], None, sd[t + ".norm2.weight"], sd[t + ".norm2.bias"],
+                                device)
+    P["ln_ff"] = fold_layernorm(sd[t + ".ff.net.0.proj.weight"], sd[t + ".ff.net.0.proj.bias"], sd[t + ".norm3.weight"],
+                                sd[t + ".norm3.bias"], device, interleave=True)
+    return P
 
 
 def prep_spatial_write(sd, p, device, heads=None):
@@ -166,8 +211,17 @@ def prep_motion(sd, p, device):
     attn = []
     for i in range(2):
         a = f"{b}.attention_blocks.{i}"
-        attn.append(Prepared(attn=prep_self_attn(sd, a, device), norm=prep_norm(sd, f"{b}.norms.{i}", device),
-                             pe=_dev(sd[a + ".pos_encoder.pe"][0], device, torch.float32)))
-    return Prepared(norm=prep_norm(sd, t + ".norm", device), proj_in=prep_linear(sd, t + ".proj_in", device),
-                    proj_out=prep_linear(sd, t + ".proj_out", device), attn=attn,
-                    ff_norm=prep_norm(sd, b + ".ff_norm", device), ff=prep_ff(sd, b + ".ff", device))
+        A = Prepared(attn=prep_self_attn(sd, a, device), norm=prep_norm(sd, f"{b}.norms.{i}", device),
+                     pe=_dev(sd[a + ".pos_encoder.pe"][0], device, torch.float32))
+        # LayerNorm folded into the fused QKV projection; the additive sinusoid table enters through the GEMM's
+        # row-bias: (LN(x) + pe[f]) W^T = LN(x) W^T + pe[f] W^T, one float32 row per frame
+        w, bq, _ = _qkv_rows(sd, a, device, None, ["to_q", "to_k", "to_v"])
+        A["ln_qkv"] = fold_layernorm(w, bq, sd[f"{b}.norms.{i}.weight"], sd[f"{b}.norms.{i}.bias"], device)
+        A["pe_rows"] = (A.pe @ w.to(BF16).float().t()).contiguous()              # [max_len, 3C]
+        attn.append(A)
+    P = Prepared(norm=prep_norm(sd, t + ".norm", device), proj_in=prep_linear(sd, t + ".proj_in", device),
+                 proj_out=prep_linear(sd, t + ".proj_out", device), attn=attn,
+                 ff_norm=prep_norm(sd, b + ".ff_norm", device), ff=prep_ff(sd, b + ".ff", device))
+    P["ln_ff"] = fold_layernorm(sd[b + ".ff.net.0.proj.weight"], sd[b + ".ff.net.0.proj.bias"],
+                                sd[b + ".ff_norm.weight"], sd[b + ".ff_norm.bias"], device, interleave=True)
+    return P
