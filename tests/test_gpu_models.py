@@ -219,6 +219,46 @@ def test_merged_unet_calls_are_bit_identical_on_the_gpu():
     assert torch.equal(outs[2], outs[4]) and torch.equal(outs[2], outs[6])
 
 
+def test_config3_window_geometry_at_sd15_widths_vs_oracle():
+    """BASELINE.json configs[2] geometry - 64 frames, context 16 / overlap 4 -> 5 windows [0, 12, 24, 36, 48] - with the
+    SD-1.5 widths (head dims 40 / 80 / 160, 16-frame temporal attention, merged UNet calls) on 8x8 latents, 2 DDIM
+    steps, against the fp32 oracle's mean-overlap loop (oracle/loop.py: pipelines/v_express_pipeline.py:498-500,526-583)
+    over the oracle UNet.  Tolerance of the loop tests: relative L2 <= 5e-2, cosine >= 0.998."""
+    _need_gpu()
+    from oracle import loop as OL, unet as OU
+    from v_express_amd import AutoencoderKLDecoder, DDIMScheduler, VExpressPipeline, synth
+    import ref_import as R
+    kw, Fn, cf, co, steps = cases.FULL, 64, 16, 4, 2
+    cfg, ocfg = cases.unet_cfg(kw), cases.oracle_cfg(kw)
+    sd3, sd2 = synth.unet3d_state_dict(cfg), synth.refnet_state_dict(cfg)
+    unet, refnet = build_models(kw, sd3, sd2)
+    vae = AutoencoderKLDecoder(synth.VaeConfig(**cases.SMALL_VAE)).to("cuda")
+    vae.load_state_dict(synth.vae_decoder_state_dict(synth.VaeConfig(**cases.SMALL_VAE)))
+    pipe = VExpressPipeline(vae=vae, reference_net=refnet, denoising_unet=unet,
+                            scheduler=DDIMScheduler(**R.NOISE_SCHEDULER_KWARGS))
+    inp = synth.synthetic_inputs(cfg, Fn, 8, 8)
+    assert OL.uniform_windows(Fn, cf, co) == [list(range(s, s + 16)) for s in (0, 12, 24, 36, 48)]
+    got = pipe(None, None, None, 64, 64, Fn, steps, cases.GUIDANCE, context_frames=cf, context_overlap=co,
+               reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD,
+               reference_latents=inp["ref_latents"], kps_features=inp["kps_features"],
+               audio_embeddings=inp["audio_embeddings"], latents=inp["latents"], decode=False).cpu()
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    try:
+        with torch.no_grad():
+            banks = OU.reader_banks(OU.refnet_banks(sd2, ocfg, inp["ref_latents"]))
+            ddim = OL.DDIM()
+            ref = OL.mean_overlap(lambda x, t, e, k: OU.unet3d_forward(sd3, ocfg, x, t, e, k, banks, cases.W_REF,
+                                                                       cases.W_AUD),
+                                  inp["latents"], ddim.set_timesteps(steps), ddim, OL.uniform_windows(Fn, cf, co),
+                                  cases.GUIDANCE, inp["kps_features"], inp["audio_embeddings"])
+    finally:
+        torch.set_num_threads(nthreads)
+    r, c = rel_l2(got, ref), cosine(got, ref)
+    print(f"[config-3 geometry, SD-1.5 widths, F=64 16/4, {steps} steps] relL2={r:.4g} cosine={c:.6f}")
+    assert torch.isfinite(got).all() and r <= 5e-2 and c >= 0.998, (r, c)
+
+
 def test_pipeline_without_cfg_vs_reference_golden():
     """guidance_scale = 1.0 through VExpressPipeline.__call__: no classifier-free guidance, batch of 1, the reference
     bank without the zero half (pipelines/v_express_pipeline.py:443,539,548; mutual_self_attention.py:357-363)."""
