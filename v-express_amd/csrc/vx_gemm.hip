@@ -67,9 +67,12 @@ __device__ __forceinline__ f32x4_t mfma16_f8(const uint4& a_lo, const uint4& a_h
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST, bool F8 = false>
+// LNF: a LayerNorm folded into the GEMM (vx_gemm_params.ln_stats) - a template flag, not a run-time branch: the
+// transform's live values pushed the 256 x 320 instantiations into 150-200 spilled registers when every kernel carried it.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST, bool F8 = false, bool LNF = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const vx_gemm_params p) {
   static_assert(!F8 || FAST, "fp8 operands use the FAST addressing only");
+  static_assert(!LNF || (FAST && !F8), "a folded LayerNorm sits in front of a plain bf16 linear");
   constexpr int ES = F8 ? 1 : 2;            // bytes per operand element
   constexpr int BKE = 128 / ES;             // elements per K-tile (one 128-byte LDS row)
   constexpr int CE = 16 / ES;               // elements per 16-byte chunk
@@ -334,24 +337,18 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
     }
   }
 
-  if (p.ln_stats != nullptr) {
+  if constexpr (LNF) {
     // folded LayerNorm: acc <- rstd[m] * (acc - mean[m] * colsum[n])   (see vx_gemm_params.ln_stats)
     const float2* __restrict__ st = reinterpret_cast<const float2*>(p.ln_stats);
     const float* __restrict__ cs = p.ln_colsum;
-    float mu[MI], rs[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const float2 t = st[min(wrow0 + i * 16 + lrow, p.m - 1)];
-      mu[i] = t.x;
-      rs[i] = t.y;
-    }
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const float4 s4 = *reinterpret_cast<const float4*>(cs + min(wcol0 + j * 16 + lq * 4, p.n - 4));
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        acc[i][j][0] = rs[i] * (acc[i][j][0] - mu[i] * s4.x); acc[i][j][1] = rs[i] * (acc[i][j][1] - mu[i] * s4.y);
-        acc[i][j][2] = rs[i] * (acc[i][j][2] - mu[i] * s4.z); acc[i][j][3] = rs[i] * (acc[i][j][3] - mu[i] * s4.w);
+      for (int j = 0; j < NI; ++j) {
+        const float4 s4 = *reinterpret_cast<const float4*>(cs + min(wcol0 + j * 16 + lq * 4, p.n - 4));
+        acc[i][j][0] = t.y * (acc[i][j][0] - t.x * s4.x); acc[i][j][1] = t.y * (acc[i][j][1] - t.x * s4.y);
+        acc[i][j][2] = t.y * (acc[i][j][2] - t.x * s4.z); acc[i][j][3] = t.y * (acc[i][j][3] - t.x * s4.w);
       }
     }
   }
@@ -614,14 +611,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vx_gemm_params
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST, bool F8 = false>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST, bool F8 = false, bool LNF = false>
 int launch_impl(const vx_gemm_params& p, hipStream_t stream) {
   constexpr int stage_bytes = STAGES * (BM + BN) * 128;
   constexpr int epi_bytes = (EPI == VX_EPI_SPLIT) ? BN * (64 + 4) * 4 : 0;   // V^T transposition slab
   constexpr int smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
   constexpr int nthreads = 64 * WARPS_M * WARPS_N;
   static bool attr_set = false;
-  auto kern = gemm_kernel<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, FAST, F8>;
+  auto kern = gemm_kernel<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, FAST, F8, LNF>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
@@ -659,6 +656,13 @@ namespace {
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI>
 int launch(const vx_gemm_params& p, hipStream_t stream) {
+  if (p.ln_stats != nullptr) {
+    if (!fast_ok(p)) {
+      vx_set_error("vx_gemm: a folded LayerNorm needs a plain linear (k %% 64 == 0, no padding / upsampling)");
+      return VX_ERR_UNSUPPORTED;
+    }
+    return launch_impl<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, true, false, true>(p, stream);
+  }
   if (fast_ok(p)) return launch_impl<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, true>(p, stream);
   return launch_impl<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, false>(p, stream);
 }
