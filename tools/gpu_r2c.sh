@@ -12,7 +12,7 @@ timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${T}_smoke
 timeout 900 python bench.py --steps 3 --warmup 1 --gemm-shapes $OUT/${T}_gemm_by_shape.txt > $OUT/${T}_bench.json 2> $OUT/${T}_bench.err
 bash tools/gpu_profile.sh $T
 bash tools/exp_pmc_bench.sh $T > $OUT/${T}_pmc_bench.log 2>&1
-VX_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 8 --steps 1 --warmup 0 --ddim-steps 2 --no-roofline > $OUT/${T}_bench_8rank_folded.json 2> $OUT/${T}_bench_8rank_folded.err
+VX_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 1 --warmup 0 --ddim-steps 2 --no-roofline > $OUT/${T}_bench_2rank_folded.json 2> $OUT/${T}_bench_2rank_folded.err
 timeout 600 python bench.py --steps 1 --warmup 1 --frames 124 --no-cpu-baseline --no-roofline > $OUT/${T}_bench_F124_1gpu.json 2> $OUT/${T}_bench_F124_1gpu.err
 timeout 600 python bench.py --steps 1 --warmup 1 --frames 64 --no-cpu-baseline --no-roofline > $OUT/${T}_bench_F64_1gpu.json 2> $OUT/${T}_bench_F64_1gpu.err
 tail -4 $OUT/${T}_pytest_gpu.log; tail -1 $OUT/${T}_smoke.log
@@ -25,4 +25,4 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
 done
-tail -3 $OUT/${T}_bench_8rank_folded.err
+tail -3 $OUT/${T}_bench_2rank_folded.err
