@@ -793,7 +793,18 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
     if (p.n <= 32) return launch<256, 32, 4, 1, 2, VX_EPI_STORE>(p, stream);
     if (use_big(p)) return launch<256, 320, 4, 2, 2, VX_EPI_STORE>(p, stream);
     if (use_small64(p)) return launch<64, 160, 1, 2, 3, VX_EPI_STORE>(p, stream);
-    if (prefer160(p.n)) return launch<128, 160, 2, 2, 2, VX_EPI_STORE>(p, stream);
+    if (prefer160(p.n)) {
+      // pipeline depth of the 128 x 160 tile (VX_GEMM_STAGES128 = 2 | 3 | 4; A/B knob): the 16x16-level launches are
+      // DMA-latency bound at depth 2 (8192 x 1280 x 1280: 2 us per K-tile against 0.3 us of MFMA work)
+      static int st = -1;
+      if (st < 0) {
+        const char* e = getenv("VX_GEMM_STAGES128");
+        st = e ? atoi(e) : 2;
+      }
+      if (st == 3) return launch<128, 160, 2, 2, 3, VX_EPI_STORE>(p, stream);
+      if (st == 4) return launch<128, 160, 2, 2, 4, VX_EPI_STORE>(p, stream);
+      return launch<128, 160, 2, 2, 2, VX_EPI_STORE>(p, stream);
+    }
     return launch<128, 128, 2, 2, 2, VX_EPI_STORE>(p, stream);
   } else if (p.epi == VX_EPI_GEGLU) {
     VX_REQUIRE(p.out != nullptr && (p.n % 32) == 0 && (p.ldc % 8) == 0,
