@@ -70,14 +70,17 @@ def _pmc_traffic(kernel_key):
     want = "gemm_ring_kernel<0," if "STORE" in kernel_key else ("gemm_ring_kernel<1," if "GEGLU" in kernel_key else None)
     if want is None or "gemm_ring" not in kernel_key:
         return None, None
-    with open(files[-1]) as f:
-        d = json.load(f)
-    n = b = 0.0
-    for k, v in d.items():
-        if want in k:
-            n += v["launches"]
-            b += v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
-    return (b / n, os.path.relpath(files[-1], ROOT)) if n else (None, None)
+    for path in reversed(files):                       # newest profile that actually holds both passes for this kernel
+        with open(path) as f:
+            d = json.load(f)
+        n = b = 0.0
+        for k, v in d.items():
+            if want in k and v["launches"] and v["fetch_bytes_per_launch"] > 0:
+                n += v["launches"]
+                b += v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
+        if n:
+            return b / n, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def _pick_threads():
