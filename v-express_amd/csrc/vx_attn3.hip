@@ -16,6 +16,11 @@
 //   * Keys are permuted inside a tile on the DMA source side (LDS row r holds key pi(r) = 32(r>>5) + 8((r>>2)&3) +
 //     4((r>>4)&1) + (r&3)) so that the 8 P^T values a lane owns after two S^T tiles are 8 CONSECUTIVE keys: the V^T
 //     A-operand is one ds_read_b128 per MFMA instead of two ds_read_b64.
+//   * QK32: QK^T on v_mfma_f32_32x32x16_bf16 - its K dimension steps by 16, so d = 40 (+ the shift column) pads to 48
+//     instead of 64: 6 x 32 = 192 matrix cycles per 64-key tile instead of 16 x 16 = 256 (the kernel is matrix-pipe
+//     bound).  A lane then owns query l & 31 and 16 keys of each 32-key tile; v_permlane16_swap of the packed P^T halves
+//     hands every 16-lane row the 8 consecutive keys the 16x16x32 PV MFMA wants (8 swaps per tile), with the matching key
+//     permutation on the DMA source side.
 //   * PIPE: the S^T tile of key tile t+1 is multiplied while the exponentials of tile t are taken (two S^T register
 //     sets, static ping-pong); needs NBUF = 3.
 // Rows whose probabilities underflow under the bound (row sum < 2^-100) are detected block-uniformly; the block then
@@ -55,11 +60,25 @@ constexpr int A3_V = 5120;                // V^T: [48 rows][128 B], chunk ^= (ro
 constexpr int A3_STAGE = 5120 + 48 * 128; // 11264
 constexpr int A3_QT = 2;                  // 16-query tiles per wave (32 queries per wave, 128 per block)
 
-__device__ __forceinline__ int a3_pi(int r) { return 32 * (r >> 5) + 8 * ((r >> 2) & 3) + 4 * ((r >> 4) & 1) + (r & 3); }
+__device__ __forceinline__ int a3_pi16(int r) { return 32 * (r >> 5) + 8 * ((r >> 2) & 3) + 4 * ((r >> 4) & 1) + (r & 3); }
+// QK32: row r of a 32-key S^T tile (C register (r&3) + 8 (r>>2) of lane half 4 (l>>5)) holds key
+// 16 b2 + 8 b4 + 4 b3 + (r & 3): the 8 packed values a 16-lane row presents to the PV MFMA after the swap are then keys 8 g .. 8 g + 7
+__device__ __forceinline__ int a3_pi32(int r) {
+  return 32 * (r >> 5) + 16 * ((r >> 2) & 1) + 8 * ((r >> 4) & 1) + 4 * ((r >> 3) & 1) + (r & 3);
+}
+template <bool QK32>
+__device__ __forceinline__ int a3_pi(int r) { return QK32 ? a3_pi32(r) : a3_pi16(r); }
 
-template <int NBUF, bool PIPE, bool UNIT>   // UNIT: p.c == 1 (K already carries scale * log2 e)
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0,
+                                                 0);
+}
+
+template <int NBUF, bool PIPE, bool UNIT, bool QK32 = false>   // UNIT: p.c == 1 (K already carries scale * log2 e)
 __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Params p) {
   static_assert(!PIPE || NBUF == 3, "the pipelined loop needs three stages");
+  static_assert(!(PIPE && QK32), "the 32x32 QK^T body is built for the plain loop only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ONES = NBUF * A3_STAGE, ZERO = ONES + 1024;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -96,10 +115,10 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
     is_k[s] = pw < 5;
     if (pw < 4) {
       const int r = 16 * pw + (lane >> 2), pos = lane & 3, chunk = pos ^ ((0 - (r >> 2)) & 3);
-      src0[s] = ((uint32_t)a3_pi(r) * (uint32_t)p.ldk + 8u * chunk) * 2u;
+      src0[s] = ((uint32_t)a3_pi<QK32>(r) * (uint32_t)p.ldk + 8u * chunk) * 2u;
       dst[s] = A3_K0 + pw * 1024;
     } else if (pw == 4) {
-      src0[s] = ((uint32_t)a3_pi(lane) * (uint32_t)p.ldk + 32u) * 2u;
+      src0[s] = ((uint32_t)a3_pi<QK32>(lane) * (uint32_t)p.ldk + 32u) * 2u;
       dst[s] = A3_K1;
     } else {
       const int r = 8 * (pw - 5) + (lane >> 3), pos = lane & 7, chunk = pos ^ ((r >> 1) & 7);
@@ -118,7 +137,7 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
     uint32_t off = src0[s] + (uint32_t)te * (is_k[s] ? kstep : vstep);
     if (pw < 5) {
       const int r = pw < 4 ? 16 * pw + (lane >> 2) : lane;
-      const int over = te * 64 + a3_pi(r) - (p.n_kv - 1);
+      const int over = te * 64 + a3_pi<QK32>(r) - (p.n_kv - 1);
       if (over > 0) off -= (uint32_t)over * (uint32_t)p.ldk * 2u;
     } else {
       const int r = 8 * (pw - 5) + (lane >> 3), pos = lane & 7, chunk = pos ^ ((r >> 1) & 7);
@@ -181,6 +200,38 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
     for (int qt = 0; qt < A3_QT; ++qt)
       if (g == 1) qf[qt][1] = make_uint4((uint32_t)f32_to_bf16(-m[qt]), 0, 0, 0);
   };
+
+  // ---- QK32: lane (query l & 31, half hi = l >> 5); k-step s covers d 16 s .. 16 s + 15: chunk 2 s + hi
+  const int q32 = lane & 31, hi = lane >> 5;
+  uint4 qf32[3];
+  float mfix32 = 0.f;
+  if constexpr (QK32) {
+    const int qrow = q0 + q32;
+    float ss = 0.f;
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+      const int dcol = 16 * st + 8 * hi;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qrow < p.n_q && dcol < A3_D) {
+        v = *reinterpret_cast<const uint4*>(p.q + (size_t)(b * p.n_q + qrow) * p.ldq + h * A3_D + dcol);
+        float f[8];
+        unpack_bf16x8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+      }
+      qf32[st] = v;
+    }
+    ss = wave_xor_sum(ss, 32);
+    mfix32 = sqrtf(ss) * p.kmax[kvb * p.heads + h];
+  }
+  auto set_shift32 = [&](float m) {
+    if (hi == 1) qf32[2] = make_uint4((uint32_t)f32_to_bf16(-m), 0, 0, 0);
+  };
+  const int sw32 = (0 - (q32 >> 2)) & 3;
+  const int a_k32_0 = A3_K0 + q32 * 64 + (((0 + hi) ^ sw32) << 4);                 // + kt32 * 2048   (d  0..15)
+  const int a_k32_1 = A3_K0 + q32 * 64 + (((2 + hi) ^ sw32) << 4);                 //                 (d 16..31)
+  const int a_k32_2 = (hi == 0 ? A3_K1 : ONES) + q32 * 16;                         // + kt32 * 512    (d 32..47)
+  const int k32_stage = hi == 0 ? 1 : 0;
 
   // ---- per-lane LDS read offsets (stage offset added per tile)
   const int a_k0 = A3_K0 + i * 64 + ((g ^ ((0 - (i >> 2)) & 3)) << 4);             // + kt * 1024
@@ -270,7 +321,66 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
     }
   };
 
+  // ---- QK32 body: S^T as two 32 x 32 tiles (register r of tile kt32: key 32 kt32 + pi32((r&3) + 8 (r>>2) + 4 hi))
+  auto qk32 = [&](f32x16_t (&s_)[2], int t) {
+    const int so = (t % NBUF) * A3_STAGE;
+    const char* k0 = smem + a_k32_0 + so;
+    const char* k1 = smem + a_k32_1 + so;
+    const char* k2 = smem + a_k32_2 + so * k32_stage;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const uint4 f0 = *reinterpret_cast<const uint4*>(k0 + kt * 2048);
+      const uint4 f1 = *reinterpret_cast<const uint4*>(k1 + kt * 2048);
+      const uint4 f2 = *reinterpret_cast<const uint4*>(k2 + kt * 512);
+      f32x16_t z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+      z = mfma32(f0, qf32[0], z);
+      z = mfma32(f1, qf32[1], z);
+      s_[kt] = mfma32(f2, qf32[2], z);
+    }
+  };
+  auto mask32 = [&](f32x16_t (&s_)[2], int t) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (t * 64 + 32 * kt + a3_pi32((r & 3) + 8 * (r >> 2) + 4 * hi) >= p.n_kv) s_[kt][r] = -INFINITY;
+  };
+  auto expo32 = [&](f32x16_t (&s_)[2]) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_[kt][r] = __builtin_amdgcn_exp2f(UNIT ? s_[kt][r] : s_[kt][r] * p.c);
+  };
+  // O^T += V^T(t) P^T: registers 0..7 / 8..15 of a tile are two key octets of THIS lane's query; swapping the odd 16-lane
+  // rows of the first with the even rows of the second gives, per 16-query tile, lane row g the octet g of query l & 15
+  auto pv32 = [&](const f32x16_t (&s_)[2], int t) {
+    const int so = (t % NBUF) * A3_STAGE;
+#pragma unroll
+    for (int ks_ = 0; ks_ < 2; ++ks_) {
+      const f32x16_t& a = s_[ks_];
+      uint32_t fx[4], gx[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t fo = pack_bf16x2(a[2 * e], a[2 * e + 1]), go = pack_bf16x2(a[8 + 2 * e], a[8 + 2 * e + 1]);
+        auto sw = __builtin_amdgcn_permlane16_swap(fo, go, false, false);
+        fx[e] = sw[0];
+        gx[e] = sw[1];
+      }
+      const uint4 pb[A3_QT] = {make_uint4(fx[0], fx[1], fx[2], fx[3]), make_uint4(gx[0], gx[1], gx[2], gx[3])};
+      const char* vp = smem + (ks_ ? a_v1 : a_v0) + so;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) {
+        const uint4 vf = *reinterpret_cast<const uint4*>(vp + dt * 2048);
+#pragma unroll
+        for (int qt = 0; qt < A3_QT; ++qt) o[dt][qt] = mfma16(vf, pb[qt], o[dt][qt]);
+      }
+    }
+  };
+
   // ---- the key loop.  MAXPASS: QK^T only, running row maxima into mrun (the exact-shift fallback).
+  float mrun32 = -INFINITY;
   float mrun[A3_QT];
   auto run = [&](auto maxpass_c) {
     constexpr bool MAXPASS = decltype(maxpass_c)::value;
@@ -312,6 +422,21 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
         wait_dma(NBUF == 3 && t + 1 < n_tiles);
         if (!A3ABL(16)) __syncthreads();   // tile t landed for everyone; everyone is done with tile t-1
         if (t + NBUF - 1 < n_tiles) issue(t + NBUF - 1);
+        if constexpr (QK32) {
+          f32x16_t c32[2];
+          qk32(c32, t);
+          if (ragged && t == n_tiles - 1) mask32(c32, t);
+          if (MAXPASS) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) mrun32 = fmaxf(mrun32, c32[kt][r]);
+          } else {
+            expo32(c32);
+            pv32(c32, t);
+          }
+          continue;
+        }
         f32x4_t cur[4][A3_QT];
         qk(cur, t);
         if (ragged && t == n_tiles - 1) mask(cur, t);
@@ -334,7 +459,8 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
   // softmax denominator of query tile qt: O^T row 40 (fragment 2, lane group 2, register 0), for every lane of the column
   auto row_sum = [&](int qt) -> float { return __shfl(o[2][qt][0], i + 32, 64); };
 
-  set_shift(mfix);
+  if constexpr (QK32) set_shift32(mfix32);
+  else set_shift(mfix);
   zero_o();
   run(std::false_type{});
   bool bad = false;
@@ -345,13 +471,20 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
   }
   if (__syncthreads_or(bad)) {   // block-uniform (the stages are shared by the 4 waves)
     const float zero[A3_QT] = {0.f, 0.f};
-    set_shift(zero);
+    if constexpr (QK32) set_shift32(0.f);
+    else set_shift(zero);
+    mrun32 = -INFINITY;
 #pragma unroll
     for (int qt = 0; qt < A3_QT; ++qt) mrun[qt] = -INFINITY;
     run(std::true_type{});
+    if constexpr (QK32) {
+      mrun32 = wave_xor_max(mrun32, 32);
+      set_shift32(mrun32);
+    } else {
 #pragma unroll
-    for (int qt = 0; qt < A3_QT; ++qt) mrun[qt] = wave_rows_max(mrun[qt]);
-    set_shift(mrun);
+      for (int qt = 0; qt < A3_QT; ++qt) mrun[qt] = wave_rows_max(mrun[qt]);
+      set_shift(mrun);
+    }
     zero_o();
     run(std::false_type{});
   }
@@ -376,10 +509,10 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
   }
 }
 
-template <int NBUF, bool PIPE, bool UNIT>
+template <int NBUF, bool PIPE, bool UNIT, bool QK32 = false>
 int launch_attn3(const Attn3Params& p, hipStream_t stream) {
   constexpr int smem = NBUF * A3_STAGE + 2048;
-  auto kern = attn3_kernel<NBUF, PIPE, UNIT>;
+  auto kern = attn3_kernel<NBUF, PIPE, UNIT, QK32>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -396,7 +529,8 @@ int launch_attn3(const Attn3Params& p, hipStream_t stream) {
 
 }  // namespace
 
-// variant: 0 = off (attn2), 1 = NBUF 2 (default), 2 = NBUF 3, 3 = NBUF 3 + in-wave pipeline; VX_ATTN3 overrides.
+// variant: 0 = off (attn2), 1 = NBUF 2 (default), 2 = NBUF 3, 3 = NBUF 3 + in-wave pipeline, 4 = NBUF 2 with QK^T on
+// the 32x32x16 MFMA; VX_ATTN3 overrides.
 // The three variants measure within 3 % of each other (profiles/r02a_attn_bench.txt, r02b_attn3_ablation.txt): the
 // kernel is matrix-pipe / power bound (SQ_VALU_MFMA_BUSY_CYCLES = 61 % of the SIMD cycles at an effective 1.66 GHz,
 // profiles/r02b_attn3_pmc.txt), so neither the ring depth nor the in-wave overlap of exp and MFMA moves it.
@@ -418,6 +552,7 @@ int vx_attn3_launch(const void* q, int ldq, const void* k, int ldk, const void* 
   switch (vx_attn3_variant()) {
     case 2: return unit ? launch_attn3<3, false, true>(p, stream) : launch_attn3<3, false, false>(p, stream);
     case 3: return unit ? launch_attn3<3, true, true>(p, stream) : launch_attn3<3, true, false>(p, stream);
+    case 4: return unit ? launch_attn3<2, false, true, true>(p, stream) : launch_attn3<2, false, false, true>(p, stream);
     default: return unit ? launch_attn3<2, false, true>(p, stream) : launch_attn3<2, false, false>(p, stream);
   }
 }
