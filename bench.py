@@ -209,6 +209,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus})")
     # VX_DIST_BACKEND=gloo (+ ranks folded onto the visible GPUs) exists only to exercise the multi-rank control flow on
     # a single-GPU box; the measured configuration is one rank per GPU over RCCL ("nccl").
     backend = os.environ.get("VX_DIST_BACKEND", "nccl")
@@ -220,9 +223,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
-                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus})")
 
     import v_express_amd as vx
     from v_express_amd import ops, synth

@@ -347,3 +347,20 @@ def test_ring_dma_schedule_is_race_free():
     in_checker = sorted({e[1] for g in (0, 1) for S, nk in ((1, 1), (2, 1), (10, 5)) for e in orig(g, S, nk)
                          if e[0] == "wait"})
     assert in_kernel == in_checker, (in_kernel, in_checker)
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus(tmp_path):
+    """bench.py: `--gpus N` without a torchrun environment re-launches N ranks - and says so loudly when the box has
+    fewer GPUs; inside a torchrun environment a WORLD_SIZE that differs from --gpus is an error, never a silent
+    single-rank run that prints n_gpus = 1."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VX_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "only 0 GPU(s) are visible" in (r.stdout + r.stderr)
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], cwd=root, env=env2,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr), r.stdout[-500:] + r.stderr[-500:]
