@@ -8,7 +8,6 @@ Both models are compositions of the hot-path kernels: every convolution is the i
 the rest of the path; the kps features are produced directly in the `[b, F, hw, 320]` token layout the denoising
 loop consumes (the reference moves them to the CPU and back every window, pipelines/v_express_pipeline.py:363,531).
 """
-from types import SimpleNamespace
 
 import torch
 
