@@ -126,7 +126,8 @@ def _spawn(world, F, cs, co, steps, S):
     return results
 
 
-@pytest.mark.parametrize("world,S,F,cs,co", [(2, 2, 8, 8, 2), (4, 2, 8, 8, 2), (4, 2, 14, 8, 2), (4, 4, 8, 8, 2)])
+@pytest.mark.parametrize("world,S,F,cs,co", [(2, 2, 8, 8, 2), (4, 2, 8, 8, 2), (4, 2, 14, 8, 2), (4, 4, 8, 8, 2),
+                                             (4, 1, 32, 8, 2)])      # last: 5 windows on 4 ranks, balanced assignment
 def test_frame_sharded_units_are_bit_identical_to_single_process(world, S, F, cs, co):
     """S ranks share each (window, CFG-half) unit, each holding f/S frames; the temporal mixing
     runs in the pixel-shard layout between two all-to-alls inside the unit's process group (world/S groups work on
@@ -134,6 +135,31 @@ def test_frame_sharded_units_are_bit_identical_to_single_process(world, S, F, cs
     ref = run_loop(0, 1, F, cs, co, 2, distributed.DistContext())
     for rank, out, _ in _spawn(world, F, cs, co, 2, S):
         assert torch.equal(out, ref), f"rank {rank} diverged from the single-process loop"
+
+
+def test_balanced_unit_assignment_for_uneven_cfg_clips():
+    """partition_units: every unit exactly once, sizes differ by at most one; on the config-4 clip (10 windows, 8 ranks)
+    the 3-unit ranks hold a whole window plus a lone UNCONDITIONAL half, the orphaned conditional halves sit in pairs on
+    2-unit ranks; where the balanced form does not apply the blocks stay contiguous."""
+    D = distributed
+    for W in range(1, 14):
+        for R in (1, 2, 3, 4, 6, 8):
+            for halves in (1, 2):
+                a = D.partition_units(W, R, halves)
+                assert sorted(u for x in a for u in x) == [(w, h) for w in range(W) for h in range(halves)]
+                assert max(len(x) for x in a) - min(len(x) for x in a) <= 1
+                sch = D.UnitSchedule(W, R, 1, halves)
+                for r in range(R):                      # slots follow the call order (what pack_rows relies on)
+                    rows = [(w, h) for w, hs in sch.calls(r) for h in hs]
+                    assert [sch.slot[u] for u in rows] == [(r, i) for i in range(len(rows))]
+    a = D.partition_units(10, 8)
+    assert [len(x) for x in a] == [3, 3, 3, 3, 2, 2, 2, 2]
+    for r in range(4):
+        lone = [u for u in a[r] if sum(1 for v in a[r] if v[0] == u[0]) == 1]
+        assert len(lone) == 1 and lone[0][1] == 0, a[r]          # the lone half of a heavy rank is the uncond one
+    assert a[4] == [(4, 1), (5, 1)] and a[5] == [(6, 1), (7, 1)] and a[6] == [(8, 0), (8, 1)]
+    assert D.partition_units(10, 4) == [[(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)], [(2, 1), (3, 0), (3, 1), (4, 0), (4, 1)],
+                                        [(5, 0), (5, 1), (6, 0), (6, 1), (7, 0)], [(7, 1), (8, 0), (8, 1), (9, 0), (9, 1)]]
 
 
 def test_frame_shard_schedule_and_auto_policy():

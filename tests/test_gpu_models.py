@@ -415,7 +415,7 @@ def test_bench_two_rank_control_flow_on_one_gpu():
     assert d["same_clip_1gpu_fps"] > 0 and d["speedup_vs_1gpu_same_clip"] > 0
 
 
-@pytest.mark.parametrize("world,S,F,cf,co", [(2, 2, 8, 8, 2), (4, 0, 8, 8, 2), (4, 2, 14, 8, 2)])
+@pytest.mark.parametrize("world,S,F,cf,co", [(2, 2, 8, 8, 2), (4, 0, 8, 8, 2), (4, 2, 14, 8, 2), (4, 1, 32, 8, 2)])
 def test_frame_sharded_loop_matches_single_rank(world, S, F, cf, co, tmp_path):
     """SURVEY.md §8f rank 1 on the real kernels: S ranks per (window, CFG-half) unit, each running the UNet on f/S
     frames with the motion modules exchanging layouts through all-to-alls inside the unit's process group (ranks folded

@@ -150,7 +150,7 @@ def _worker(rank, world, port, F, cf, co, S, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,S,F,cf,co", [(2, 2, 8, 8, 2), (4, 0, 8, 8, 2), (2, 1, 14, 8, 2)])
+@pytest.mark.parametrize("world,S,F,cf,co", [(2, 2, 8, 8, 2), (4, 0, 8, 8, 2), (2, 1, 14, 8, 2), (4, 1, 32, 8, 2)])
 def test_sharded_loop_with_the_real_host_code_matches_single_process(emulated, world, S, F, cf, co):
     """`VExpressPipeline.denoise` + `UNet3DConditionModel.forward_tokens` + `blocks.motion_module(shard=)` under real
     process groups (gloo): unit sharding (S = 1), frame sharding (S = 2) and the automatic policy (S = 0: 4 ranks, one
