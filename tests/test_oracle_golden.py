@@ -78,6 +78,24 @@ def test_ddim_constants_match_scheduler():
     assert d.set_timesteps(25) == g["timesteps"].tolist() == list(range(999, 0, -40))
     assert torch.allclose(d.alphas_cumprod, g["alphas_cumprod"], atol=1e-7)
     assert d.alphas_cumprod[999].item() == 0.0        # zero terminal SNR
+    # known answers that do not pass through the diffusers stand-in: the Stable Diffusion schedule's published
+    # endpoints (abar_0 = 1 - 0.00085, abar_999 = 0.00466) and the zero-terminal-SNR rescale of them in closed form
+    import numpy as np
+    betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2
+    abar = np.cumprod(1.0 - betas)
+    assert abs(abar[0] - 0.99915) < 1e-9 and abs(abar[-1] - 0.00466) < 1e-5
+    r = np.sqrt(abar)
+    want = ((r - r[-1]) * r[0] / (r[0] - r[-1])) ** 2
+    assert np.abs(d.alphas_cumprod.double().numpy() - want).max() < 2e-6
+    # one DDIM step (eta = 0, v-prediction) keeps a sample that the model predicts perfectly on its trajectory:
+    # x_t = sqrt(a) x0 + sqrt(1-a) eps, v = sqrt(a) eps - sqrt(1-a) x0  ->  x_prev = sqrt(a') x0 + sqrt(1-a') eps
+    gen = torch.Generator().manual_seed(3)
+    x0, eps = torch.randn(64, generator=gen), torch.randn(64, generator=gen)
+    for t in (959, 479, 39):
+        a, ap = d.alphas_cumprod[t], (d.alphas_cumprod[t - 40] if t >= 40 else torch.tensor(1.0))
+        xt = a.sqrt() * x0 + (1 - a).sqrt() * eps
+        v = a.sqrt() * eps - (1 - a).sqrt() * x0
+        assert torch.allclose(d.step(v, t, xt), ap.sqrt() * x0 + (1 - ap).sqrt() * eps, atol=2e-6)
 
 
 def test_prologue_oracle_matches_reference_golden():
