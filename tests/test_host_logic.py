@@ -334,18 +334,23 @@ def test_ring_dma_schedule_is_race_free():
     for nk in (1, 2, 3, 5, 9, 10, 45, 90):
         for tiles in (1, 2, 3, 4):
             assert m.check(nk * tiles, nk) is None, (nk, tiles)
+            for variant in (1, 2, 3):   # the experimental issue placements (VX_RING_MISSUE)
+                assert m.check(nk * tiles, nk, variant) is None, (nk, tiles, variant)
     orig = m.program
-    for old, new in ((13, 14), (11, 12), (15, 16), (9, 10), (3, 4)):
-        m.program = lambda g, S, nk, o=old, n=new: [("wait", n) if e == ("wait", o) else e for e in orig(g, S, nk)]
-        assert m.check(10, 5) is not None, f"vmcnt({old}) -> vmcnt({new}) went unnoticed"
+    for variant, bumps in ((0, ((13, 14), (11, 12), (15, 16), (9, 10), (3, 4))), (1, ((14, 15), (10, 11))),
+                           (2, ((12, 13), (14, 15), (10, 11))), (3, ((9, 10), (11, 12)))):
+        for old, new in bumps:
+            m.program = lambda g, S, nk, mi=0, o=old, n=new: [("wait", n) if e == ("wait", o) else e
+                                                              for e in orig(g, S, nk, mi)]
+            assert m.check(10, 5, variant) is not None, f"variant {variant}: vmcnt({old}) -> vmcnt({new}) went unnoticed"
     m.program = orig
     # the immediates of the kernel source are the ones the checker replays
     src = open(os.path.join(os.path.dirname(path), "..", "v-express_amd", "csrc", "vx_gemm_ring.hip")).read()
     import re
     in_kernel = sorted({int(v) for v in re.findall(r"RING_WAIT_VM\((\d+)\)", src)} |
                        {int(v) for v in re.findall(r"ring_wait_vm<(\d+)>\(\)", src)})
-    in_checker = sorted({e[1] for g in (0, 1) for S, nk in ((1, 1), (2, 1), (10, 5)) for e in orig(g, S, nk)
-                         if e[0] == "wait"})
+    in_checker = sorted({e[1] for g in (0, 1) for S, nk in ((1, 1), (2, 1), (10, 5)) for mi in (0, 1, 2, 3)
+                         for e in orig(g, S, nk, mi) if e[0] == "wait"})
     assert in_kernel == in_checker, (in_kernel, in_checker)
 
 

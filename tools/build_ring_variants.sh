@@ -9,6 +9,10 @@ done
 for m in 1 64 65; do
   /opt/rocm/bin/hipcc $F -DVX_GEMM_ABLATE=$m vx_gemm.hip vx_gemm_ring.hip vx_norm.hip -x hip vx_api.cpp -o ../../tools/ringlibs/cabl$m.so &
 done
+for m in 0 1 2 3; do   # experimental issue placements (tools/exp_ring_missue.sh)
+  /opt/rocm/bin/hipcc $F -DVX_RING_MISSUE=$m vx_gemm.hip vx_gemm_ring.hip vx_norm.hip -x hip vx_api.cpp -o ../../tools/ringlibs/mi$m.so &
+  /opt/rocm/bin/hipcc $F -DVX_RING_MISSUE=$m -DVX_RING_TRACE vx_gemm.hip vx_gemm_ring.hip vx_norm.hip -x hip vx_api.cpp -o ../../tools/ringlibs/mi${m}_trace.so &
+done
 /opt/rocm/bin/hipcc $F -DVX_RING_TRACE vx_gemm.hip vx_gemm_ring.hip vx_norm.hip -x hip vx_api.cpp -o ../../tools/ringlibs/trace.so &
 wait
 ls -la ../../tools/ringlibs

@@ -21,8 +21,9 @@ GROUPS = {0: ["B0", "B1", "B2"], 1: ["B3", "B4", "A0"], 2: ["A1", "A2"], 3: ["A3
 B_PIECES = ["B0", "B1", "B2", "B3", "B4"]
 
 
-def program(grp, S, nk):
-    """Event list of one wave of wave row `grp`: ("issue", u, piece) | ("wait", n) | ("read", u, piece) | ("lgkm0",) |
+def program(grp, S, nk, m_issue=0):
+    """m_issue: the experimental placements of vx_gemm_ring.hip's VX_RING_MISSUE (0 = product schedule).
+    Event list of one wave of wave row `grp`: ("issue", u, piece) | ("wait", n) | ("read", u, piece) | ("lgkm0",) |
     ("bar",).  Mirrors the kernel: prologue (vx_gemm_ring.hip 'prologue'), then per output tile the stagger barrier
     of row 1, nk x ktile(e1, e2), the re-align barrier of row 0."""
     ev = []
@@ -35,9 +36,9 @@ def program(grp, S, nk):
         issue_group(g)
     iss += 1
     if S > 1:
-        for g in range(3):
+        for g in range(2 if m_issue == 3 else 3):
             issue_group(g)
-        ev.append(("wait", 11))
+        ev.append(("wait", 9 if m_issue == 3 else 11))
     else:
         ev.append(("wait", 3))
     ev.append(("bar",))
@@ -55,6 +56,8 @@ def program(grp, S, nk):
                 ev.append(("read", u, f"A{ph}"))
                 if ph == 0:
                     if e1:
+                        if m_issue == 3:
+                            issue_group(2)     # A1, A2 of u+1
                         issue_group(3)         # A3 of u+1 (iss == u+1 here)
                         iss += 1
                         ev.append(("wait", 11))
@@ -62,25 +65,46 @@ def program(grp, S, nk):
                         ev.append(("wait", 2))
                 elif ph == 1:
                     if e2:
-                        issue_group(0)
-                        ev.append(("wait", 13))
+                        if m_issue == 2:
+                            ev.append(("issue", iss, "B0")); ev.append(("issue", iss, "B1"))
+                            ev.append(("wait", 12))
+                        else:
+                            issue_group(0)
+                            ev.append(("wait", 13))
                     else:
                         ev.append(("wait", 10 if e1 else 1))
                 elif ph == 2:
                     if e2:
-                        issue_group(1)
-                        ev.append(("wait", 15))
+                        if m_issue in (1, 2):
+                            ev.append(("issue", iss, "B3")); ev.append(("issue", iss, "B4"))
+                            ev.append(("wait", 14))
+                        else:
+                            issue_group(1)
+                            ev.append(("wait", 15))
                     else:
                         ev.append(("wait", 9 if e1 else 0))
                 else:
                     if e2:
-                        issue_group(2)
-                        ev.append(("wait", 11))
+                        if m_issue in (1, 2):
+                            ev.append(("issue", iss, "A1"))
+                            ev.append(("wait", 10))
+                        elif m_issue == 3:
+                            ev.append(("wait", 9))
+                        else:
+                            issue_group(2)
+                            ev.append(("wait", 11))
                     else:
                         ev.append(("wait", 3 if e1 else 0))
                 ev.append(("lgkm0",))
                 ev.append(("bar",))
-                ev.append(("bar",))            # (M slot between the two barriers: MFMAs only)
+                # M slot between the two barriers: MFMAs, and under m_issue the copies that left the L slots
+                if e2 and m_issue == 2 and ph == 1:
+                    ev.append(("issue", iss, "B2"))
+                if e2 and m_issue in (1, 2) and ph == 2:
+                    ev.append(("issue", iss, "A0"))
+                if e2 and m_issue in (1, 2) and ph == 3:
+                    ev.append(("issue", iss, "A2"))
+                ev.append(("bar",))
             u += 1
         if grp == 0:
             ev.append(("bar",))
@@ -115,8 +139,8 @@ def annotate(ev):
     return dict(bars=bars, retired_at=retired_at, issued_at=issued_at, reads=reads, unretired=pending)
 
 
-def check(S, nk):
-    agents = [annotate(program(g, S, nk)) for g in (0, 1)]
+def check(S, nk, m_issue=0):
+    agents = [annotate(program(g, S, nk, m_issue)) for g in (0, 1)]
     if agents[0]["bars"] != agents[1]["bars"]:
         return f"barrier counts differ: {agents[0]['bars']} vs {agents[1]['bars']}"
     for a in agents:
@@ -143,9 +167,11 @@ def check(S, nk):
 
 
 def main():
+    import sys
+    m_issue = int(sys.argv[sys.argv.index("--m-issue") + 1]) if "--m-issue" in sys.argv else 0
     bad = 0
     for nk, tiles in itertools.product((1, 2, 3, 5, 10, 45), (1, 2, 3)):
-        err = check(nk * tiles, nk)
+        err = check(nk * tiles, nk, m_issue)
         print(f"nk={nk:3d} tiles={tiles}: {'ok' if err is None else err}")
         bad += err is not None
     raise SystemExit(1 if bad else 0)

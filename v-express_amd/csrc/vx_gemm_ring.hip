@@ -57,6 +57,20 @@ constexpr int R_LDS_BYTES = 2 * BUF_BYTES;  // 147,456
 #else
 #define RABL(bit) false
 #endif
+// Experimental issue placement (tools/build_ring_variants.sh builds one library per value; the product library is built
+// without): some copies move from the L slots into the issuing wave's own M slot, after its 10th MFMA.
+//   1: A0 of u+2 in M(t,2), A2 of u+2 in M(t,3)            2: additionally B2 of u+2 in M(t,1)
+//   3: no M-slot issue; A1, A2 of u+1 are issued with A3 of u+1 in L(t,0) instead of one K-tile earlier in L(t-1,3)
+// (tools/ring_schedule_check.py --m-issue N proves each variant's vmcnt immediates).
+#ifndef VX_RING_MISSUE
+#define VX_RING_MISSUE 0
+#endif
+// VX_RING_PRIO (experiment): 1 = the M slot runs at s_setprio 1 (product), 0 = no priority changes, 2 = the L slot does
+#ifndef VX_RING_PRIO
+#define VX_RING_PRIO 1
+#endif
+constexpr bool RING_MI_M = VX_RING_MISSUE == 1 || VX_RING_MISSUE == 2;
+constexpr bool RING_MI_LATE = VX_RING_MISSUE == 3;
 #ifdef VX_RING_TRACE
 // slot timing trace (tools/gemm_bench --trace): waves 0 and 4 of block 0 record s_memtime at every barrier
 __device__ unsigned long long* g_ring_trace = nullptr;
@@ -264,8 +278,13 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
   issue_group(0, 0); issue_group(1, 0); issue_group(2, 0); issue_group(3, 0);
   advance_issue(S > 1);
   if (S > 1) {
-    issue_group(0, 1); issue_group(1, 1); issue_group(2, 1);
-    ring_wait_vm<11>();   // g0, g1 of K-tile 0 landed (younger: g2, g3 of 0 and g0..g2 of 1)
+    issue_group(0, 1); issue_group(1, 1);
+    if constexpr (RING_MI_LATE) {
+      ring_wait_vm<9>();
+    } else {
+      issue_group(2, 1);
+      ring_wait_vm<11>();   // g0, g1 of K-tile 0 landed (younger: g2, g3 of 0 and g0..g2 of 1)
+    }
   } else {
     ring_wait_vm<3>();
   }
@@ -297,6 +316,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
       RING_STAMP();
       if (ph == 0) {
         if (e1) {
+          if constexpr (RING_MI_LATE) issue_group(2, par ^ 1);
           issue_group(3, par ^ 1);          // A3 of u+1
           advance_issue(e2);                // -> u+2
           RING_WAIT_VM(11);
@@ -305,8 +325,14 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
         }
       } else if (ph == 1) {
         if (e2) {
-          issue_group(0, par);              // u+2 reuses this K-tile's buffer: its B slots were read in L(u,0)
-          RING_WAIT_VM(13);
+          // u+2 reuses this K-tile's buffer: its B slots were read in L(u,0)
+          if constexpr (VX_RING_MISSUE == 2) {
+            issue_b(lds_wave + par * BUF_BYTES, 0); issue_b(lds_wave + par * BUF_BYTES, 1);
+            RING_WAIT_VM(12);
+          } else {
+            issue_group(0, par);
+            RING_WAIT_VM(13);
+          }
         } else if (e1) {
           RING_WAIT_VM(10);
         } else {
@@ -314,8 +340,13 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
         }
       } else if (ph == 2) {
         if (e2) {
-          issue_group(1, par);
-          RING_WAIT_VM(15);
+          if constexpr (RING_MI_M) {
+            issue_b(lds_wave + par * BUF_BYTES, 3); issue_b(lds_wave + par * BUF_BYTES, 4);
+            RING_WAIT_VM(14);
+          } else {
+            issue_group(1, par);
+            RING_WAIT_VM(15);
+          }
         } else if (e1) {
           RING_WAIT_VM(9);
         } else {
@@ -323,8 +354,15 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
         }
       } else {
         if (e2) {
-          issue_group(2, par);
-          RING_WAIT_VM(11);
+          if constexpr (RING_MI_M) {
+            issue_a(lds_wave + par * BUF_BYTES, 1);
+            RING_WAIT_VM(10);
+          } else if constexpr (RING_MI_LATE) {
+            RING_WAIT_VM(9);
+          } else {
+            issue_group(2, par);
+            RING_WAIT_VM(11);
+          }
         } else if (e1) {
           RING_WAIT_VM(3);
         } else {
@@ -336,16 +374,29 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
       ring_barrier();
       RING_STAMP();
       // ---------------- M slot
-      __builtin_amdgcn_s_setprio(1);
+      if constexpr (VX_RING_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+      if constexpr (VX_RING_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+      auto m_slot_issue = [&]() {   // VX_RING_MISSUE only: this wave's copies that left the L slots
+        if (!e2) return;
+        __builtin_amdgcn_sched_barrier(0);
+        if (VX_RING_MISSUE == 2 && ph == 1) issue_b(lds_wave + par * BUF_BYTES, 2);
+        if (ph == 2) issue_a(lds_wave + par * BUF_BYTES, 0);
+        if (ph == 3) issue_a(lds_wave + par * BUF_BYTES, 2);
+        __builtin_amdgcn_sched_barrier(0);
+      };
       if constexpr (F8) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
           for (int j = 0; j < 5; ++j)
             acc[2 * ph + s][j] = ring_mfma_f8(bfr[j][0], bfr[j][1], af[s][0], af[s][1], acc[2 * ph + s][j]);
+          if constexpr (RING_MI_M) {
+            if (s == 0) m_slot_issue();
+          }
+        }
       } else {
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+      for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -356,8 +407,13 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
             }
             acc[2 * ph + s][j] = mfma16(bfr[j][kk], af[s][kk], acc[2 * ph + s][j]);
           }
+        if constexpr (RING_MI_M) {
+          if (kk == 0) m_slot_issue();
+        }
       }
-      __builtin_amdgcn_s_setprio(0);
+      }
+      if constexpr (VX_RING_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+      if constexpr (VX_RING_PRIO == 2) __builtin_amdgcn_s_setprio(1);
       RING_STAMP();
       ring_barrier();
       RING_STAMP();
