@@ -16,6 +16,7 @@ for rep in 1 2; do
   done
 done
 for m in $ARMS; do
+  [ -f tools/ringlibs/${m}_trace.so ] || continue
   echo "=== trace arm=$m" >> $O
   RING_TRACE=1 timeout 40 tools/gemm_bench tools/ringlibs/${m}_trace.so 3 "L0 conv3x3 320>320 prepad" 2>&1 | head -16 >> $O
 done

@@ -18,15 +18,21 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 __device__ __forceinline__ uint32_t lds_addr_of(const void* shared_ptr) {
   return (uint32_t)(size_t)(__attribute__((address_space(3))) const char*)shared_ptr;
 }
+// Cache-policy experiment for the copies (build with -DVX_GLDS_MOD='" nt"', '" sc1"', '" sc0 sc1"'; the product library
+// is built without, i.e. default policy): the long-K GEMMs are bound by the CU's L1 miss path
+#ifndef VX_GLDS_MOD
+#define VX_GLDS_MOD ""
+#endif
 // wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset
 __device__ __forceinline__ void glds16_s(const void* sbase, uint32_t voff, uint32_t lds_wave_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave_addr), "v"(voff),
-               "s"(sbase)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" VX_GLDS_MOD ::"s"(lds_wave_addr),
+               "v"(voff), "s"(sbase)
                : "memory", "m0");
 }
 // per-lane 64-bit address
 __device__ __forceinline__ void glds16_v(const void* vaddr, uint32_t lds_wave_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_wave_addr), "v"(vaddr)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" VX_GLDS_MOD ::"s"(lds_wave_addr),
+               "v"(vaddr)
                : "memory", "m0");
 }
 
