@@ -7,12 +7,15 @@ legacy "old_attn" denoising-UNet layout) are written to tmp_path, loaded through
 load order (inference.py:77-129: ReferenceNet strict=False; denoising UNet strict=False, then the motion-module file on
 top; guider / audio projection strict; VAE directory) and every loaded model's forward must equal, BIT FOR BIT, the
 model that received the same tensors through `load_state_dict` directly."""
+import contextlib
 import json
+import os
 
 import pytest
 import torch
 
 import cases
+from v_express_amd import module_base
 
 def _unet_config_json(path, kw):
     cfg = cases.unet_cfg(kw)
@@ -87,9 +90,18 @@ def unet_and_reference_net_from_files(tmp_path, layout, device):
         writer.clear()
     assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
     assert torch.equal(outs[0], outs[1]), "the file-loaded UNet3D / ReferenceNet differ from the load_state_dict ones"
-    with pytest.raises(NotImplementedError):                                      # the reference's default dtype
-        checkpoints.load_reference_net(str(tmp_path / "config.json"), str(tmp_path / "reference_net.bin"),
-                                       dtype=torch.float16, device=device)
+    # the reference's default dtype (inference.py:44): accepted as an I/O dtype with a warning, bf16 compute
+    with pytest.warns(UserWarning) if not module_base._FP16_WARNED[0] else contextlib.nullcontext():
+        r16 = checkpoints.load_reference_net(str(tmp_path / "config.json"), str(tmp_path / "reference_net.bin"),
+                                             dtype=torch.float16, device=device)
+    assert r16.dtype == torch.float16
+    os.environ["VX_STRICT_FP16"] = "1"
+    try:
+        with pytest.raises(NotImplementedError):
+            checkpoints.load_reference_net(str(tmp_path / "config.json"), str(tmp_path / "reference_net.bin"),
+                                           dtype=torch.float16, device=device)
+    finally:
+        del os.environ["VX_STRICT_FP16"]
 
 
 def vae_guider_and_audio_projection_from_files(tmp_path, device):

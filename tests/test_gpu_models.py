@@ -154,6 +154,14 @@ def test_full_size_unet_forward_vs_oracle(latent):
         print(f"[full {8 * latent}x{8 * latent} f=2] worst bank relL2={worst[0]:.4g} ({worst[1]}); forward relL2={r:.4g} "
               f"cosine={c:.6f}")
         assert torch.isfinite(got).all() and r <= 3e-2 and c >= 0.999, (r, c)
+        # BASELINE.json configs[4]'s fp8 q / k / v / out projections on the same inputs against the same oracle output
+        # (latent = 96 is that configuration's own 768x768 geometry); stated tolerance of the mode: 6e-2 / 0.998
+        unet.fp8_projections = True
+        got8 = unet(x, t, encoder_hidden_states=ehs, kps_features=inp["kps_features"], return_dict=False)[0]
+        unet.fp8_projections = False
+        r8, c8 = rel_l2(got8, ref), cosine(got8, ref)
+        print(f"[full {8 * latent}x{8 * latent} f=2] fp8 projections: forward relL2={r8:.4g} cosine={c8:.6f}")
+        assert torch.isfinite(got8).all() and not torch.equal(got8, got) and r8 <= 6e-2 and c8 >= 0.998, (r8, c8)
     finally:
         torch.set_num_threads(nthreads)
 

@@ -4,16 +4,42 @@ kernel-specific device layouts).  What the reference's call sites use is here: `
 (inference.py:77-129,150-163; pipelines/v_express_pipeline.py:345).
 
 Compute dtype: the gfx950 kernels store activations and weights in bf16 and accumulate in fp32 (MFMA
-v_mfma_f32_16x16x32_bf16).  `torch.float16` - the reference's default (`inference.py:44`) - is NOT implemented and is
-rejected instead of being silently replaced: run the reference entry point with `--dtype bf16` (inference.py:150-157).
-`torch.float32` is accepted as an I/O dtype only (outputs are returned in float32 anyway).
+v_mfma_f32_16x16x32_bf16).  `torch.float16` - the reference's default (`inference.py:44,150-151`) - and
+`torch.float32` are accepted as I/O dtypes: `.dtype` reports them and model outputs follow the caller's input dtype
+like the reference's, but every kernel computes in bf16 storage / fp32 accumulation (same MFMA rate as an f16 path,
+wider exponent range).  Asking for float16 emits ONE warning per process that says so; set VX_STRICT_FP16=1 to get the
+round-2 behaviour (NotImplementedError) back when a silent change of the compute dtype is not acceptable.
 """
+import os
+import warnings
 from types import SimpleNamespace
 
 import torch
 
 _NO_FP16 = ("v_express_amd computes in bfloat16 (bf16 storage, fp32 accumulation on the gfx950 matrix cores); a float16 "
             "compute path is not implemented.  Use torch.bfloat16 (reference CLI: --dtype bf16).")
+_FP16_WARNED = [False]
+
+
+def _fp16_io():
+    """torch.float16 requested: bf16 compute behind a float16 I/O surface (one warning), or an error in strict mode."""
+    if os.environ.get("VX_STRICT_FP16", "0") == "1":
+        raise NotImplementedError(_NO_FP16)
+    if not _FP16_WARNED[0]:
+        _FP16_WARNED[0] = True
+        warnings.warn("v_express_amd: torch.float16 is accepted as an I/O dtype only - the gfx950 kernels compute in "
+                      "bfloat16 storage with fp32 accumulation (VX_STRICT_FP16=1 turns this into an error)",
+                      stacklevel=3)
+
+
+def _norm_device(device):
+    """torch.device with an explicit index for CUDA ('cuda' == the current device), so that the two spellings of one
+    GPU compare equal."""
+    device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        idx = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        device = torch.device("cuda", idx)
+    return device
 
 
 class DeviceModule:
@@ -45,13 +71,13 @@ class DeviceModule:
                 continue
             if isinstance(a, torch.dtype):
                 if a == torch.float16:
-                    raise NotImplementedError(_NO_FP16)
-                if a not in (torch.bfloat16, torch.float32):
+                    _fp16_io()
+                if a not in (torch.bfloat16, torch.float32, torch.float16):
                     raise TypeError(f"unsupported dtype {a}")
                 self._dtype = a
             elif isinstance(a, (torch.device, str, int)):
-                device = torch.device("cuda", a) if isinstance(a, int) else torch.device(a)
-        if device != self._device:
+                device = _norm_device(a)
+        if device != _norm_device(self._device):
             if self._released:
                 raise RuntimeError("release_raw_weights() dropped the source-layout weights; this model can no longer "
                                    "move to another device - load the state dict again first")
@@ -63,7 +89,7 @@ class DeviceModule:
         return self.to(torch.device("cuda", device) if device is not None else "cuda")
 
     def half(self):
-        raise NotImplementedError(_NO_FP16)
+        return self.to(torch.float16)
 
     def bfloat16(self):
         return self.to(torch.bfloat16)
