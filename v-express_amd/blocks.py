@@ -65,10 +65,12 @@ def _fold_on(F):
     return F is not None and ops.LN_FOLD[0] and not ops.FP8_PROJ[0]
 
 
-def _self_attention(A, ln, h, *, seqs, n_tok, heads, fold=None):
+def _self_attention(A, ln, h, *, seqs, n_tok, heads, fold=None, item_bias=None, rows_per_item=0):
     """diffusers Attention as self-attention: fused QKV GEMM whose epilogue also emits V^T, flash attention,
-    out-projection with the residual add fused (in place on h)."""
-    """fold = (folded weights, row statistics): `ln` is then the UN-normalised h and the LayerNorm runs inside the GEMM."""
+    out-projection with the residual add fused (in place on h).
+    fold = (folded weights, row statistics): `ln` is then the UN-normalised h and the LayerNorm runs inside the GEMM.
+    item_bias: float32 [items, C] added to the out-projection per batch item (rows_per_item rows each) in the same
+    epilogue - the constant contributions of the blocks that follow for that item (see _spatial_transformer_read)."""
     m, c = ln.shape
     d = c // heads
     q = torch.empty((m, c), device=ln.device, dtype=ops.BF16)
@@ -85,7 +87,8 @@ def _self_attention(A, ln, h, *, seqs, n_tok, heads, fold=None):
                       k_prescaled=bool(A.get("k_prescaled")))
     if isinstance(ln, ops.Fp8Rows):
         a = ops.quantize_fp8(a)
-    ops.gemm(a, ops.proj_weight(a, A.out.w), A.out.b, residual=h, out=h)
+    ops.gemm(a, ops.proj_weight(a, A.out.w), A.out.b, residual=h, out=h, rowbias=item_bias,
+             rows_per_group=rows_per_item)
 
 
 def _feed_forward(P, h):
@@ -123,19 +126,36 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
     x2d = x.view(m, c)
     n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
     h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b)
-    # 1. self-attention (:177-184)
-    if _fold_on(P.get("ln_qkv")):
-        _self_attention(P.attn1, h, h, seqs=frames, n_tok=hw, heads=heads, fold=(P.ln_qkv, ops.row_stats(h)))
-    else:
-        ln = ops.proj_layernorm(h, P.norm1.g, P.norm1.b)
-        _self_attention(P.attn1, ln, h, seqs=frames, n_tok=hw, heads=heads)
-    # 1.5 reference attention (:186-224): K/V = bank of the batch row, shared by its f frames
+    # A batch item without a bank (the unconditional CFG half) gets exactly w_ref * attn1_5.to_out.bias from block 1.5,
+    # and - when its audio tokens are all zero as well - exactly w_aud * attn2.to_out.bias from block 2 (SURVEY.md App.
+    # E4); nothing reads that item's h in between, so both constants ride in the epilogue of the attn1 out-projection
+    # as a per-item row bias instead of two read-modify-write passes over h (vx_add_row_bias) per block.
     d = c // heads
     rows = f * hw
+    fold_ref = [bank[bi] is None for bi in range(b)]
+    fold_aud = [fold_ref[bi] and audio_zero is not None and bool(audio_zero[bi]) for bi in range(b)]
+    item_bias = None
+    if any(fold_ref):
+        key = ("item_bias", tuple(fold_ref), tuple(fold_aud), float(w_ref), float(w_aud))
+        item_bias = P.get(key)
+        if item_bias is None:                      # built once per (CFG pattern, weights): a few tiny launches
+            item_bias = torch.zeros((b, c), device=x.device, dtype=torch.float32)
+            for bi in range(b):
+                if fold_ref[bi]:
+                    item_bias[bi] = P.attn1_5.out.b * w_ref + (P.attn2.out.b * w_aud if fold_aud[bi] else 0.0)
+            P[key] = item_bias
+    # 1. self-attention (:177-184)
+    if _fold_on(P.get("ln_qkv")):
+        _self_attention(P.attn1, h, h, seqs=frames, n_tok=hw, heads=heads, fold=(P.ln_qkv, ops.row_stats(h)),
+                        item_bias=item_bias, rows_per_item=rows)
+    else:
+        ln = ops.proj_layernorm(h, P.norm1.g, P.norm1.b)
+        _self_attention(P.attn1, ln, h, seqs=frames, n_tok=hw, heads=heads, item_bias=item_bias, rows_per_item=rows)
+    # 1.5 reference attention (:186-224): K/V = bank of the batch row, shared by its f frames
     for bi in range(b):
         hb = h[bi * rows:(bi + 1) * rows]
         if bank[bi] is None:
-            ops.add_row_bias(hb, P.attn1_5.out.b, w_ref)
+            pass                                   # folded into the attn1 out-projection above
         else:
             kref, vtref, kmax = bank[bi]
             with ops.frame_rows(hw, items=1):          # these launches cover ONE batch item
@@ -168,7 +188,8 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
         for bi in range(b):
             hb = h[bi * rows:(bi + 1) * rows]
             if audio_zero[bi]:
-                ops.add_row_bias(hb, P.attn2.out.b, w_aud)
+                if not fold_aud[bi]:
+                    ops.add_row_bias(hb, P.attn2.out.b, w_aud)
                 continue
             with ops.frame_rows(hw, items=1):
                 if _fold_on(P.get("ln_q2")):
