@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 8
+#define VX_ABI_VERSION 9
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
@@ -97,6 +97,21 @@ typedef struct {
    * F.linear pairs of modules/mutual_self_attention.py:177-247 and modules/motion_module.py:243-256. */
   const float* ln_stats;     /* [m][2] = (mean, rstd) per row, or NULL */
   const float* ln_colsum;    /* [n] */
+  /* Row statistics of the OUTPUT (round 3; STORE epilogue into bf16): row_stats_out != NULL -> row_stats_out[m] = (mean,
+   * 1 / sqrt(var + row_stats_eps)) of the stored bf16 row out[m, 0:n], i.e. exactly what the next GEMM needs as its
+   * ln_stats when it folds the LayerNorm of this output (modules/mutual_self_attention.py:177-247: every norm reads the
+   * residual stream a projection has just written).  When one 256 x 320 tile of the persistent kernel holds whole rows
+   * (n == 320: the 64x64 level) the epilogue produces them from its registers and the read-only vx_row_stats pass over the
+   * tensor disappears; otherwise vx_gemm runs vx_row_stats on `out` itself after the launch - same result contract
+   * (variance of the stored values; the fused form sums x and x^2 in float32 in a fixed order). */
+  float* row_stats_out;      /* [m][2] or NULL */
+  float row_stats_eps;
+  /* Per-row-group weights (round 3): w_group_rows > 0 -> output rows [g * w_group_rows, (g + 1) * w_group_rows) multiply
+   * the weight matrix w + g * n * k (w holds m / w_group_rows matrices back to back).  This is how a GroupNorm WITHOUT
+   * activation in front of a 1x1 / linear layer is folded into that layer (vx_groupnorm_fold_linear: one scaled weight
+   * copy per frame, modules/transformer_3d.py:124-126, modules/motion_module.py:156-158).  Only the persistent 256 x 320
+   * kernel implements it: w_group_rows % 256 == 0 and every other ring condition must hold, else VX_ERR_UNSUPPORTED. */
+  int32_t w_group_rows;
 } vx_gemm_params;
 
 int vx_gemm(const vx_gemm_params* p, void* stream);
@@ -121,6 +136,20 @@ int64_t vx_groupnorm_ws_floats(int frames, int slices, int groups);
 int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int frames, int hw, int groups, float eps,
                  const float* gamma, const float* beta, int silu, void* out, float* ws, int slices, int width,
                  int out_pad, void* stream);
+
+/* GroupNorm WITHOUT activation folded into the 1x1 / linear layer that consumes it (round 3; Transformer3DModel.norm ->
+ * proj_in, modules/transformer_3d.py:124-126, and the motion module's norm -> proj_in, modules/motion_module.py:156-158):
+ * vx_groupnorm_stats is the statistics pass of vx_groupnorm alone (same workspace, same bits); vx_groupnorm_fold_linear
+ * turns them into one scaled weight copy and one bias row per frame,
+ *   w_out[f][n][c] = bf16(w[n][c] * gamma[c] * rstd[f][group(c)]),
+ *   bias_out[f][n] = bias_beta[n] - sum_c float(w_out[f][n][c]) * mean[f][group(c)],   bias_beta = bias + w beta,
+ * so that GN(x) w^T + bias == x w_out[f]^T + bias_out[f] for the pixels of frame f: the GEMM reads the raw tensor with
+ * vx_gemm_params.w_group_rows = hw and rowbias = bias_out, and the normalised tensor is never written or re-read. */
+int vx_groupnorm_stats(const void* x1, int c1, const void* x2, int c2, int frames, int hw, int groups, float* ws,
+                       int slices, void* stream);
+int vx_groupnorm_fold_linear(const float* ws, int frames, int hw, int slices, int groups, float eps, const float* gamma,
+                             int c, const void* w, const float* bias_beta, int n, void* w_out, float* bias_out,
+                             void* stream);
 
 /* ---- LayerNorm over the channel axis (+ optional additive table: motion-module positional encoding) -------
  * Replaces F.layer_norm (modules/attention.py:329-376 norms via mutual_self_attention.py:176-247;

@@ -42,6 +42,25 @@ def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=No
     return y.contiguous()
 
 
+def groupnorm_stats(x1, *, frames, hw, groups, x2=None):
+    """Emulated workspace: (mean, rstd-less variance) per (frame, group) in float64 - opaque to the host code."""
+    x = x1.double().view(frames, hw, -1)
+    if x2 is not None:
+        x = torch.cat([x, x2.double().view(frames, hw, -1)], dim=-1)
+    c = x.shape[-1]
+    xg = x.view(frames, hw, groups, c // groups)
+    return torch.stack([xg.mean(dim=(1, 3)), xg.var(dim=(1, 3), unbiased=False)], dim=-1)      # [frames, groups, 2]
+
+
+def groupnorm_fold_linear(ws, gamma, w, bias_beta, *, frames, hw, groups, eps):
+    n, c = w.shape
+    mean = ws[..., 0].repeat_interleave(c // groups, dim=1)                                    # [frames, c]
+    rstd = torch.rsqrt(ws[..., 1] + eps).repeat_interleave(c // groups, dim=1)
+    w_f = (w.double()[None] * (gamma.double()[None] * rstd)[:, None, :]).to(BF16)              # one rounding
+    b_f = bias_beta.double()[None] - (w_f.double() * mean[:, None, :]).sum(dim=-1)
+    return w_f.contiguous(), b_f.float().contiguous()
+
+
 def layernorm(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_entries=1, out=None):
     assert x.dtype == BF16
     x2 = x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x
@@ -56,11 +75,16 @@ def layernorm(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_e
     return y
 
 
-def row_stats(x, eps=1e-5):
+def row_stats(x, eps=1e-5, out=None):
     x2 = (x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x).double()
     mean = x2.mean(dim=1)
     var = x2.var(dim=1, unbiased=False)
-    return torch.stack([mean, torch.rsqrt(var + eps)], dim=1).float()
+    st = torch.stack([mean, torch.rsqrt(var + eps)], dim=1).float()
+    if out is not None:
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.shape == st.shape
+        out.copy_(st)
+        return out
+    return st
 
 
 def _apply_ln(y, ln):
@@ -127,8 +151,13 @@ def _conv_rows(a, a2, w, geom):
 
 
 def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=0, rowbias=None, rows_per_group=0,
-         out=None, out_f32=False, ln=None):
-    if _is_fp8(a):
+         out=None, out_f32=False, ln=None, stats_out=None, stats_eps=1e-5, w_group_rows=0):
+    if w_group_rows:                                   # per-row-group weights [groups, N, K] (vx_gemm_params.w_group_rows)
+        assert geom is None and a2 is None and w.dim() == 3 and w.is_contiguous() and a.dtype == BF16
+        assert a.shape[0] == w.shape[0] * w_group_rows
+        y = torch.einsum("grk,gnk->grn", a.double().view(w.shape[0], w_group_rows, -1), w.double())
+        y = y.reshape(a.shape[0], w.shape[1])
+    elif _is_fp8(a):
         assert geom is None and a2 is None
         x, wt = _dequant(a, w)
         y = x @ wt.t()
@@ -155,6 +184,9 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=0
     elif alpha != 1.0:
         y = alpha * y
     y = y.float() if out_f32 else y.to(BF16)
+    if stats_out is not None:                          # statistics of the STORED rows (vx_gemm_params.row_stats_out)
+        assert not out_f32
+        row_stats(y, stats_eps, out=stats_out)
     if out is not None:
         assert out.shape[-1] == y.shape[-1] and out.stride(-1) == 1
         out.reshape(y.shape).copy_(y) if out.is_contiguous() else out.copy_(y)
@@ -304,7 +336,7 @@ def vae_postprocess(x, n, c, h, w):
     return (x[:, :c].float().reshape(n, h, w, c).permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1).contiguous()
 
 
-ALL = ("wave_conv1d", "groupnorm", "layernorm", "row_stats", "layernorm_fp8", "quantize_fp8", "gemm", "geglu", "alloc_vt", "gemm_split", "key_norm_max", "attention",
+ALL = ("wave_conv1d", "groupnorm", "groupnorm_stats", "groupnorm_fold_linear", "layernorm", "row_stats", "layernorm_fp8", "quantize_fp8", "gemm", "geglu", "alloc_vt", "gemm_split", "key_norm_max", "attention",
        "temporal_attention", "small_kv_attention", "add_row_bias", "gather_latents", "cfg_combine", "pack_rows", "combine_units", "overlap_ddim_step",
        "ncfhw_to_nhwc", "nhwc_to_ncfhw", "vae_postprocess")
 

@@ -20,7 +20,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for n in names:
         assert hasattr(so, n), n
-    assert lib.lib.vx_abi_version() == 8
+    assert lib.lib.vx_abi_version() == 9
     assert ctypes.sizeof(lib.GemmParams) % 8 == 0
     # argument validation happens before any launch, so it works without a GPU and never aborts the process
     p = lib.GemmParams()

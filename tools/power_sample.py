@@ -24,8 +24,25 @@ def _read(path):
         return None
 
 
+def hip_pci_bus_id(device=0):
+    """PCI bus id ('0000:c1:00.0') of HIP device `device` - the host's sysfs lists every GPU of the node, the process
+    sees one."""
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, device) == 0:
+            return buf.value.decode().lower()
+    except OSError:
+        pass
+    return None
+
+
 def find_hwmon():
-    for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+    bus = hip_pci_bus_id()
+    cands = sorted(glob.glob(f"/sys/bus/pci/devices/{bus}/hwmon/hwmon*")) if bus else []
+    cands += sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+    for d in cands:
         if _read(os.path.join(d, "power1_average")) or _read(os.path.join(d, "power1_input")):
             return d
     return None
@@ -41,6 +58,7 @@ class Sysfs:
         cap = _read(os.path.join(d, "power1_cap"))
         self.cap = float(cap) * 1e-6 if cap else None
         self.dev = os.path.dirname(os.path.dirname(d))
+        self.name = f"sysfs-hwmon {os.path.realpath(self.dev)}"
 
     def sample(self):
         p, f = _read(self.pfile), _read(self.ffile)

@@ -65,7 +65,7 @@ def _fold_on(F):
     return F is not None and ops.LN_FOLD[0] and not ops.FP8_PROJ[0]
 
 
-def _self_attention(A, ln, h, *, seqs, n_tok, heads, fold=None, item_bias=None, rows_per_item=0):
+def _self_attention(A, ln, h, *, seqs, n_tok, heads, fold=None, item_bias=None, rows_per_item=0, stats_out=None):
     """diffusers Attention as self-attention: fused QKV GEMM whose epilogue also emits V^T, flash attention,
     out-projection with the residual add fused (in place on h).
     fold = (folded weights, row statistics): `ln` is then the UN-normalised h and the LayerNorm runs inside the GEMM.
@@ -88,15 +88,35 @@ def _self_attention(A, ln, h, *, seqs, n_tok, heads, fold=None, item_bias=None, 
     if isinstance(ln, ops.Fp8Rows):
         a = ops.quantize_fp8(a)
     ops.gemm(a, ops.proj_weight(a, A.out.w), A.out.b, residual=h, out=h, rowbias=item_bias,
-             rows_per_group=rows_per_item)
+             rows_per_group=rows_per_item, stats_out=stats_out)
 
 
-def _feed_forward(P, h):
+def _ff_fold_on(P):
+    return P.get("ln_ff") is not None and ops.LN_FOLD[0]
+
+
+def _norm_proj_in(P, x, frames, hw, groups, stats_out=None):
+    """h = proj_in(GroupNorm(x)) (modules/transformer_3d.py:124-126, modules/motion_module.py:156-158).  Where
+    `ops.gn_fold_applies` (the 64x64 level) the normalised tensor is never materialised: the statistics pass alone,
+    one scaled weight copy + bias row per frame (`ops.groupnorm_fold_linear`), and the GEMM reads the raw x with
+    per-frame weights.  stats_out: see ops.gemm (row statistics of h for the LayerNorm the next GEMM folds)."""
+    c = x.shape[-1]
+    m = frames * hw
+    G = P.get("gn_fold")
+    if G is not None and ops.gn_fold_applies(m, hw, c, G.w.shape[0]):
+        ws = ops.groupnorm_stats(x, frames=frames, hw=hw, groups=groups)
+        w_f, b_f = ops.groupnorm_fold_linear(ws, G.g, G.w, G.bb, frames=frames, hw=hw, groups=groups, eps=1e-6)
+        return ops.gemm(x.view(m, c), w_f, None, rowbias=b_f, rows_per_group=hw, w_group_rows=hw, stats_out=stats_out)
+    n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
+    return ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b, stats_out=stats_out)
+
+
+def _feed_forward(P, h, stats=None):
     """h += FF(LN(h)): GEGLU fused in the first GEMM's epilogue (with the LayerNorm folded into that GEMM when the
-    weights carry the fold), residual in the second's."""
+    weights carry the fold), residual in the second's.  stats: the row statistics of h when its producer emitted them."""
     F = P.get("ln_ff")
     if F is not None and ops.LN_FOLD[0]:
-        g = ops.geglu(h, F.w, F.b, ln=(ops.row_stats(h), F.s))
+        g = ops.geglu(h, F.w, F.b, ln=(stats if stats is not None else ops.row_stats(h), F.s))
     else:
         ln = ops.layernorm(h, P.norm3.g if "norm3" in P else P.ff_norm.g, P.norm3.b if "norm3" in P else P.ff_norm.b)
         g = ops.geglu(ln, P.ff.w1, P.ff.b1)
@@ -124,8 +144,13 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
     frames, hw, c = b * f, H * W, x.shape[-1]
     m = frames * hw
     x2d = x.view(m, c)
-    n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
-    h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b)
+    # Row statistics of the residual stream h for the LayerNorms folded into the q / qkv / GEGLU projections: every
+    # GEMM that writes rows of h also writes their (mean, rstd) into `st` when the next reader of those rows folds its
+    # LayerNorm (at the 64x64 level straight from the epilogue's registers: ops.gemm(stats_out=...))
+    f_qkv, f_q15, f_q2 = _fold_on(P.get("ln_qkv")), _fold_on(P.get("ln_q15")), _fold_on(P.get("ln_q2"))
+    f_ff = _ff_fold_on(P)
+    st = torch.empty((m, 2), device=x.device, dtype=torch.float32) if (f_qkv or f_q15 or f_q2 or f_ff) else None
+    h = _norm_proj_in(P, x, frames, hw, groups, stats_out=st if f_qkv else None)
     # A batch item without a bank (the unconditional CFG half) gets exactly w_ref * attn1_5.to_out.bias from block 1.5,
     # and - when its audio tokens are all zero as well - exactly w_aud * attn2.to_out.bias from block 2 (SURVEY.md App.
     # E4); nothing reads that item's h in between, so both constants ride in the epilogue of the attn1 out-projection
@@ -145,29 +170,33 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
                     item_bias[bi] = P.attn1_5.out.b * w_ref + (P.attn2.out.b * w_aud if fold_aud[bi] else 0.0)
             P[key] = item_bias
     # 1. self-attention (:177-184)
-    if _fold_on(P.get("ln_qkv")):
-        _self_attention(P.attn1, h, h, seqs=frames, n_tok=hw, heads=heads, fold=(P.ln_qkv, ops.row_stats(h)),
-                        item_bias=item_bias, rows_per_item=rows)
+    st1 = st if (f_q15 or f_q2 or f_ff) else None
+    if f_qkv:
+        _self_attention(P.attn1, h, h, seqs=frames, n_tok=hw, heads=heads, fold=(P.ln_qkv, st),
+                        item_bias=item_bias, rows_per_item=rows, stats_out=st1)
     else:
         ln = ops.proj_layernorm(h, P.norm1.g, P.norm1.b)
-        _self_attention(P.attn1, ln, h, seqs=frames, n_tok=hw, heads=heads, item_bias=item_bias, rows_per_item=rows)
+        _self_attention(P.attn1, ln, h, seqs=frames, n_tok=hw, heads=heads, item_bias=item_bias, rows_per_item=rows,
+                        stats_out=st1)
     # 1.5 reference attention (:186-224): K/V = bank of the batch row, shared by its f frames
     for bi in range(b):
         hb = h[bi * rows:(bi + 1) * rows]
+        sb = None if st is None else st[bi * rows:(bi + 1) * rows]
         if bank[bi] is None:
             pass                                   # folded into the attn1 out-projection above
         else:
             kref, vtref, kmax = bank[bi]
             with ops.frame_rows(hw, items=1):          # these launches cover ONE batch item
-                if _fold_on(P.get("ln_q15")):
-                    q = ops.gemm(hb, P.ln_q15.w, P.ln_q15.b, ln=(ops.row_stats(hb), P.ln_q15.s))
+                if f_q15:
+                    q = ops.gemm(hb, P.ln_q15.w, P.ln_q15.b, ln=(sb, P.ln_q15.s))
                 else:
                     ln = ops.proj_layernorm(hb, P.norm1_5.g, P.norm1_5.b)
                     q = ops.gemm(ln, ops.proj_weight(ln, P.attn1_5.wq))
                 a = ops.proj_input(ops.attention(q, kref, vtref, batch=f, heads=heads, n_q=hw, n_kv=kref.shape[0],
                                                  head_dim=d, q_per_kv=f, kmax=kmax,
                                                  k_prescaled=bool(P.attn1_5.get("k_prescaled"))))
-                ops.gemm(a, ops.proj_weight(a, P.attn1_5.out.w), P.attn1_5.out.b, residual=hb, alpha=w_ref, out=hb)
+                ops.gemm(a, ops.proj_weight(a, P.attn1_5.out.w), P.attn1_5.out.b, residual=hb, alpha=w_ref, out=hb,
+                         stats_out=sb if (f_q2 or f_ff) else None)
     # 2. audio cross-attention (:227-244).  A batch row whose audio tokens are ALL ZERO (the unconditional CFG half:
     # torch.zeros_like, pipelines/v_express_pipeline.py:403-405) has K = V = 0 (to_k / to_v carry no bias): every
     # score is 0, the softmax is uniform, the weighted sum of V is exactly 0 and the block adds exactly
@@ -176,32 +205,37 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
     if kv is None:
         kv = audio_kv(P, ehs)
     if audio_zero is None or not any(audio_zero):
-        if _fold_on(P.get("ln_q2")):
-            q = ops.gemm(h, P.ln_q2.w, P.ln_q2.b, ln=(ops.row_stats(h), P.ln_q2.s))
+        if f_q2:
+            q = ops.gemm(h, P.ln_q2.w, P.ln_q2.b, ln=(st, P.ln_q2.s))
         else:
             ln = ops.proj_layernorm(h, P.norm2.g, P.norm2.b)
             q = ops.gemm(ln, ops.proj_weight(ln, P.attn2.wq))
         a = ops.proj_input(ops.small_kv_attention(q, kv, batch=frames, n_q=hw, n_kv=n_ctx, heads=heads, head_dim=d))
-        ops.gemm(a, ops.proj_weight(a, P.attn2.out.w), P.attn2.out.b, residual=h, alpha=w_aud, out=h)
+        ops.gemm(a, ops.proj_weight(a, P.attn2.out.w), P.attn2.out.b, residual=h, alpha=w_aud, out=h,
+                 stats_out=st if f_ff else None)
     else:
         kvr = f * n_ctx
         for bi in range(b):
             hb = h[bi * rows:(bi + 1) * rows]
+            sb = None if st is None else st[bi * rows:(bi + 1) * rows]
             if audio_zero[bi]:
                 if not fold_aud[bi]:
                     ops.add_row_bias(hb, P.attn2.out.b, w_aud)
+                    if f_ff:
+                        ops.row_stats(hb, out=sb)      # the rows changed after their producer's statistics
                 continue
             with ops.frame_rows(hw, items=1):
-                if _fold_on(P.get("ln_q2")):
-                    q = ops.gemm(hb, P.ln_q2.w, P.ln_q2.b, ln=(ops.row_stats(hb), P.ln_q2.s))
+                if f_q2:
+                    q = ops.gemm(hb, P.ln_q2.w, P.ln_q2.b, ln=(sb, P.ln_q2.s))
                 else:
                     ln = ops.proj_layernorm(hb, P.norm2.g, P.norm2.b)
                     q = ops.gemm(ln, ops.proj_weight(ln, P.attn2.wq))
                 a = ops.proj_input(ops.small_kv_attention(q, kv[bi * kvr:(bi + 1) * kvr], batch=f, n_q=hw, n_kv=n_ctx,
                                                           heads=heads, head_dim=d))
-                ops.gemm(a, ops.proj_weight(a, P.attn2.out.w), P.attn2.out.b, residual=hb, alpha=w_aud, out=hb)
+                ops.gemm(a, ops.proj_weight(a, P.attn2.out.w), P.attn2.out.b, residual=hb, alpha=w_aud, out=hb,
+                         stats_out=sb if f_ff else None)
     # 3. feed-forward (:247)
-    _feed_forward(P, h)
+    _feed_forward(P, h, st if f_ff else None)
     out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x2d)
     return out.view(frames, hw, c)
 
@@ -248,26 +282,32 @@ def _motion_module(P, x, *, b, f, H, W, heads, groups, shard=None):
     residual add are per token again and run back in the frame-shard layout."""
     frames, hw, c = b * f, H * W, x.shape[-1]
     d = c // heads
-    n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
     f_all, hw_t = f, hw
     if shard is not None:
-        n = shard.to_pixel_shard(n, b, f)
         f_all, hw_t = f * shard.size, hw // shard.size
     m = b * f_all * hw_t
-    h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b)
-    for A in P.attn:
-        if _fold_on(A.get("ln_qkv")):
+    # row statistics of h for the folded LayerNorms: written by the GEMM that produces the rows (see the spatial block)
+    folds = [_fold_on(A.get("ln_qkv")) for A in P.attn] + [_ff_fold_on(P)]
+    st = torch.empty((m, 2), device=x.device, dtype=torch.float32) if any(folds) else None
+    if shard is not None:
+        n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
+        n = shard.to_pixel_shard(n, b, f)
+        h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b, stats_out=st if folds[0] else None)
+    else:
+        h = _norm_proj_in(P, x, frames, hw, groups, stats_out=st if folds[0] else None)
+    for i, A in enumerate(P.attn):
+        if folds[i]:
             key = ("pe_rows_tiled", b, f_all)
             if key not in A:                   # [b * f_all, 3C] float32: frame (m // hw_t) % f_all of the table
                 A[key] = A.pe_rows[:f_all].repeat(b, 1).contiguous()
-            qkv = ops.gemm(h, A.ln_qkv.w, A.ln_qkv.b, rowbias=A[key], rows_per_group=hw_t,
-                           ln=(ops.row_stats(h), A.ln_qkv.s))
+            qkv = ops.gemm(h, A.ln_qkv.w, A.ln_qkv.b, rowbias=A[key], rows_per_group=hw_t, ln=(st, A.ln_qkv.s))
         else:
             ln = ops.proj_layernorm(h, A.norm.g, A.norm.b, add=A.pe, add_rows_per_entry=hw_t, add_entries=f_all)
             qkv = ops.gemm(ln, ops.proj_weight(ln, A.attn.wqkv), A.attn.bqkv)
         a = ops.proj_input(ops.temporal_attention(qkv, b=b, f=f_all, hw=hw_t, heads=heads, head_dim=d))
-        ops.gemm(a, ops.proj_weight(a, A.attn.out.w), A.attn.out.b, residual=h, out=h)
-    _feed_forward(P, h)
+        ops.gemm(a, ops.proj_weight(a, A.attn.out.w), A.attn.out.b, residual=h, out=h,
+                 stats_out=st if folds[i + 1] else None)
+    _feed_forward(P, h, st if folds[-1] else None)
     if shard is not None:
         h = shard.to_frame_shard(h.view(b * f_all, hw_t, c), b, f).view(frames * hw, c)
     out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x.view(frames * hw, c))

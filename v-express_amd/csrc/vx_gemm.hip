@@ -744,9 +744,24 @@ extern "C" const char* vx_gemm_config_name(const vx_gemm_params* pp) {
   return buf;
 }
 
+static int vx_gemm_dispatch(const vx_gemm_params& p, hipStream_t stream);
+
 extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
   const vx_gemm_params& p = *pp;
   hipStream_t stream = (hipStream_t)stream_;
+  if (p.row_stats_out != nullptr)
+    VX_REQUIRE(p.epi == VX_EPI_STORE && !p.out_f32 && p.row_stats_eps > 0.f && p.out != nullptr,
+               "vx_gemm: row_stats_out needs the STORE epilogue into bf16 and row_stats_eps > 0");
+  if (p.w_group_rows != 0)
+    VX_REQUIRE(p.w_group_rows > 0 && (p.m % p.w_group_rows) == 0 && p.epi == VX_EPI_STORE && !p.a_fp8 && p.splitk <= 1,
+               "vx_gemm: w_group_rows=%d must divide m=%d (STORE epilogue, no fp8 / split-K)", p.w_group_rows, p.m);
+  const int rc = vx_gemm_dispatch(p, stream);
+  if (rc != VX_OK || p.row_stats_out == nullptr) return rc;
+  if (vx_gemm_ring_eligible(p) && vx_gemm_ring_writes_row_stats(p)) return rc;   // the epilogue wrote them
+  return vx_row_stats(p.out, p.ldc, p.m, p.n, p.row_stats_eps, p.row_stats_out, stream_);
+}
+
+static int vx_gemm_dispatch(const vx_gemm_params& p, hipStream_t stream) {
   VX_REQUIRE(p.a != nullptr && p.w != nullptr, "vx_gemm: null operand");
   VX_REQUIRE(p.m > 0 && p.n > 0 && p.k > 0, "vx_gemm: empty problem m=%d n=%d k=%d", p.m, p.n, p.k);
   VX_REQUIRE((p.c1 % 8) == 0 && (p.c2 % 8) == 0 && p.c1 > 0, "vx_gemm: channels must be multiples of 8 (c1=%d c2=%d)",
@@ -790,6 +805,11 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
     VX_REQUIRE(p.residual == nullptr || (p.ldr % 8) == 0, "vx_gemm: ldr%%8");
     VX_REQUIRE(p.rowbias == nullptr || p.rows_per_group > 0, "vx_gemm: rows_per_group");
     if (vx_gemm_ring_eligible(p)) return vx_gemm_ring_launch(p, stream);
+    if (p.w_group_rows != 0) {
+      vx_set_error("vx_gemm: per-row-group weights (w_group_rows=%d) need a launch the persistent 256 x 320 kernel "
+                   "accepts (m %% 256, n %% 320, w_group_rows %% 256, plain addressing)", p.w_group_rows);
+      return VX_ERR_UNSUPPORTED;
+    }
     if (p.n <= 32) return launch<256, 32, 4, 1, 2, VX_EPI_STORE>(p, stream);
     if (use_big(p)) return launch<256, 320, 4, 2, 2, VX_EPI_STORE>(p, stream);
     if (use_small64(p)) return launch<64, 160, 1, 2, 3, VX_EPI_STORE>(p, stream);

@@ -48,3 +48,4 @@ bool vx_gemm_fast_ok(const vx_gemm_params& p);
 // persistent ring-staged kernel (vx_gemm_ring.hip)
 bool vx_gemm_ring_eligible(const vx_gemm_params& p);
 int vx_gemm_ring_launch(const vx_gemm_params& p, hipStream_t stream);
+bool vx_gemm_ring_writes_row_stats(const vx_gemm_params& p);

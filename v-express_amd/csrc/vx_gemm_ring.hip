@@ -48,6 +48,9 @@ constexpr int NB_PIECES = 5, NA_PIECES = 4;
 constexpr int BUF_BYTES = (NB_PIECES + NA_PIECES) * PIECE;   // 73,728
 constexpr int B_OFF = 0, A_OFF = NB_PIECES * PIECE;
 constexpr int R_LDS_BYTES = 2 * BUF_BYTES;  // 147,456
+// behind the two K-tile buffers: exchange area of the STATS epilogue, float2 [256 rows][4 wave columns] = (sum, sumsq)
+constexpr int STATS_OFF = R_LDS_BYTES, STATS_BYTES = R_BM * 4 * 8;
+constexpr int R_LDS_TOTAL = R_LDS_BYTES + STATS_BYTES;   // 155,648 of the CU's 163,840
 
 // Compile-time ablation switches (tools/exp_ring_ablate.sh builds one library per mask with -DVX_RING_ABLATE=mask; the
 // product library is built without): 1 no MFMA, 2 no LDS reads (and no MFMA), 4 every tile gathers tile 0's
@@ -119,7 +122,10 @@ __device__ __forceinline__ f32x4_t ring_mfma_f8(const uint4& a_lo, const uint4& 
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 
-template <int EPI, bool RES, bool F8 = false>   // RES: STORE epilogue with a residual addend
+// RES: STORE epilogue with a residual addend.  STATS (STORE, n == 320: one column tile holds whole rows): the epilogue
+// also writes (mean, rstd) of every stored bf16 row to p.row_stats_out - the statistics of the LayerNorm that the NEXT
+// GEMM folds (vx_gemm_params.ln_stats), so no separate pass re-reads the tensor.
+template <int EPI, bool RES, bool F8 = false, bool STATS = false>
 __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params p) {
   constexpr int ES = F8 ? 1 : 2;      // bytes per operand element
   constexpr int BKE = 128 / ES;       // elements per K-tile
@@ -191,6 +197,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
     const int tile_m = iss_lid / n_tiles, tile_n = iss_lid - tile_m * n_tiles;
     const int m0 = tile_m * R_BM;
     bbase_tile = Wt + (long)(tile_n * R_BN) * p.k * ES;
+    if (p.w_group_rows > 0) bbase_tile += (long)(m0 / p.w_group_rows) * ((long)p.n * p.k * ES);   // per-group weights
     if (is_conv) {
       const int fr = m0 / hw_out;
       const int rem = m0 - fr * hw_out;
@@ -533,6 +540,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
 #pragma unroll
         for (int k = 0; k < RES_DEPTH; ++k) load_res(k);
       }
+      float st_s = 0.f, st_q = 0.f;   // STATS: this lane's (sum, sum of squares) of row 16 i + lrow, 20 columns
 #pragma unroll
       for (int k = 0; k < N_ITEMS; ++k) {
         if (RES && !RABL(64) && k + RES_DEPTH < N_ITEMS) load_res(k + RES_DEPTH);
@@ -553,7 +561,26 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
             asm volatile("" ::"v"(v[0]), "v"(v[3]));
             continue;
           }
-          *reinterpret_cast<uint2*>(outb + out_off(k)) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          const uint2 pk2 = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          *reinterpret_cast<uint2*>(outb + out_off(k)) = pk2;
+          if constexpr (STATS) {
+            // statistics of the STORED (bf16-rounded) values, as vx_row_stats would read them back
+            const float r0 = __uint_as_float(pk2.x << 16), r1 = __uint_as_float(pk2.x & 0xffff0000u);
+            const float r2 = __uint_as_float(pk2.y << 16), r3 = __uint_as_float(pk2.y & 0xffff0000u);
+            st_s += (r0 + r1) + (r2 + r3);
+            st_q = fmaf(r0, r0, st_q); st_q = fmaf(r1, r1, st_q); st_q = fmaf(r2, r2, st_q); st_q = fmaf(r3, r3, st_q);
+            // last item of row block i: add up the four lanes (lq = 0..3) that share the row.  permlane16_swap(s, q)
+            // leaves (s0, q0, s2, q2) / (s1, q1, s3, q3) in the four 16-lane rows; their sum, then the two halves
+            // exchanged by permlane32_swap: 16-lane rows 0 / 2 hold the row's sum, rows 1 / 3 its sum of squares
+            auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(st_s), __float_as_uint(st_q), false, false);
+            const float t = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+            auto b2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+            const float tot = __uint_as_float(b2[0]) + __uint_as_float(b2[1]);
+            if (lq < 2)
+              *reinterpret_cast<float*>(smem + STATS_OFF + ((128 * grp + 16 * i + lrow) * 4 + wc) * 8 + 4 * lq) = tot;
+            st_s = 0.f;
+            st_q = 0.f;
+          }
         } else {
           float v[8];
 #pragma unroll
@@ -581,7 +608,29 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
             asm volatile("" ::"v"(v[0]), "v"(v[7]));
             continue;
           }
-          *reinterpret_cast<uint4*>(outb + out_off(k)) = pack_bf16x8(v);
+          const uint4 pk8 = pack_bf16x8(v);
+          *reinterpret_cast<uint4*>(outb + out_off(k)) = pk8;
+          if constexpr (STATS) {
+            float rr[8];
+            unpack_bf16x8(pk8, rr);
+            st_s += ((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) st_q = fmaf(rr[e], rr[e], st_q);
+          }
+        }
+      }
+      if constexpr (STATS) {
+        // the four wave columns of a row meet in LDS (fixed order -> deterministic); rows 0..255 of the tile = tid
+        ring_barrier();
+        if (tid < R_BM) {
+          const float4 p01 = *reinterpret_cast<const float4*>(smem + STATS_OFF + tid * 32);
+          const float4 p23 = *reinterpret_cast<const float4*>(smem + STATS_OFF + tid * 32 + 16);
+          const float inv_n = 1.0f / (float)R_BN;
+          const float mean = ((p01.x + p01.z) + (p23.x + p23.z)) * inv_n;
+          float var = ((p01.y + p01.w) + (p23.y + p23.w)) * inv_n - mean * mean;
+          var = var > 0.f ? var : 0.f;
+          reinterpret_cast<float2*>(p.row_stats_out)[tile_m * R_BM + tid] =
+              make_float2(mean, 1.0f / sqrtf(var + p.row_stats_eps));
         }
       }
     } else {   // VX_EPI_GEGLU
@@ -688,6 +737,7 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
   }
   if ((p.epi != VX_EPI_STORE && p.epi != VX_EPI_GEGLU) || p.out_f32 || p.splitk > 1 || p.act == VX_ACT_GELU) return false;
   if ((p.m % R_BM) != 0 || (p.n % R_BN) != 0) return false;
+  if (p.w_group_rows != 0 && (p.w_group_rows < 0 || (p.w_group_rows % R_BM) != 0 || p.a_fp8)) return false;
   if ((p.ldc % 8) != 0 || (p.residual != nullptr && (p.ldr % 8) != 0)) return false;
   if ((unsigned long long)p.m * p.ldc * 2ull >= (1ull << 32) ||
       (p.residual != nullptr && (unsigned long long)p.m * p.ldr * 2ull >= (1ull << 32)))
@@ -711,14 +761,14 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
   return mode == 2 || p.k <= 1280;
 }
 
-template <int EPI, bool RES, bool F8 = false>
+template <int EPI, bool RES, bool F8 = false, bool STATS = false>
 static int ring_launch(const vx_gemm_params& p, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = gemm_ring_kernel<EPI, RES, F8>;
+  auto kern = gemm_ring_kernel<EPI, RES, F8, STATS>;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_TOTAL);
     if (e != hipSuccess) {
-      vx_set_error("vx_gemm(ring): hipFuncSetAttribute(%d B LDS) failed: %s", R_LDS_BYTES, hipGetErrorString(e));
+      vx_set_error("vx_gemm(ring): hipFuncSetAttribute(%d B LDS) failed: %s", R_LDS_TOTAL, hipGetErrorString(e));
       return VX_ERR_HIP;
     }
     int dev = 0, cus = 0;
@@ -730,7 +780,7 @@ static int ring_launch(const vx_gemm_params& p, hipStream_t stream) {
   }
   const long tiles = (long)(p.m / R_BM) * (p.n / R_BN);
   const unsigned grid = (unsigned)(tiles < g_cu_count ? tiles : g_cu_count);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(R_NT), R_LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(R_NT), R_LDS_TOTAL, stream, p);
   return vx_check_launch("vx_gemm(ring)");
 }
 
@@ -739,5 +789,13 @@ int vx_gemm_ring_launch(const vx_gemm_params& p, hipStream_t stream) {
     return p.residual != nullptr ? ring_launch<VX_EPI_STORE, true, true>(p, stream)
                                  : ring_launch<VX_EPI_STORE, false, true>(p, stream);
   if (p.epi == VX_EPI_GEGLU) return ring_launch<VX_EPI_GEGLU, false>(p, stream);
+  if (vx_gemm_ring_writes_row_stats(p))
+    return p.residual != nullptr ? ring_launch<VX_EPI_STORE, true, false, true>(p, stream)
+                                 : ring_launch<VX_EPI_STORE, false, false, true>(p, stream);
   return p.residual != nullptr ? ring_launch<VX_EPI_STORE, true>(p, stream) : ring_launch<VX_EPI_STORE, false>(p, stream);
+}
+
+// whether the ring launch of p fills p.row_stats_out itself (otherwise vx_gemm runs vx_row_stats on the output)
+bool vx_gemm_ring_writes_row_stats(const vx_gemm_params& p) {
+  return p.row_stats_out != nullptr && !p.a_fp8 && p.epi == VX_EPI_STORE && p.n == R_BN;
 }

@@ -153,24 +153,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
   }
 }
 
-__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __restrict__ x1, int c1,
-                                                              const bf16_t* __restrict__ x2, int c2, int hw,
-                                                              int groups, float eps, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, int silu,
-                                                              bf16_t* __restrict__ out, int slices, int slice_pix,
-                                                              const float* __restrict__ ws, int width, int w_shift,
-                                                              int out_pad) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int C = c1 + c2;
-  const int frame = blockIdx.x / slices, slice = blockIdx.x % slices;
+// (mean, rstd) of every group of one frame from the per-slice partial sums of gn_stats_kernel: re-reduced in fp64, all
+// threads helping: sub-sum `sub` takes slices sub, sub+8, ... (ascending), then the GN_SUBS sub-sums are added in fixed
+// order -> same bits in every block that asks for the frame (gn_apply and gn_fold_linear).  Ends with a barrier.
+__device__ __forceinline__ void gn_group_stats(const float* __restrict__ ws, int frame, int slices, int groups, int cg,
+                                               int hw, float eps, float* gstat, double* dpart) {
   const int tid = threadIdx.x;
-  float* scale = reinterpret_cast<float*>(smem);   // [C]
-  float* shift = scale + C;                        // [C]
-  float* gstat = shift + C;                        // [groups][2] mean, rstd
-  double* dpart = reinterpret_cast<double*>(gstat + 2 * groups);   // [GN_SUBS][groups][2]
-  const int cg = C / groups;
-  // re-reduce the frame's `slices` partials in fp64, all threads helping: sub-sum `sub` takes slices sub, sub+8, ...
-  // (ascending), then the GN_SUBS sub-sums are added in fixed order -> same bits in every block of the frame
   for (int idx = tid; idx < groups * GN_SUBS; idx += GN_THREADS) {
     const int g = idx % groups, sub = idx / groups;
     double a = 0.0, b = 0.0;
@@ -197,6 +185,76 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
     gstat[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
   __syncthreads();
+}
+
+// GroupNorm (no activation) folded into the 1x1 / linear layer behind it: per frame f
+//   w_out[f][n][c] = bf16( w[n][c] * gamma[c] * rstd[f][g(c)] )                      (ONE rounding)
+//   bias_out[f][n] = bias_beta[n] - sum_c float(w_out[f][n][c]) * mean[f][g(c)]      (of the ROUNDED weights the MFMA sees)
+// with bias_beta[n] = bias[n] + sum_c w[n][c] beta[c] (frame independent, prepared at load time), so that
+//   GN(x)[m, :] W^T + bias == x[m, :] w_out[f]^T + bias_out[f]      for every pixel m of frame f.
+// grid (n / GN_FOLD_ROWS, frames); a thread octet owns one output row.
+constexpr int GN_FOLD_ROWS = GN_THREADS / 8;
+__global__ __launch_bounds__(GN_THREADS) void gn_fold_linear_kernel(const float* __restrict__ ws, int hw, int slices,
+                                                                    int groups, float eps,
+                                                                    const float* __restrict__ gamma, int C,
+                                                                    const bf16_t* __restrict__ w,
+                                                                    const float* __restrict__ bias_beta, int n,
+                                                                    bf16_t* __restrict__ w_out,
+                                                                    float* __restrict__ bias_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int frame = blockIdx.y, tid = threadIdx.x;
+  float* scale = reinterpret_cast<float*>(smem);   // [C] gamma * rstd
+  float* meanc = scale + C;                        // [C] mean of the channel's group
+  float* gstat = meanc + C;                        // [groups][2]
+  double* dpart = reinterpret_cast<double*>(gstat + 2 * groups);
+  const int cg = C / groups;
+  gn_group_stats(ws, frame, slices, groups, cg, hw, eps, gstat, dpart);
+  for (int ch = tid; ch < C; ch += GN_THREADS) {
+    const int g = ch / cg;
+    scale[ch] = gamma[ch] * gstat[g * 2 + 1];
+    meanc[ch] = gstat[g * 2 + 0];
+  }
+  __syncthreads();
+  const int row = blockIdx.x * GN_FOLD_ROWS + (tid >> 3), sub = tid & 7;
+  float dot = 0.f;
+  if (row < n) {
+    const bf16_t* src = w + (size_t)row * C;
+    bf16_t* dst = w_out + ((size_t)frame * n + row) * C;
+    for (int ch = sub * 8; ch < C; ch += 64) {
+      float f[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(src + ch), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= scale[ch + e];
+      const uint4 pk = pack_bf16x8(f);
+      *reinterpret_cast<uint4*>(dst + ch) = pk;
+      unpack_bf16x8(pk, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dot = fmaf(f[e], meanc[ch + e], dot);
+    }
+  }
+  dot = wave_xor_sum(dot, 1);
+  dot = wave_xor_sum(dot, 2);
+  dot = wave_xor_sum(dot, 4);
+  if (row < n && sub == 0) bias_out[(size_t)frame * n + row] = bias_beta[row] - dot;
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __restrict__ x1, int c1,
+                                                              const bf16_t* __restrict__ x2, int c2, int hw,
+                                                              int groups, float eps, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int silu,
+                                                              bf16_t* __restrict__ out, int slices, int slice_pix,
+                                                              const float* __restrict__ ws, int width, int w_shift,
+                                                              int out_pad) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int C = c1 + c2;
+  const int frame = blockIdx.x / slices, slice = blockIdx.x % slices;
+  const int tid = threadIdx.x;
+  float* scale = reinterpret_cast<float*>(smem);   // [C]
+  float* shift = scale + C;                        // [C]
+  float* gstat = shift + C;                        // [groups][2] mean, rstd
+  double* dpart = reinterpret_cast<double*>(gstat + 2 * groups);   // [GN_SUBS][groups][2]
+  const int cg = C / groups;
+  gn_group_stats(ws, frame, slices, groups, cg, hw, eps, gstat, dpart);
   for (int ch = tid; ch < C; ch += GN_THREADS) {
     int g = ch / cg;
     float sc = gamma[ch] * gstat[g * 2 + 1];
@@ -566,6 +624,41 @@ extern "C" int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int 
                      (const bf16_t*)x1, c1, (const bf16_t*)x2, c2, hw, groups, eps, gamma, beta, silu,
                      (bf16_t*)out, slices, slice_pix, (const float*)ws, width, w_shift, out_pad);
   return vx_check_launch("vx_groupnorm(apply)");
+}
+
+extern "C" int vx_groupnorm_stats(const void* x1, int c1, const void* x2, int c2, int frames, int hw, int groups,
+                                  float* ws, int slices, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int C = c1 + c2;
+  VX_REQUIRE(x1 != nullptr && ws != nullptr, "vx_groupnorm_stats: null pointer");
+  VX_REQUIRE((c2 == 0) == (x2 == nullptr), "vx_groupnorm_stats: x2/c2 mismatch");
+  VX_REQUIRE(c1 > 0 && (c1 % 8) == 0 && (c2 % 8) == 0, "vx_groupnorm_stats: channels must be multiples of 8");
+  VX_REQUIRE(groups > 0 && (C % groups) == 0, "vx_groupnorm_stats: C=%d not divisible by groups=%d", C, groups);
+  VX_REQUIRE(C <= 8 * GN_THREADS * GN_MAX_SETS, "vx_groupnorm_stats: C=%d too large", C);
+  VX_REQUIRE(frames > 0 && hw > 0 && slices > 0 && slices <= hw, "vx_groupnorm_stats: bad geometry");
+  const int slice_pix = ceil_div(hw, slices);
+  const int nchunks = C / 8;
+  const int tp = nchunks < GN_THREADS ? nchunks : GN_THREADS;
+  const size_t smem_stats = (size_t)(GN_THREADS / tp) * C * 2 * sizeof(float);
+  VX_REQUIRE(smem_stats <= 64 * 1024, "vx_groupnorm_stats: stats LDS %zu too large", smem_stats);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(frames * slices), dim3(GN_THREADS), smem_stats, stream,
+                     (const bf16_t*)x1, c1, (const bf16_t*)x2, c2, hw, groups, slices, slice_pix, ws);
+  return vx_check_launch("vx_groupnorm_stats");
+}
+
+extern "C" int vx_groupnorm_fold_linear(const float* ws, int frames, int hw, int slices, int groups, float eps,
+                                        const float* gamma, int c, const void* w, const float* bias_beta, int n,
+                                        void* w_out, float* bias_out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  VX_REQUIRE(ws != nullptr && gamma != nullptr && w != nullptr && bias_beta != nullptr && w_out != nullptr &&
+                 bias_out != nullptr, "vx_groupnorm_fold_linear: null pointer");
+  VX_REQUIRE(frames > 0 && hw > 0 && slices > 0 && n > 0 && c > 0 && (c % 8) == 0 && groups > 0 && (c % groups) == 0,
+             "vx_groupnorm_fold_linear: bad geometry (c=%d groups=%d n=%d)", c, groups, n);
+  const size_t smem = (size_t)(2 * c + 2 * groups) * sizeof(float) + (size_t)GN_SUBS * groups * 2 * sizeof(double);
+  VX_REQUIRE(smem <= 64 * 1024, "vx_groupnorm_fold_linear: c=%d too large", c);
+  hipLaunchKernelGGL(gn_fold_linear_kernel, dim3(ceil_div(n, GN_FOLD_ROWS), frames), dim3(GN_THREADS), smem, stream, ws,
+                     hw, slices, groups, eps, gamma, c, (const bf16_t*)w, bias_beta, n, (bf16_t*)w_out, bias_out);
+  return vx_check_launch("vx_groupnorm_fold_linear");
 }
 
 extern "C" int vx_layernorm(const void* x, int ldx, int rows, int c, float eps, const float* gamma,

@@ -44,6 +44,8 @@ class GemmParams(C.Structure):
         ("ring_hint", C.c_int32),
         ("a_fp8", C.c_int32), ("a_scale", C.c_void_p), ("w_scale", C.c_void_p),
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p),
+        ("row_stats_out", C.c_void_p), ("row_stats_eps", C.c_float),
+        ("w_group_rows", C.c_int32),
     ]
 
 
@@ -85,6 +87,8 @@ def _load():
     lib.vx_groupnorm_ws_floats.restype = i64
     lib.vx_groupnorm_ws_floats.argtypes = [i32, i32, i32]
     lib.vx_groupnorm.argtypes = [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, i32, i32, i32, vp]
+    lib.vx_groupnorm_stats.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp]
+    lib.vx_groupnorm_fold_linear.argtypes = [vp, i32, i32, i32, i32, f32, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.vx_layernorm.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp]
     lib.vx_row_stats.argtypes = [vp, i32, i32, i32, f32, vp, vp]
     lib.vx_layernorm_fp8.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp, vp]
@@ -110,7 +114,7 @@ def _load():
         if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name",
                         "vx_gemm_splitk_ws_bytes"):
             fn.restype = i32
-    if lib.vx_abi_version() != 8:
+    if lib.vx_abi_version() != 9:
         raise ImportError("libvexpress_hip.so ABI version mismatch")
     return lib
 

@@ -201,12 +201,15 @@ def fp8_weight(w):
 LN_FOLD = [os.environ.get("VX_LN_FOLD", "1") != "0"]
 
 
-def row_stats(x, eps=1e-5):
+def row_stats(x, eps=1e-5, out=None):
     """float32 [rows, 2] = (mean, rstd) of every row: the statistics of a LayerNorm folded into its consumer GEMM
     (`gemm(..., ln=(stats, colsum))`, weights.fold_layernorm)."""
     _chk_bf16(x, "x")
     ldx, rows = _row_stride(x)
-    out = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
+    elif out.dtype != torch.float32 or not out.is_contiguous() or tuple(out.shape) != (rows, 2):
+        raise ValueError("row_stats: out must be a contiguous float32 [rows, 2] tensor")
     L.check(_lib.vx_row_stats(_ptr(x), ldx, rows, x.shape[-1], float(eps), _ptr(out), _stream()), "vx_row_stats")
     return out
 
@@ -366,12 +369,25 @@ def _splitk(p, geom, device, plain):
 
 
 def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L.VX_ACT_NONE, rowbias=None,
-         rows_per_group=0, out=None, out_f32=False, ln=None):
+         rows_per_group=0, out=None, out_f32=False, ln=None, stats_out=None, stats_eps=1e-5, w_group_rows=0):
     """out[m, n] = residual + alpha * act(sum_k A[m,k] W[n,k] + bias[n] + rowbias[m // rows_per_group, n]).
     ln=(stats, colsum): a LayerNorm folded into this GEMM - the sum is replaced by rstd[m] * (sum - mean[m] * colsum[n])
-    with `w`, `bias` the folded weight / bias of weights.fold_layernorm and `a` the un-normalised rows."""
+    with `w`, `bias` the folded weight / bias of weights.fold_layernorm and `a` the un-normalised rows.
+    stats_out: float32 [m, 2] (contiguous) that receives (mean, rstd) of every STORED output row - the `ln` statistics
+    of the next GEMM (produced by the epilogue itself at the 64x64 level, by vx_row_stats inside vx_gemm otherwise).
+    w_group_rows > 0: `w` is [m // w_group_rows, N, K]; output rows of group g use w[g] (groupnorm_fold_linear)."""
     plain = geom is None
+    if w_group_rows:
+        if w.dim() != 3 or not w.is_contiguous():
+            raise ValueError("grouped weights must be a contiguous [groups, N, K] tensor")
+        n_groups = w.shape[0]
+        w = w.view(-1, w.shape[-1])
     p, geom = _base_params(a, w, geom, a2)
+    if w_group_rows:
+        if p.m != n_groups * w_group_rows:
+            raise ValueError(f"{n_groups} weight groups of {w_group_rows} rows do not cover m={p.m}")
+        p.n //= n_groups
+        p.w_group_rows = w_group_rows
     n = p.n
     if out is None:
         out = torch.empty((geom.m, n), device=a.device, dtype=torch.float32 if out_f32 else BF16)
@@ -395,6 +411,11 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
             _splitk(p, geom, a.device, plain)
         p.ring_hint = _ring_hint(p)
     _set_ln(p, ln)
+    if stats_out is not None:
+        if stats_out.dtype != torch.float32 or not stats_out.is_contiguous() or tuple(stats_out.shape) != (p.m, 2) \
+                or out_f32:
+            raise ValueError("stats_out must be a contiguous float32 [m, 2] tensor (bf16 output only)")
+        p.row_stats_out, p.row_stats_eps = stats_out.data_ptr(), float(stats_eps)
     _launch_gemm(p, "vx_gemm")
     return out
 
@@ -495,6 +516,51 @@ def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=No
     L.check(_lib.vx_groupnorm(_ptr(x1), c1, _ptr(x2), c2, frames, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
                               int(silu), _ptr(out), _ptr(ws), slices, width, pad, _stream()), "vx_groupnorm")
     return out
+
+
+GN_FOLD = [os.environ.get("VX_GN_FOLD", "1") != "0"]
+
+
+def gn_fold_applies(m, hw, c, n):
+    """Whether `groupnorm_fold_linear` + a grouped-weight GEMM replace groupnorm + GEMM for a [m, c] -> [m, n] layer:
+    the switch is on, the persistent 256 x 320 kernel takes the launch (decided from batch-independent facts, like
+    `_ring_hint`), a 256-row tile never straddles a frame, and the per-frame weight copies (frames x n x c) are cheaper
+    to write than the normalised tensor (2 x m x c): c = 320 in practice (the 64x64 and 96x96 levels)."""
+    items = _ITEMS[0]
+    if not GN_FOLD[0] or items is None or items <= 0 or m % items or hw % 256 or n % 320 or c % 64:
+        return False
+    rows_item = m // items
+    return rows_item % 256 == 0 and (2 * rows_item // 256) * (n // 320) >= 192 and n * 2 <= hw
+
+
+def groupnorm_stats(x1, *, frames, hw, groups, x2=None):
+    """The statistics pass of `groupnorm` alone -> workspace for `groupnorm_fold_linear` (slices as in `groupnorm`)."""
+    _chk_bf16(x1, "x1")
+    if not x1.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+        raise ValueError("groupnorm inputs must be contiguous")
+    c1 = x1.shape[-1]
+    c2 = x2.shape[-1] if x2 is not None else 0
+    slices = _gn_slices(hw)
+    ws = torch.empty(int(_lib.vx_groupnorm_ws_floats(frames, slices, groups)), device=x1.device, dtype=torch.float32)
+    L.check(_lib.vx_groupnorm_stats(_ptr(x1), c1, _ptr(x2), c2, frames, hw, groups, _ptr(ws), slices, _stream()),
+            "vx_groupnorm_stats")
+    return ws
+
+
+def groupnorm_fold_linear(ws, gamma, w, bias_beta, *, frames, hw, groups, eps):
+    """GroupNorm (no activation) folded into the linear layer behind it: -> (w_f bf16 [frames, N, C], b_f float32
+    [frames, N]) with GN(x) w^T + b == x w_f[f]^T + b_f[f] on the pixels of frame f; bias_beta = b + w beta (float32,
+    weights.fold_groupnorm).  Use: gemm(x, w_f, None, rowbias=b_f, rows_per_group=hw, w_group_rows=hw)."""
+    _chk_bf16(w, "w")
+    n, c = w.shape
+    if bias_beta.dtype != torch.float32 or gamma.dtype != torch.float32 or not w.is_contiguous():
+        raise TypeError("groupnorm_fold_linear: float32 gamma / bias_beta, contiguous bf16 weight expected")
+    w_f = torch.empty((frames, n, c), device=w.device, dtype=BF16)
+    b_f = torch.empty((frames, n), device=w.device, dtype=torch.float32)
+    L.check(_lib.vx_groupnorm_fold_linear(_ptr(ws), frames, hw, _gn_slices(hw), groups, float(eps), _ptr(gamma), c,
+                                          _ptr(w), _ptr(bias_beta), n, _ptr(w_f), _ptr(b_f), _stream()),
+            "vx_groupnorm_fold_linear")
+    return w_f, b_f
 
 
 def layernorm(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_entries=1, out=None):

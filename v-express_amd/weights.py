@@ -108,6 +108,20 @@ def fold_layernorm(w_src, bias, gamma, beta, device, row_scale=None, interleave=
     return Prepared(w=w.contiguous(), s=colsum.contiguous(), b=b.contiguous())
 
 
+def fold_groupnorm(w_src, bias, gamma, beta, device):
+    """A GroupNorm WITHOUT activation folded into the 1x1 / linear layer that consumes it (ops.groupnorm_fold_linear):
+    the frame-independent parts - the bf16 weight the per-frame copies are scaled from, gamma, and
+    bb = bias + W beta (float32, from the float32 source weight)."""
+    w32 = w_src.detach().to(device=device, dtype=torch.float32)
+    if w32.dim() == 4:
+        w32 = w32.reshape(w32.shape[0], w32.shape[1])
+    bb = w32 @ beta.detach().to(device=device, dtype=torch.float32)
+    if bias is not None:
+        bb = bb + bias.detach().to(device=device, dtype=torch.float32)
+    return Prepared(w=w32.to(BF16).contiguous(), g=gamma.detach().to(device=device, dtype=torch.float32).contiguous(),
+                    bb=bb.contiguous())
+
+
 def _qkv_rows(sd, p, device, heads, names):
     """fp32 row-concatenated source weight, bias (or None) and the per-row key-fold scale of a fused projection."""
     ws = [sd[f"{p}.{n}.weight"].detach().to(device=device, dtype=torch.float32) for n in names]
@@ -192,6 +206,9 @@ def prep_spatial_read(sd, p, device, heads=None):
                                 device)
     P["ln_ff"] = fold_layernorm(sd[t + ".ff.net.0.proj.weight"], sd[t + ".ff.net.0.proj.bias"], sd[t + ".norm3.weight"],
                                 sd[t + ".norm3.bias"], device, interleave=True)
+    # the block's GroupNorm (no activation) folded into proj_in (used where ops.gn_fold_applies says so)
+    P["gn_fold"] = fold_groupnorm(sd[p + ".proj_in.weight"], sd.get(p + ".proj_in.bias"), sd[p + ".norm.weight"],
+                                  sd[p + ".norm.bias"], device)
     return P
 
 
@@ -224,4 +241,6 @@ def prep_motion(sd, p, device):
                  ff_norm=prep_norm(sd, b + ".ff_norm", device), ff=prep_ff(sd, b + ".ff", device))
     P["ln_ff"] = fold_layernorm(sd[b + ".ff.net.0.proj.weight"], sd[b + ".ff.net.0.proj.bias"],
                                 sd[b + ".ff_norm.weight"], sd[b + ".ff_norm.bias"], device, interleave=True)
+    P["gn_fold"] = fold_groupnorm(sd[t + ".proj_in.weight"], sd.get(t + ".proj_in.bias"), sd[t + ".norm.weight"],
+                                  sd[t + ".norm.bias"], device)
     return P
