@@ -20,11 +20,3 @@ def reference():
     if not ref_import.have_reference():
         pytest.skip("/root/reference not present (GPU box): Tier-A checks run in the dev container only")
     return ref_import.import_reference()
-
-
-# The ring kernel's fp8 instantiation is opt-in in the product (it measures slower than the classic fp8 tiles:
-# DESIGN.md §8); the test session turns it on so that tests/test_gpu_kernels.py::test_gemm_fp8_ring_vs_classic_tiles
-# really compares the two kernels (the library reads the variable once, at its first fp8 launch).
-import os  # noqa: E402
-
-os.environ.setdefault("VX_FP8_RING", "1")

@@ -610,9 +610,9 @@ def test_gemm_fp8_store_and_split(ops, m, n, k):
 
 
 def test_gemm_fp8_ring_vs_classic_tiles(ops):
-    """The persistent ring kernel's fp8 instantiation (opt-in, VX_FP8_RING=1: it spills and measures slower than the
-    classic fp8 tiles; the test process enables it through the environment before the library first decides) against
-    the classic fp8 tiles (ring mode 0) and the float64 reference of the dequantised operands."""
+    """The persistent ring kernel's fp8 instantiation (opt-in: it spills and measures slower than the classic fp8 tiles;
+    enabled here, for this comparison only, through vx_gemm_set_fp8_ring so that every model-level fp8 test runs the
+    product default) against the classic fp8 tiles and the float64 reference of the dequantised operands."""
     from v_express_amd import lib as L
     m, n, k = 256 * 200, 640, 640
     a8, w8 = ops.quantize_fp8(rnd(m, k, seed=1)), ops.fp8_weight(rnd(n, k, scale=k ** -0.5, seed=2))
@@ -621,10 +621,12 @@ def test_gemm_fp8_ring_vs_classic_tiles(ops):
     outs = {}
     try:
         for mode in (2, 0):
-            L.check(L.lib.vx_gemm_set_ring_mode(mode), "ring mode")
-            outs[mode] = (ops.gemm(a8, w8, bias), ops.gemm(a8, w8, bias, residual=res, alpha=0.5))
+            L.check(L.lib.vx_gemm_set_fp8_ring(1 if mode else 0), "fp8 ring")
+            with ops.GemmProfile() as prof:
+                outs[mode] = (ops.gemm(a8, w8, bias), ops.gemm(a8, w8, bias, residual=res, alpha=0.5))
+            assert _ring_used(prof) == bool(mode), prof.records[0][3]
     finally:
-        L.check(L.lib.vx_gemm_set_ring_mode(2), "ring mode")
+        L.check(L.lib.vx_gemm_set_fp8_ring(0), "fp8 ring")
     for mode, (plain, with_res) in outs.items():
         check(plain, ref.float(), f"fp8 gemm ring mode {mode}")
         check(with_res, (res.double() + 0.5 * ref).float(), f"fp8 gemm + residual, ring mode {mode}")
@@ -706,3 +708,90 @@ def test_geglu_and_split_with_folded_layernorm(ops):
     check(kk, r[:, c:2 * c], "folded LN split k", rel=8e-3, mx=2 ** -6)
     check(vt[..., :seq], r[:, 2 * c:].view(m // seq, seq, heads, d).permute(0, 2, 3, 1), "folded LN split v^T", rel=8e-3,
           mx=2 ** -6)
+
+
+# ------------------------------------------------------------------- round 3: producer-side statistics, GroupNorm fold
+@pytest.mark.parametrize("m,n,k,res,offset", [(256 * 384, 320, 320, True, 0.0), (256 * 200, 320, 1280, True, 2.5),
+                                              (256 * 192, 320, 64, False, 0.5), (256 * 96, 640, 320, True, 0.5),
+                                              (300, 320, 640, True, 1.0)])
+def test_gemm_row_stats_out(ops, m, n, k, res, offset):
+    """vx_gemm_params.row_stats_out: (mean, rstd) of every STORED bf16 output row, against float64 statistics of the
+    tensor the launch wrote - from the ring epilogue's registers when one 256 x 320 tile holds whole rows (n = 320; sums
+    of x and x^2 in float32, rows with a mean of up to 2.5 standard deviations), from vx_row_stats inside vx_gemm
+    otherwise (n = 640 on the ring kernel, the classic tiles).  The output itself must not change."""
+    a, w = rnd(m, k), rnd(n, k, scale=k ** -0.5, seed=1)
+    bias = rnd(n, seed=2, dtype=torch.float32) + offset
+    r = rnd(m, n, seed=3) if res else None
+    st = torch.full((m, 2), float("nan"), device="cuda")
+    with ops.GemmProfile() as prof:
+        out = ops.gemm(a, w, bias, residual=r, alpha=0.75 if res else 1.0, stats_out=st, stats_eps=1e-5)
+    if m % 256 == 0:
+        assert _ring_used(prof), prof.records[0][3]
+    plain = ops.gemm(a, w, bias, residual=r, alpha=0.75 if res else 1.0)
+    assert torch.equal(out, plain)
+    x = out.double()
+    mean, rstd = x.mean(dim=1), torch.rsqrt(x.var(dim=1, unbiased=False) + 1e-5)
+    assert torch.isfinite(st).all()
+    assert torch.allclose(st[:, 0].double(), mean, rtol=2e-5, atol=2e-6), (st[:, 0].double() - mean).abs().max()
+    assert torch.allclose(st[:, 1].double(), rstd, rtol=1e-4), ((st[:, 1].double() - rstd) / rstd).abs().max()
+    # a launch over the first half of the rows gives the same bits (batch invariance of the fused statistics)
+    if (m // 2) % 256 == 0 and (m // 2 // 256) * (n // 320) >= 192:
+        st2 = torch.empty((m // 2, 2), device="cuda")
+        ops.gemm(a[:m // 2], w, bias, residual=None if r is None else r[:m // 2], alpha=0.75 if res else 1.0,
+                 stats_out=st2)
+        assert torch.equal(st2, st[:m // 2])
+
+
+@pytest.mark.parametrize("frames,hw,c,n", [(32, 1024, 320, 320), (4, 9216, 320, 320), (16, 2304, 640, 640)])
+def test_groupnorm_folded_into_linear(ops, frames, hw, c, n):
+    """GroupNorm without activation folded into the 1x1 / linear layer behind it (vx_groupnorm_stats +
+    vx_groupnorm_fold_linear + vx_gemm_params.w_group_rows): against GroupNorm + linear in float32, next to the
+    unfused pair of kernels, with per-frame statistics that differ strongly between frames and groups."""
+    groups, eps = 32, 1e-6
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(frames, hw, c, generator=g)
+    x = x * (0.5 + 2.0 * torch.rand(frames, 1, c, generator=g)) + 1.5 * torch.randn(frames, 1, c, generator=g)
+    x = x.to("cuda").to(BF)
+    w, bias = rnd(n, c, scale=c ** -0.5, seed=1), rnd(n, seed=2, dtype=torch.float32)
+    gamma, beta = 1 + 0.2 * rnd(c, seed=3, dtype=torch.float32), 0.3 * rnd(c, seed=4, dtype=torch.float32)
+    from v_express_amd import weights as Wt
+    G = Wt.fold_groupnorm(w.float(), bias, gamma, beta, "cuda")
+    ref = F.group_norm(x.float().transpose(1, 2), groups, gamma, beta, eps).transpose(1, 2).reshape(frames * hw, c)
+    ref = ref @ w.float().t() + bias
+    with ops.frame_rows(hw, items=1):
+        assert ops.gn_fold_applies(frames * hw, hw, c, n)
+        ws = ops.groupnorm_stats(x, frames=frames, hw=hw, groups=groups)
+        w_f, b_f = ops.groupnorm_fold_linear(ws, G.g, G.w, G.bb, frames=frames, hw=hw, groups=groups, eps=eps)
+        st = torch.empty((frames * hw, 2), device="cuda")
+        with ops.GemmProfile() as prof:
+            out = ops.gemm(x.view(frames * hw, c), w_f, None, rowbias=b_f, rows_per_group=hw, w_group_rows=hw,
+                           stats_out=st if n == 320 else None)
+        assert _ring_used(prof), prof.records[0][3]
+        unfused = ops.gemm(ops.groupnorm(x, gamma, beta, frames=frames, hw=hw, groups=groups, eps=eps,
+                                         silu=False).view(frames * hw, c), w, bias)
+    check(out, ref, f"GroupNorm folded into linear {frames}x{hw}x{c}->{n}")
+    check(unfused, ref, "GroupNorm + linear, unfused")
+    # the per-frame weights: one rounding of w * gamma * rstd
+    xf = x.float().view(frames, hw, groups, c // groups)
+    rstd = torch.rsqrt(xf.var(dim=(1, 3), unbiased=False) + eps).repeat_interleave(c // groups, dim=1)
+    check(w_f, w.float()[None] * (gamma[None] * rstd)[:, None, :], "per-frame folded weights", rel=4e-3, mx=2 ** -8)
+    if n == 320:
+        o = out.double()
+        assert torch.allclose(st[:, 0].double(), o.mean(dim=1), rtol=2e-5, atol=2e-6)
+    # a lone frame range computed alone is bit-identical (the fold is per frame)
+    half = frames // 2
+    with ops.frame_rows(hw, items=1):
+        if ops.gn_fold_applies(half * hw, hw, c, n):
+            ws2 = ops.groupnorm_stats(x[:half], frames=half, hw=hw, groups=groups)
+            w2, b2 = ops.groupnorm_fold_linear(ws2, G.g, G.w, G.bb, frames=half, hw=hw, groups=groups, eps=eps)
+            o2 = ops.gemm(x[:half].reshape(half * hw, c), w2, None, rowbias=b2, rows_per_group=hw, w_group_rows=hw)
+            assert torch.equal(o2, out[:half * hw])
+
+
+def test_grouped_weights_need_the_ring_kernel(ops):
+    """w_group_rows on a launch the persistent kernel does not take is refused (VX_ERR_UNSUPPORTED), never silently
+    computed with one weight."""
+    from v_express_amd.lib import VxError
+    x, w = rnd(4 * 64, 64), rnd(4, 64, 64, scale=0.1, seed=1)
+    with pytest.raises(VxError):
+        ops.gemm(x, w, None, w_group_rows=64)

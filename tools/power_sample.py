@@ -136,17 +136,31 @@ def main():
     if src is None:
         print(json.dumps(dict(tag=tag, error="no power/clock source (sysfs hwmon, amd-smi, rocm-smi) works here")))
         return subprocess.call(cmd)
+    def all_cards():
+        """(device, W, MHz) of every amdgpu hwmon the host exposes - shows which card actually follows the load"""
+        out = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            p = _read(os.path.join(d, "power1_average")) or _read(os.path.join(d, "power1_input"))
+            f = _read(os.path.join(d, "freq1_input"))
+            out.append((os.path.basename(os.path.realpath(os.path.dirname(os.path.dirname(d)))),
+                        round(float(p) * 1e-6, 1) if p else None, round(float(f) * 1e-6) if f else None))
+        return out
+
     idle = [src.sample() for _ in range(5)]
+    cards_idle, cards_busy = all_cards(), None
     t0 = time.time()
     proc = subprocess.Popen(cmd)
     samples = []
     while proc.poll() is None:
         samples.append((round(time.time() - t0, 3),) + src.sample())
+        if cards_busy is None and time.time() - t0 > 1.5:
+            cards_busy = all_cards()
         time.sleep(1.0 / hz)
     # the command's launch phase (dlopen, fills, reference checks) is not the loop: report the busiest half too
     pw = [s[1] for s in samples]
     top = sorted([p for p in pw if p is not None])[len(pw) // 2:]
     print(json.dumps(dict(tag=tag, source=src.name, hz_requested=hz, seconds=round(time.time() - t0, 2),
+                          hip_device_pci=hip_pci_bus_id(), cards_idle=cards_idle, cards_at_1p5s=cards_busy,
                           power_cap_w=src.cap, idle=dict(power_w=summarize([s[0] for s in idle]),
                                                          sclk_mhz=summarize([s[1] for s in idle])),
                           power_w=summarize(pw), power_w_busiest_half=summarize(top),

@@ -707,6 +707,17 @@ extern "C" int vx_gemm_ring_set_trace(void* dev_buf) {
 
 static int g_ring_mode = -1;   // VX_GEMM_RING: 0 off, 1 short K only, 2 (default) every eligible shape
 
+static int g_fp8_ring = -1;    // VX_FP8_RING / vx_gemm_set_fp8_ring: fp8 operands on the ring kernel (opt-in, see below)
+
+extern "C" int vx_gemm_set_fp8_ring(int on) {
+  if (on < -1 || on > 1) {
+    vx_set_error("vx_gemm_set_fp8_ring: %d outside [-1, 1]", on);
+    return VX_ERR_INVALID;
+  }
+  g_fp8_ring = on;
+  return VX_OK;
+}
+
 extern "C" int vx_gemm_set_ring_mode(int mode) {
   if (mode < 0 || mode > 2) {
     vx_set_error("vx_gemm_set_ring_mode: mode %d outside [0, 2]", mode);
@@ -727,8 +738,8 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
     // fp8 operands on the ring kernel: correct (tests/test_gpu_kernels.py::test_gemm_fp8_ring_vs_classic_tiles), but
     // its 8-register MFMA operand tuples push the 256-VGPR budget over (67-72 spilled registers in the K loop) and it
     // measures SLOWER than the classic fp8 tiles (287 vs 207 us at 294912 x 320 x 384; 768^2 clip 3.59 vs 3.92
-    // frames/s, profiles/r02d_*): off unless VX_FP8_RING=1
-    static int on = -1;
+    // frames/s, profiles/r02d_*): off unless VX_FP8_RING=1 / vx_gemm_set_fp8_ring(1)
+    int& on = g_fp8_ring;
     if (on < 0) {
       const char* e = getenv("VX_FP8_RING");
       on = e && !strcmp(e, "1");

@@ -137,6 +137,12 @@ class DistContext:
     def enabled(self):
         return self.world_size > 1
 
+    @property
+    def backend(self):
+        """Collective backend of the group ("nccl" = RCCL over xGMI, the only measured configuration; anything else
+        stages CUDA tensors through the host and exists for control-flow tests on one GPU)."""
+        return dist.get_backend(self.group) if self.enabled else None
+
     @staticmethod
     def from_env():
         if dist.is_available() and dist.is_initialized():

@@ -107,6 +107,7 @@ def _load():
     lib.vx_nhwc_to_ncfhw.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     lib.vx_vae_postprocess.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     lib.vx_gemm_set_ring_mode.argtypes = [i32]
+    lib.vx_gemm_set_fp8_ring.argtypes = [i32]
     lib.vx_median3d.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
     lib.vx_wave_conv1d.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp]
     for name in declared_symbols():

@@ -198,7 +198,10 @@ def fp8_weight(w):
     return hit[1]
 
 
-LN_FOLD = [os.environ.get("VX_LN_FOLD", "1") != "0"]
+# the folded-LayerNorm GEMMs exist for the FAST addressing path only: the VX_GEMM_NOFAST A/B knob turns the fold off too
+LN_FOLD = [os.environ.get("VX_LN_FOLD", "1") != "0" and os.environ.get("VX_GEMM_NOFAST") is None]
+# VX_FUSED_STATS=0 (A/B knob): the row statistics a GEMM is asked for come from a separate vx_row_stats pass
+FUSED_STATS = [os.environ.get("VX_FUSED_STATS", "1") != "0"]
 
 
 def row_stats(x, eps=1e-5, out=None):
@@ -415,8 +418,11 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
         if stats_out.dtype != torch.float32 or not stats_out.is_contiguous() or tuple(stats_out.shape) != (p.m, 2) \
                 or out_f32:
             raise ValueError("stats_out must be a contiguous float32 [m, 2] tensor (bf16 output only)")
-        p.row_stats_out, p.row_stats_eps = stats_out.data_ptr(), float(stats_eps)
+        if FUSED_STATS[0]:
+            p.row_stats_out, p.row_stats_eps = stats_out.data_ptr(), float(stats_eps)
     _launch_gemm(p, "vx_gemm")
+    if stats_out is not None and not FUSED_STATS[0]:
+        row_stats(out, stats_eps, out=stats_out)       # A/B arm: the separate read pass of round 2
     return out
 
 
