@@ -120,6 +120,7 @@ int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk);
  * persistent ring-staged 256x320 kernel, 1 = only for K <= 1280, 2 = for every eligible problem.  Results differ only by
  * fp32 summation order (the ring kernel walks conv taps innermost).  For A/B measurements and cross-checking tests. */
 int vx_gemm_set_ring_mode(int mode);
+int vx_gemm_get_ring_mode(void);   /* the mode in force (0 / 1 / 2): callers that need the persistent kernel (w_group_rows) ask first */
 /* fp8 operands (a_fp8) on the persistent ring kernel: 1 = on, 0 = off (product default: it measures slower than the
  * classic fp8 tiles), -1 = re-read the VX_FP8_RING environment variable at the next fp8 launch.  Process-wide; for the
  * kernel-level cross-check test, so that model-level fp8 tests run the product default. */

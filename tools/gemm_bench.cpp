@@ -293,6 +293,17 @@ int main(int argc, char** argv) {
         p.residual = res; p.ldr = N;
       }
     }
+    // LNFOLD=1: the product form of the q / qkv / GEGLU projections (vx_gemm_params.ln_stats: timing only, the spot
+    // check below is skipped for these launches)
+    float *lnst = nullptr, *lncs = nullptr;
+    const bool lnfold = getenv("LNFOLD") && atoi(getenv("LNFOLD")) && s.ks == 1 && s.epi != 3;
+    if (lnfold) {
+      CK(hipMalloc(&lnst, (size_t)M * 2 * 4));
+      CK(hipMalloc(&lncs, (size_t)N * 4));
+      fill_f32<<<(2 * M + 255) / 256, 256, 0, st>>>(lnst, (size_t)2 * M, 11u, 0.25f);
+      fill_f32<<<(N + 255) / 256, 256, 0, st>>>(lncs, N, 12u, 0.5f);
+      p.ln_stats = lnst; p.ln_colsum = lncs;
+    }
     void* skws = nullptr;
     if (getenv("SPLITK") && atoi(getenv("SPLITK")) > 1 && p.epi == VX_EPI_STORE && K / 64 >= atoi(getenv("SPLITK"))) {
       p.splitk = atoi(getenv("SPLITK"));   // two-launch deterministic split-K (the 8x8-level policy of ops._splitk)
@@ -308,7 +319,7 @@ int main(int argc, char** argv) {
     // ---- spot check (STORE and the Q part of SPLIT are directly comparable)
     double maxrel = -1;
     bool ok = true;
-    if (s.epi != 1) {
+    if (s.epi != 1 && !lnfold) {
       int ncheck = s.epi == 2 ? N / 3 : N;
       for (int i = 0; i < NS; ++i) {
         uint32_t h = hash32(i * 7919u + 17u);
@@ -380,7 +391,7 @@ int main(int argc, char** argv) {
     fflush(stdout);
     tot_us += us * s.per_fwd;
     tot_fl += fl * s.per_fwd;
-    for (void* q : {(void*)a, (void*)a2, (void*)w, (void*)bias, (void*)out, (void*)res, (void*)p1, (void*)p2})
+    for (void* q : {(void*)a, (void*)a2, (void*)w, (void*)bias, (void*)out, (void*)res, (void*)p1, (void*)p2, (void*)lnst, (void*)lncs})
       if (q) CK(hipFree(q));
   }
   if (!filter || strstr("norm", filter)) norm_bench(lib, st, reps);

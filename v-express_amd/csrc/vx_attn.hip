@@ -642,14 +642,17 @@ struct TemporalParams {
   float c;
 };
 
-template <int KK, int DT, int FT>
-__global__ __launch_bounds__(256) void temporal_attn_kernel(const TemporalParams p) {
+// WPB waves per block, consecutive heads of one pixel: with WPB = heads = 8 a block reads whole 128-byte lines of the
+// token rows (a head's q / k / v slice is d * 2 = 80 bytes at d = 40: with 4 heads per block the line in the middle of a
+// pixel's 8 heads was fetched by two blocks on two XCDs, i.e. two L2s - 1.6x the traffic of an HBM-bound kernel)
+template <int KK, int DT, int FT, int WPB>
+__global__ __launch_bounds__(64 * WPB) void temporal_attn_kernel(const TemporalParams p) {
   constexpr int VP = 32 * KK + 8;   // V tile pitch in elements (pad breaks the power-of-two stride)
-  __shared__ __attribute__((aligned(16))) bf16_t vsm[4][16 * FT][VP];
+  __shared__ __attribute__((aligned(16))) bf16_t vsm[WPB][16 * FT][VP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, g = lane >> 4;
   const long total = (long)p.b * p.hw * p.heads;
-  long wg = (long)blockIdx.x * 4 + wave;
+  long wg = (long)blockIdx.x * WPB + wave;
   const bool live = wg < total;
   if (!live) wg = total - 1;
   const int h = (int)(wg % p.heads);
@@ -768,9 +771,21 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TemporalParams
 template <int KK, int DT>
 int launch_temporal(const TemporalParams& p, hipStream_t stream) {
   long waves = (long)p.b * p.hw * p.heads;
+  static int wpb_env = -1;   // VX_TEMPORAL_WPB = 4 | 8 (A/B knob; default: 8 when the head count allows)
+  if (wpb_env < 0) {
+    const char* e = getenv("VX_TEMPORAL_WPB");
+    wpb_env = e ? atoi(e) : 0;
+  }
+  const bool wide = wpb_env ? wpb_env == 8 : (p.heads % 8) == 0;
+  if (wide && (p.heads % 8) == 0 && KK * (p.f <= 16 ? 1 : 2) <= 6) {   // LDS: 8 x 16 FT x (32 KK + 8) x 2 B <= 64 KiB
+    dim3 grid((unsigned)((waves + 7) / 8));
+    if (p.f <= 16) hipLaunchKernelGGL((temporal_attn_kernel<KK, DT, 1, 8>), grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((temporal_attn_kernel<KK, DT, 2, 8>), grid, dim3(512), 0, stream, p);
+    return vx_check_launch("vx_temporal_attention");
+  }
   dim3 grid((unsigned)((waves + 3) / 4));
-  if (p.f <= 16) hipLaunchKernelGGL((temporal_attn_kernel<KK, DT, 1>), grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((temporal_attn_kernel<KK, DT, 2>), grid, dim3(256), 0, stream, p);
+  if (p.f <= 16) hipLaunchKernelGGL((temporal_attn_kernel<KK, DT, 1, 4>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((temporal_attn_kernel<KK, DT, 2, 4>), grid, dim3(256), 0, stream, p);
   return vx_check_launch("vx_temporal_attention");
 }
 

@@ -466,7 +466,33 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
         }
       }
     }
-    if (p.ln_stats != nullptr) {
+    if constexpr (EPI == VX_EPI_GEGLU) {
+      // bias and the folded LayerNorm in one pass over the raw accumulators, on every lane's OWN columns (before the
+      // value / gate pairing): acc <- rstd[m] * acc + (bias[n] - rstd[m] * mean[m] * colsum[n]) = 2 FMA per element
+      // instead of FMA + MUL + ADD - the GEGLU epilogue is VALU-bound on the short-K shapes
+      const bool has_ln = p.ln_stats != nullptr;
+      const float2* __restrict__ st = reinterpret_cast<const float2*>(p.ln_stats);
+      float rs[8], rm[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float2 t = has_ln ? st[row_base + 16 * i] : make_float2(0.f, 1.f);
+        rs[i] = t.y;
+        rm[i] = -t.x * t.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int col = tile_n * R_BN + 80 * wc + 16 * j + 4 * lq;
+        const float4 b4 = bias != nullptr ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 s4 = has_ln ? *reinterpret_cast<const float4*>(p.ln_colsum + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc[i][j][0] = fmaf(rs[i], acc[i][j][0], fmaf(rm[i], s4.x, b4.x));
+          acc[i][j][1] = fmaf(rs[i], acc[i][j][1], fmaf(rm[i], s4.y, b4.y));
+          acc[i][j][2] = fmaf(rs[i], acc[i][j][2], fmaf(rm[i], s4.z, b4.z));
+          acc[i][j][3] = fmaf(rs[i], acc[i][j][3], fmaf(rm[i], s4.w, b4.w));
+        }
+      }
+    } else if (p.ln_stats != nullptr) {
       // folded LayerNorm: acc <- rstd[m] * (acc - mean[m] * colsum[n])   (see vx_gemm_params.ln_stats)
       const float2* __restrict__ st = reinterpret_cast<const float2*>(p.ln_stats);
       const float* __restrict__ cs = p.ln_colsum;
@@ -640,23 +666,11 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
       // gives lanes 0-31 value AND gate of block i, lanes 32-63 those of block i+1: no lane idles in the GELU.
       // Then the packed results of fragments (j, j+1) are exchanged with v_permlane16_swap for 16-byte stores.
       const int ocol_base = (tile_n * R_BN + 80 * wc) / 2 + 4 * (lq & 1);    // + 8 j (+ r)
-      const int bcol_base = tile_n * R_BN + 80 * wc + 4 * (lq & 1);         // value bias; gate bias at + 8
       const int orow = row_base + 16 * (lane >> 5);                          // + 16 i  (i even)
       bf16_t* __restrict__ outp = (bf16_t*)p.out;
 #pragma unroll
       for (int jp = 0; jp < 5; jp += 2) {
         const int nj = jp + 1 < 5 ? 2 : 1;
-        float bval[2][4], bgat[2][4];
-#pragma unroll
-        for (int jj = 0; jj < nj; ++jj) {
-          float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = v4;
-          if (bias != nullptr) {
-            v4 = *reinterpret_cast<const float4*>(bias + bcol_base + 16 * (jp + jj));
-            g4 = *reinterpret_cast<const float4*>(bias + bcol_base + 16 * (jp + jj) + 8);
-          }
-          bval[jj][0] = v4.x; bval[jj][1] = v4.y; bval[jj][2] = v4.z; bval[jj][3] = v4.w;
-          bgat[jj][0] = g4.x; bgat[jj][1] = g4.y; bgat[jj][2] = g4.z; bgat[jj][3] = g4.w;
-        }
 #pragma unroll
         for (int i = 0; i < 8; i += 2) {
           uint32_t pk[2][2];
@@ -667,8 +681,8 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
             for (int r = 0; r < 4; ++r) {
               auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][jp + jj][r]),
                                                          __float_as_uint(acc[i + 1][jp + jj][r]), false, false);
-              const float val = __uint_as_float(sw[0]) + bval[jj][r];   // lanes 0-31: block i, lanes 32-63: block i+1
-              const float gat = __uint_as_float(sw[1]) + bgat[jj][r];
+              const float val = __uint_as_float(sw[0]);   // lanes 0-31: block i, lanes 32-63: block i+1
+              const float gat = __uint_as_float(sw[1]);   // (biases were added before the pairing)
               o[r] = val * (RABL(64) ? gat : gelu_f(gat));
             }
             pk[jj][0] = pack_bf16x2(o[0], o[1]);
@@ -727,12 +741,19 @@ extern "C" int vx_gemm_set_ring_mode(int mode) {
   return VX_OK;
 }
 
-bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
+static int ring_mode() {
   int& mode = g_ring_mode;
   if (mode < 0) {
     const char* e = getenv("VX_GEMM_RING");
     mode = (e && !strcmp(e, "0")) ? 0 : ((e && !strcmp(e, "1")) ? 1 : 2);
   }
+  return mode;
+}
+
+extern "C" int vx_gemm_get_ring_mode(void) { return ring_mode(); }
+
+bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
+  const int mode = ring_mode();
   if (!mode || p.ring_hint < 0) return false;
   if (p.a_fp8) {
     // fp8 operands on the ring kernel: correct (tests/test_gpu_kernels.py::test_gemm_fp8_ring_vs_classic_tiles), but

@@ -10,7 +10,8 @@ import re
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvexpress_hip.so")
+# VX_LIBRARY: another build of the SAME library (same-box A/B runs of kernel variants, tools/ only); default in-tree
+LIB_PATH = os.environ.get("VX_LIBRARY") or os.path.join(_HERE, "libvexpress_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vexpress_hip.h")
 

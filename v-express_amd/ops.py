@@ -535,6 +535,8 @@ def gn_fold_applies(m, hw, c, n):
     items = _ITEMS[0]
     if not GN_FOLD[0] or items is None or items <= 0 or m % items or hw % 256 or n % 320 or c % 64:
         return False
+    if _lib.vx_gemm_get_ring_mode() == 0 or (c > 1280 and _lib.vx_gemm_get_ring_mode() == 1):
+        return False                   # the persistent kernel is switched off (A/B knob vx_gemm_set_ring_mode)
     rows_item = m // items
     return rows_item % 256 == 0 and (2 * rows_item // 256) * (n // 320) >= 192 and n * 2 <= hw
 
