@@ -72,6 +72,11 @@ constexpr int R_LDS_TOTAL = R_LDS_BYTES + STATS_BYTES;   // 155,648 of the CU's 
 #ifndef VX_RING_PRIO
 #define VX_RING_PRIO 1
 #endif
+// residual loads of the STORE epilogue kept in flight ahead of their use (16 bytes each; A/B knob, product 10: the bias
+// registers of the round-2 epilogue are gone, so the prefetch is 4 items deeper at the same register count)
+#ifndef VX_RING_RES_DEPTH
+#define VX_RING_RES_DEPTH 10
+#endif
 constexpr bool RING_MI_M = VX_RING_MISSUE == 1 || VX_RING_MISSUE == 2;
 constexpr bool RING_MI_LATE = VX_RING_MISSUE == 3;
 #ifdef VX_RING_TRACE
@@ -125,7 +130,9 @@ __device__ __forceinline__ f32x4_t ring_mfma_f8(const uint4& a_lo, const uint4& 
 // RES: STORE epilogue with a residual addend.  STATS (STORE, n == 320: one column tile holds whole rows): the epilogue
 // also writes (mean, rstd) of every stored bf16 row to p.row_stats_out - the statistics of the LayerNorm that the NEXT
 // GEMM folds (vx_gemm_params.ln_stats), so no separate pass re-reads the tensor.
-template <int EPI, bool RES, bool F8 = false, bool STATS = false>
+// LNF: a LayerNorm is folded into this GEMM (p.ln_stats / p.ln_colsum); a template flag, not a run-time branch: as a
+// branch the epilogue's live values spilled (the lesson of the classic tiles in round 2).
+template <int EPI, bool RES, bool F8 = false, bool STATS = false, bool LNF = false>
 __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params p) {
   constexpr int ES = F8 ? 1 : 2;      // bytes per operand element
   constexpr int BKE = 128 / ES;       // elements per K-tile
@@ -466,44 +473,47 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
         }
       }
     }
-    if constexpr (EPI == VX_EPI_GEGLU) {
-      // bias and the folded LayerNorm in one pass over the raw accumulators, on every lane's OWN columns (before the
-      // value / gate pairing): acc <- rstd[m] * acc + (bias[n] - rstd[m] * mean[m] * colsum[n]) = 2 FMA per element
-      // instead of FMA + MUL + ADD - the GEGLU epilogue is VALU-bound on the short-K shapes
-      const bool has_ln = p.ln_stats != nullptr;
-      const float2* __restrict__ st = reinterpret_cast<const float2*>(p.ln_stats);
+    {
+      // Bias (+ the tile's time-embedding / per-item row) and the folded LayerNorm in ONE pass over the raw accumulators,
+      // on every lane's OWN columns (before any lane exchange): with the fold, acc <- rstd[m] * acc + (bias[n] -
+      // rstd[m] * mean[m] * colsum[n]) = 2 FMA per element instead of FMA + MUL + ADD; without it one ADD.  Both
+      // epilogues are VALU / latency bound on the short-K shapes, and the STORE epilogue needs no bias registers while it
+      // walks its items (they hold a deeper residual prefetch instead).
+      const float* rb_row0 = nullptr;
+      if constexpr (EPI == VX_EPI_STORE)
+        rb_row0 = rowbias != nullptr ? rowbias + (size_t)((tile_m * R_BM) / p.rows_per_group) * p.rowbias_ld : nullptr;
       float rs[8], rm[8];
+      if constexpr (LNF) {
+        const float2* __restrict__ st = reinterpret_cast<const float2*>(p.ln_stats);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float2 t = has_ln ? st[row_base + 16 * i] : make_float2(0.f, 1.f);
-        rs[i] = t.y;
-        rm[i] = -t.x * t.y;
+        for (int i = 0; i < 8; ++i) {
+          const float2 t = st[row_base + 16 * i];
+          rs[i] = t.y;
+          rm[i] = -t.x * t.y;
+        }
       }
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         const int col = tile_n * R_BN + 80 * wc + 16 * j + 4 * lq;
-        const float4 b4 = bias != nullptr ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 s4 = has_ln ? *reinterpret_cast<const float4*>(p.ln_colsum + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          acc[i][j][0] = fmaf(rs[i], acc[i][j][0], fmaf(rm[i], s4.x, b4.x));
-          acc[i][j][1] = fmaf(rs[i], acc[i][j][1], fmaf(rm[i], s4.y, b4.y));
-          acc[i][j][2] = fmaf(rs[i], acc[i][j][2], fmaf(rm[i], s4.z, b4.z));
-          acc[i][j][3] = fmaf(rs[i], acc[i][j][3], fmaf(rm[i], s4.w, b4.w));
+        float4 b4 = bias != nullptr ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rb_row0 != nullptr) {
+          const float4 r4 = *reinterpret_cast<const float4*>(rb_row0 + col);
+          b4.x += r4.x; b4.y += r4.y; b4.z += r4.z; b4.w += r4.w;
         }
-      }
-    } else if (p.ln_stats != nullptr) {
-      // folded LayerNorm: acc <- rstd[m] * (acc - mean[m] * colsum[n])   (see vx_gemm_params.ln_stats)
-      const float2* __restrict__ st = reinterpret_cast<const float2*>(p.ln_stats);
-      const float* __restrict__ cs = p.ln_colsum;
+        if constexpr (LNF) {
+          const float4 s4 = *reinterpret_cast<const float4*>(p.ln_colsum + col);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float2 t = st[row_base + 16 * i];
+          for (int i = 0; i < 8; ++i) {
+            acc[i][j][0] = fmaf(rs[i], acc[i][j][0], fmaf(rm[i], s4.x, b4.x));
+            acc[i][j][1] = fmaf(rs[i], acc[i][j][1], fmaf(rm[i], s4.y, b4.y));
+            acc[i][j][2] = fmaf(rs[i], acc[i][j][2], fmaf(rm[i], s4.z, b4.z));
+            acc[i][j][3] = fmaf(rs[i], acc[i][j][3], fmaf(rm[i], s4.w, b4.w));
+          }
+        } else if (bias != nullptr || rb_row0 != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          const float4 s4 = *reinterpret_cast<const float4*>(cs + tile_n * R_BN + 80 * wc + 16 * j + 4 * lq);
-          acc[i][j][0] = t.y * (acc[i][j][0] - t.x * s4.x); acc[i][j][1] = t.y * (acc[i][j][1] - t.x * s4.y);
-          acc[i][j][2] = t.y * (acc[i][j][2] - t.x * s4.z); acc[i][j][3] = t.y * (acc[i][j][3] - t.x * s4.w);
+          for (int i = 0; i < 8; ++i) {
+            acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w;
+          }
         }
       }
     }
@@ -515,11 +525,9 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
       // the 160 contiguous bytes of an output row within one step (partial lines meet in L2 right away), the lane's
       // 20 bias values (+ the tile's time-embedding row) are loaded once per tile, and the residual loads run
       // RES_DEPTH items ahead of their use: the epilogue of a short-K tile is a string of HBM round trips otherwise.
-      constexpr int N_ITEMS = 24, RES_DEPTH = 6;
+      constexpr int N_ITEMS = 24, RES_DEPTH = LNF ? 4 : VX_RING_RES_DEPTH;   // (LNF + RES: unused by the model, keep it spill-free)
       const int col_p = tile_n * R_BN + 80 * wc + 8 * (lq >> 1) + 16 * (lq & 1);   // + 32 t  (pair t = 0, 1)
       const int col_4 = tile_n * R_BN + 80 * wc + 64 + 4 * lq;
-      const float* rb_row = rowbias != nullptr ? rowbias + (size_t)((tile_m * R_BM) / p.rows_per_group) * p.rowbias_ld
-                                               : nullptr;   // rows_per_group % 256 == 0: one row per tile
       // byte offsets (32-bit: eligibility bounds m * ld * 2 < 4 GiB) = per-lane base + wave-uniform item part
       const uint32_t ldr2 = (uint32_t)p.ldr * 2u, ldc2 = (uint32_t)p.ldc * 2u;
       const uint32_t res_p = (uint32_t)row_base * ldr2 + (uint32_t)col_p * 2u, res_4 = (uint32_t)row_base * ldr2 + (uint32_t)col_4 * 2u;
@@ -533,26 +541,6 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
       };
       const char* __restrict__ resb = (const char*)resid;
       char* __restrict__ outb = (char*)p.out;
-      float bv[2][8], b4[4];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[t][e] = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) b4[e] = 0.f;
-      auto add_bias = [&](const float* src) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const float4 x0 = *reinterpret_cast<const float4*>(src + col_p + 32 * t);
-          const float4 x1 = *reinterpret_cast<const float4*>(src + col_p + 32 * t + 4);
-          bv[t][0] += x0.x; bv[t][1] += x0.y; bv[t][2] += x0.z; bv[t][3] += x0.w;
-          bv[t][4] += x1.x; bv[t][5] += x1.y; bv[t][6] += x1.z; bv[t][7] += x1.w;
-        }
-        const float4 x4 = *reinterpret_cast<const float4*>(src + col_4);
-        b4[0] += x4.x; b4[1] += x4.y; b4[2] += x4.z; b4[3] += x4.w;
-      };
-      if (bias != nullptr) add_bias(bias);
-      if (rb_row != nullptr) add_bias(rb_row);
       uint4 rv[N_ITEMS];   // (.x, .y only for the 8-byte items)
       auto load_res = [&](int k) {
         if (k % 3 == 2) {
@@ -575,7 +563,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            v[r] = acc[i][4][r] + b4[r];
+            v[r] = acc[i][4][r];
             if (do_silu) v[r] = silu_f(v[r]);
             v[r] *= alpha;
           }
@@ -616,8 +604,6 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
             v[r] = x;
             v[4 + r] = y;
           }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bv[kind][e];
           if (do_silu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
@@ -793,10 +779,10 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
   return mode == 2 || p.k <= 1280;
 }
 
-template <int EPI, bool RES, bool F8 = false, bool STATS = false>
+template <int EPI, bool RES, bool F8 = false, bool STATS = false, bool LNF = false>
 static int ring_launch(const vx_gemm_params& p, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = gemm_ring_kernel<EPI, RES, F8, STATS>;
+  auto kern = gemm_ring_kernel<EPI, RES, F8, STATS, LNF>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_TOTAL);
     if (e != hipSuccess) {
@@ -820,11 +806,21 @@ int vx_gemm_ring_launch(const vx_gemm_params& p, hipStream_t stream) {
   if (p.a_fp8)
     return p.residual != nullptr ? ring_launch<VX_EPI_STORE, true, true>(p, stream)
                                  : ring_launch<VX_EPI_STORE, false, true>(p, stream);
-  if (p.epi == VX_EPI_GEGLU) return ring_launch<VX_EPI_GEGLU, false>(p, stream);
+  const bool ln = p.ln_stats != nullptr;
+  if (p.epi == VX_EPI_GEGLU)
+    return ln ? ring_launch<VX_EPI_GEGLU, false, false, false, true>(p, stream) : ring_launch<VX_EPI_GEGLU, false>(p, stream);
+  const bool res = p.residual != nullptr;
+  if (ln) {
+    // the folded projections (q / qkv) never carry a residual in this model; the combination exists for completeness
+    if (vx_gemm_ring_writes_row_stats(p))
+      return res ? ring_launch<VX_EPI_STORE, true, false, true, true>(p, stream)
+                 : ring_launch<VX_EPI_STORE, false, false, true, true>(p, stream);
+    return res ? ring_launch<VX_EPI_STORE, true, false, false, true>(p, stream)
+               : ring_launch<VX_EPI_STORE, false, false, false, true>(p, stream);
+  }
   if (vx_gemm_ring_writes_row_stats(p))
-    return p.residual != nullptr ? ring_launch<VX_EPI_STORE, true, false, true>(p, stream)
-                                 : ring_launch<VX_EPI_STORE, false, false, true>(p, stream);
-  return p.residual != nullptr ? ring_launch<VX_EPI_STORE, true>(p, stream) : ring_launch<VX_EPI_STORE, false>(p, stream);
+    return res ? ring_launch<VX_EPI_STORE, true, false, true>(p, stream) : ring_launch<VX_EPI_STORE, false, false, true>(p, stream);
+  return res ? ring_launch<VX_EPI_STORE, true>(p, stream) : ring_launch<VX_EPI_STORE, false>(p, stream);
 }
 
 // whether the ring launch of p fills p.row_stats_out itself (otherwise vx_gemm runs vx_row_stats on the output)
