@@ -88,8 +88,12 @@ __device__ __forceinline__ float gelu_f(float x) {
   q = fmaf(q, u, -4.587709606e-01f);
   q = fmaf(q, u, -1.151201725e+00f);
   q = fmaf(q, u, -9.999930859e-01f);
-  float relu;   // one v_max_f32 (the compiler's fmaxf / med3 forms add a canonicalising v_max under IEEE mode)
+#ifdef VX_GELU_NOASM   // A/B build: the compiler's relu (v_max + a canonicalising v_max under IEEE mode)
+  const float relu = fmaxf(x, 0.0f);
+#else
+  float relu;   // one v_max_f32
   asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(x));
+#endif
   return fmaf(-u, __builtin_amdgcn_exp2f(q), relu);
 }
 // the Abramowitz-Stegun form (kept for A/B builds: -DVX_GELU_AS)
