@@ -330,8 +330,11 @@ def main():
     fps = F * args.steps / elapsed
     scale = (args.size / 512.0) ** 2
     fpf = flop_per_frame(F, len(windows), args.ddim_steps, scale)
-    from v_express_amd.distributed import choose_frame_shards
+    from v_express_amd.distributed import choose_frame_shards, choose_mixed_shards
     fshards = pipe.frame_shards or choose_frame_shards(len(windows), world, ctx, (args.size // 64) ** 2)
+    mshards = 1
+    if fshards == 1 and world > 1 and pipe.mixed_shards != 1:
+        mshards = pipe.mixed_shards or choose_mixed_shards(2 * len(windows), world, ctx, (args.size // 64) ** 2)
 
     result = {
         "metric": f"decoded frames/sec at {args.size}x{args.size}, {args.ddim_steps} DDIM steps", "value": fps, "unit": "frames/s",
@@ -341,9 +344,11 @@ def main():
         "config": {"workload": (f"{args.size}x{args.size}, {F} frames ({len(windows)} window(s) of {ctx}, overlap {ovl}), "
                                 f"{args.ddim_steps} DDIM steps, CFG 3.5, random-init UNet3D + ReferenceNet banks + "
                                 "sd-vae-ft-mse decode"),
-                   "frames": F, "windows": len(windows), "frame_shards": fshards,
+                   "frames": F, "windows": len(windows), "frame_shards": fshards, "mixed_shards": mshards,
                    "parallelism": (f"window x CFG-half units over {world} GPU(s)" +
-                                   (f", {fshards} frame shards per unit" if fshards > 1 else ""))},
+                                   (f", {fshards} frame shards per unit" if fshards > 1 else "") +
+                                   (f", {2 * len(windows) // world} whole units per GPU + the {2 * len(windows) % world} "
+                                    f"left-over units frame-sharded {mshards} ways" if mshards > 1 else ""))},
         "prologue_ms": 1e3 * prologue_s, "model_build_s": t_build,
     }
     if world > 1:

@@ -176,3 +176,37 @@ def test_frame_shard_schedule_and_auto_policy():
     assert [u.calls(r) for r in range(4)] == [[(0, [0, 1]), (1, [0])]] * 2 + [[(1, [1]), (2, [0, 1])]] * 2
     with pytest.raises(ValueError):
         D.UnitSchedule(1, 6, 4)
+
+
+def test_mixed_schedule_whole_units_plus_sharded_leftovers():
+    """distributed.MixedUnitSchedule (round 3): when units % world != 0 and the left-over units fill the node exactly
+    once as S-way frame-sharded units, every rank carries floor(units / world) whole units + 1/S of one more.  Checks
+    the policy, that every frame granule of every unit has exactly one (rank, slot), that a rank's slots are the
+    consecutive ones pack_rows relies on, and the per-rank load (2.5 unit-times for the config-4 clip on 8 GPUs against
+    3 for any whole-unit schedule)."""
+    D = distributed
+    assert D.choose_mixed_shards(20, 8, 16, 64) == 2          # BASELINE configs[3]: 10 windows x 2 halves on 8 GPUs
+    assert D.choose_mixed_shards(10, 4, 8, 4) == 2 and D.choose_mixed_shards(10, 8, 8, 4) == 4
+    assert D.choose_mixed_shards(20, 4, 16, 64) == 1          # divides evenly: nothing to shard
+    assert D.choose_mixed_shards(2, 8, 16, 64) == 1           # fewer units than ranks: choose_frame_shards' case
+    assert D.choose_mixed_shards(22, 8, 16, 64) == 1          # 6 left-over units do not tile 8 ranks
+    assert D.choose_mixed_shards(20, 8, 15, 64) == 1 and D.choose_mixed_shards(20, 8, 16, 1) == 1   # S | f, S | hw
+    for W, R, S in ((10, 8, 2), (5, 4, 2), (5, 8, 4), (3, 4, 2)):
+        m = D.MixedUnitSchedule(W, R, S)
+        units = [(w, h) for w in range(W) for h in range(2)]
+        assert sorted(m.slots) == units and all(len(v) == S for v in m.slots.values())
+        seen = set()
+        for u, gl in m.slots.items():
+            for (r, s) in gl:
+                assert 0 <= r < R and 0 <= s < m.max_slots and (r, s) not in seen
+                seen.add((r, s))
+        assert len(seen) == R * m.max_slots                   # every slot of every rank is used: equal load
+        for r in range(R):
+            rows = [(w, h) for w, hs in m.whole_calls(r) for h in hs]
+            assert [m.slots[u] for u in rows] == [[(r, k * S + j) for j in range(S)] for k in range(len(rows))]
+            su = m.split_unit(r)
+            assert m.slots[su][r % S] == (r, len(rows) * S)   # this rank's granule of the shared unit: its last slot
+        assert m.rounds() == len(units) // R + 1.0 / S
+    assert D.MixedUnitSchedule(10, 8, 2).rounds() == 2.5
+    with pytest.raises(ValueError):
+        D.MixedUnitSchedule(10, 8, 4)

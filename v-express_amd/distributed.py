@@ -96,6 +96,56 @@ def choose_frame_shards(num_windows: int, world_size: int, window_frames: int, m
     return s
 
 
+def choose_mixed_shards(num_units: int, world_size: int, window_frames: int, min_hw: int) -> int:
+    """S in {2, 4} when the units left over after every rank got floor(units / world) whole ones fill the node exactly
+    once as S-way frame-sharded units (extra * S == world), else 1.  The config-4 clip: 20 units on 8 GPUs = 2 whole
+    units per rank + 4 units left over = one half-unit (8 of the window's 16 frames) per rank, i.e. 2.5 unit-times per
+    step on every rank instead of 3 on half of them (whole-unit schedules cannot do better than 20 / 3 = 6.67x)."""
+    if world_size < 2 or num_units < world_size:
+        return 1
+    extra = num_units % world_size
+    if extra == 0 or world_size % extra:
+        return 1
+    s = world_size // extra
+    if s not in (2, 4) or window_frames % s or min_hw % s:
+        return 1
+    return s
+
+
+class MixedUnitSchedule:
+    """Whole units first, the left-over units frame-sharded S ways (`choose_mixed_shards`); identical on every rank.
+    Exchange granule = 1/S of a unit (f / S frames): a whole unit fills S consecutive slots of its rank, a sharded unit
+    one slot on each of its S ranks; `slots[unit][j]` = (rank, slot) of the unit's j-th frame granule."""
+
+    def __init__(self, num_windows: int, world_size: int, shards: int, halves: int = 2):
+        units = [(w, h) for w in range(num_windows) for h in range(halves)]
+        base, extra = divmod(len(units), world_size)
+        if shards < 2 or extra * shards != world_size or base < 1:
+            raise ValueError(f"{len(units)} units on {world_size} ranks do not split into whole units + {shards}-way "
+                             "sharded left-overs")
+        self.num_windows, self.world_size, self.shards, self.halves = num_windows, world_size, shards, halves
+        self.granules = shards
+        self.whole = [units[r * base:(r + 1) * base] for r in range(world_size)]
+        self.split = units[base * world_size:]                  # unit i lives on ranks [i * S, (i + 1) * S)
+        self.max_slots = base * shards + 1
+        self.slots = {}
+        for r, us in enumerate(self.whole):
+            for k, u in enumerate(us):
+                self.slots[u] = [(r, k * shards + j) for j in range(shards)]
+        for i, u in enumerate(self.split):
+            self.slots[u] = [(i * shards + j, base * shards) for j in range(shards)]
+
+    def whole_calls(self, rank: int):
+        return group_calls(self.whole[rank])
+
+    def split_unit(self, rank: int):
+        return self.split[rank // self.shards]
+
+    def rounds(self) -> float:
+        """Unit-times on the critical path of one timestep."""
+        return len(self.whole[0]) + 1.0 / self.shards
+
+
 class UnitSchedule:
     """Static (window, cfg_half) -> (rank group, slot) map of one clip; identical on every rank.  With
     frame_shards = S > 1 the ranks form world/S groups of S consecutive ranks; a group owns units like a single rank

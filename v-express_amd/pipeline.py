@@ -23,7 +23,8 @@ import torch
 
 from . import ops
 from .context import get_context_scheduler, overlap_plan
-from .distributed import DistContext, UnitSchedule, choose_frame_shards, split_frames
+from .distributed import (DistContext, MixedUnitSchedule, UnitSchedule, choose_frame_shards, choose_mixed_shards,
+                          split_frames)
 from .mutual_self_attention import ReferenceAttentionControl
 
 
@@ -44,6 +45,9 @@ class VExpressPipeline:
         # ranks per (window, CFG-half) unit, each holding 1/S of the window's frames; None = automatic (S > 1 only
         # when the clip has fewer units than ranks, distributed.choose_frame_shards)
         self.frame_shards = None
+        # uneven clips (units % world != 0): frame-shard only the left-over units so that every rank carries the same
+        # load (distributed.MixedUnitSchedule); None = automatic, 1 = never (whole units only, round-2 behaviour)
+        self.mixed_shards = None
         # batch rows per UNet call: 2 = the two CFG halves of one window; 4 (default), 6, ... also merge consecutive
         # windows of this rank into one call.  Every kernel is batch-invariant, so the rows come out bit-identical;
         # merged calls measure 4-5 % faster (profiles/r02e_host_overhead.json: b = 3 74.0 ms vs 49.2 + 28.2 ms,
@@ -186,26 +190,42 @@ class VExpressPipeline:
         if kps_tokens.shape[0] != halves_n or audio.shape[0] != halves_n:
             raise ValueError(f"guidance_scale={guidance_scale} needs {halves_n} batch row(s) of kps features / audio "
                              f"embeddings, got {kps_tokens.shape[0]} / {audio.shape[0]}")
-        S = self.frame_shards or choose_frame_shards(nW, dc.world_size, f, (H // 8) * (W // 8), halves_n)
-        if S < 1 or dc.world_size % S or f % S or ((H // 8) * (W // 8)) % S:
+        min_hw = (H // 8) * (W // 8)
+        S = self.frame_shards or choose_frame_shards(nW, dc.world_size, f, min_hw, halves_n)
+        if S < 1 or dc.world_size % S or f % S or min_hw % S:
             raise ValueError(f"frame_shards={S} must divide the world size ({dc.world_size}), the window length ({f}) "
                              f"and the {H // 8}x{W // 8} tokens of the coarsest UNet level")
-        sched_u = UnitSchedule(nW, dc.world_size, S, halves_n)
-        my_calls, max_units = sched_u.calls(dc.rank), sched_u.max_units
-        shard = dc.frame_shard(S)
-        f_loc = f // S
-        lo = (dc.rank % S) * f_loc                     # this rank's frames of every window it works on: [lo, lo+f_loc)
-        my_slot = {u: sched_u.slot[u][1] for u in sched_u.slot}
+        # Three schedules, one exchange format.  G = frame granules per unit in the exchange buffer:
+        #   uniform, S = 1: every unit whole on one rank (G = 1);  uniform, S > 1: every unit on S ranks (G = S);
+        #   mixed: floor(units / world) whole units per rank + the left-over units sharded Sm ways (G = Sm): every rank
+        #   then carries the same load (the 20 units of the config-4 clip on 8 GPUs: 2 + 1/2 per rank instead of 3 | 2).
+        Sm = 1
+        if S == 1 and dc.enabled and self.mixed_shards != 1:
+            Sm = self.mixed_shards or choose_mixed_shards(nW * halves_n, dc.world_size, f, min_hw)
+        if Sm > 1:
+            sched_m = MixedUnitSchedule(nW, dc.world_size, Sm, halves_n)
+            G, max_slots, unit_slots = Sm, sched_m.max_slots, sched_m.slots
+            # (call groups, frame shards of these calls): this rank's whole units, then its share of one sharded unit
+            su = sched_m.split_unit(dc.rank)
+            plan_calls = [(sched_m.whole_calls(dc.rank), 1), ([(su[0], [su[1]])], Sm)]
+        else:
+            sched_u = UnitSchedule(nW, dc.world_size, S, halves_n)
+            G, max_slots = S, sched_u.max_units
+            unit_slots = {}
+            for u in sched_u.slot:
+                ranks, slot = sched_u.unit_ranks(u)
+                unit_slots[u] = [(r, slot) for r in ranks]
+            plan_calls = [(sched_u.calls(dc.rank), S)]
+        g_frames = f // G                              # frames per exchange granule
         # per-timestep exchange: only conv_out's C real channels travel (the GEMM pads them to 8); unit_index tells the
-        # combine kernel which gathered unit buffer holds frame shard j of (window, CFG half)
-        local = torch.zeros((max_units, f_loc * hw, C), device=dev, dtype=torch.float32)
+        # combine kernel which gathered slot holds frame granule j of (window, CFG half)
+        local = torch.zeros((max_slots, g_frames * hw, C), device=dev, dtype=torch.float32)
         preds = torch.empty((nW, C, f, hw), device=dev, dtype=torch.float32)
-        uidx = torch.empty((nW, halves_n, S), dtype=torch.int32)
+        uidx = torch.empty((nW, halves_n, G), dtype=torch.int32)
         for wi in range(nW):
             for hlf in range(halves_n):
-                ranks, slot = sched_u.unit_ranks((wi, hlf))
-                for j, r in enumerate(ranks):
-                    uidx[wi, hlf, j] = r * max_units + slot
+                for j, (r, slot) in enumerate(unit_slots[(wi, hlf)]):
+                    uidx[wi, hlf, j] = r * max_slots + slot
         uidx = uidx.to(dev)
         # per-call constants (window ids, conditioning slices) do not depend on the timestep: build them once so
         # the timestep loop issues kernels only (no host->device copies, no syncs)
@@ -215,42 +235,49 @@ class VExpressPipeline:
         # consecutive windows into one batch (every kernel is batch-invariant, so the rows come out identical - only
         # the launches get fatter, which helps the 16x16 / 8x8 levels of multi-window clips)
         limit = int(self.units_per_call)
-        merged, cur = [], []
-        for wi, halves in my_calls:
-            if cur and (limit <= 2 or sum(len(h) for _, h in cur) + len(halves) > limit):
-                merged.append(cur)
-                cur = []
-            cur.append((wi, halves))
-        if cur:
-            merged.append(cur)
         calls = []
-        for group in merged:
-            rows = [(wi, hlf) for wi, halves in group for hlf in halves]          # batch rows of the call, in order
-            kps_l, ehs_l = [], []
-            for wi, halves in group:
-                hsel = torch.tensor(halves, device=dev)
-                ids_long = win_ids_long[wi][lo:lo + f_loc]
-                kps_l.append(kps_tokens.index_select(0, hsel).index_select(1, ids_long)
-                             .reshape(len(halves) * f_loc, hw, -1))
-                e = audio.index_select(0, hsel).index_select(1, ids_long)
-                ehs_l.append(e.reshape(-1, e.shape[-1]))
-            kps = torch.cat(kps_l, dim=0).contiguous()
-            ehs = torch.cat(ehs_l, dim=0).contiguous()
-            gathers = [(win_ids[wi][lo:lo + f_loc].contiguous(), len(halves)) for wi, halves in group]
-            # the audio K | V of all 16 transformer blocks is step-invariant: once per clip and call
-            calls.append((rows, gathers, kps, ehs, unet.precompute_audio_kv(ehs)))
+        for my_calls, Sc in plan_calls:
+            shard = dc.frame_shard(Sc)                 # collective when it creates the groups: every rank gets here
+            f_loc = f // Sc
+            lo = (dc.rank % Sc) * f_loc                # this rank's frames of the windows of these calls: [lo, lo+f_loc)
+            merged, cur = [], []
+            for wi, halves in my_calls:
+                if cur and (limit <= 2 or sum(len(h) for _, h in cur) + len(halves) > limit):
+                    merged.append(cur)
+                    cur = []
+                cur.append((wi, halves))
+            if cur:
+                merged.append(cur)
+            for group in merged:
+                rows = [(wi, hlf) for wi, halves in group for hlf in halves]      # batch rows of the call, in order
+                kps_l, ehs_l = [], []
+                for wi, halves in group:
+                    hsel = torch.tensor(halves, device=dev)
+                    ids_long = win_ids_long[wi][lo:lo + f_loc]
+                    kps_l.append(kps_tokens.index_select(0, hsel).index_select(1, ids_long)
+                                 .reshape(len(halves) * f_loc, hw, -1))
+                    e = audio.index_select(0, hsel).index_select(1, ids_long)
+                    ehs_l.append(e.reshape(-1, e.shape[-1]))
+                kps = torch.cat(kps_l, dim=0).contiguous()
+                ehs = torch.cat(ehs_l, dim=0).contiguous()
+                gathers = [(win_ids[wi][lo:lo + f_loc].contiguous(), len(halves)) for wi, halves in group]
+                # send slots of the call: its units occupy consecutive slots in row order (a whole unit of a mixed
+                # schedule = G consecutive granules, a sharded unit this rank's one granule)
+                s0 = min(slot for (r, slot) in unit_slots[rows[0]] if r == dc.rank)
+                n_slots = len(rows) * (G // Sc)
+                # the audio K | V of all 16 transformer blocks is step-invariant: once per clip and call
+                calls.append((rows, gathers, kps, ehs, unet.precompute_audio_kv(ehs), f_loc, shard, s0, n_slots))
         for i, t in enumerate(timesteps):
             t = int(t)
-            for rows, gathers, kps, ehs, akv in calls:
+            for rows, gathers, kps, ehs, akv, f_loc, shard, s0, n_slots in calls:
                 parts = [ops.gather_latents(latents, ids, reps=reps) for ids, reps in gathers]
                 x_in = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
                 out = unet.forward_tokens(x_in, t, ehs, kps, b=len(rows), f=f_loc, H=H, W=W,
                                           batch_rows=[hlf for _, hlf in rows], audio_kv=akv,
                                           audio_zero=[audio_is_zero[hlf] for _, hlf in rows], frame_shard=shard)
                 # a call's units occupy consecutive send slots, in row order: one strided pack per call
-                s0 = my_slot[rows[0]]
-                ops.pack_rows(out, C, local[s0:s0 + len(rows)])
-            gathered = dc.all_gather_units(local, max_units)          # [world, max_units, (f/S)*hw, C]
+                ops.pack_rows(out, C, local[s0:s0 + n_slots])
+            gathered = dc.all_gather_units(local, max_slots)          # [world, max_slots, (f/G)*hw, C]
             # CFG combine of every window in one launch (:548-550; without CFG the prediction itself)
             ops.combine_units(gathered, uidx, C, f, hw, guidance_scale if do_cfg else 1.0, preds)
             ops.overlap_ddim_step(latents, preds, terms, frame_ids, counts, self.scheduler.step_coefficients(t))
