@@ -369,3 +369,46 @@ def test_bench_refuses_a_world_size_that_differs_from_gpus(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], cwd=root, env=env2,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr), r.stdout[-500:] + r.stderr[-500:]
+
+
+def test_float16_is_an_io_dtype_and_device_spellings_compare_equal(monkeypatch):
+    """Round-3 boundary items (reference inference.py:44,150-151: `--dtype fp16` is the default and every model gets
+    `.to(dtype=dtype, device=device)`): float16 is accepted as an I/O dtype with ONE warning per process, `.half()` too,
+    VX_STRICT_FP16=1 restores the NotImplementedError; 'cuda' and 'cuda:<current>' are the same device for `.to()`."""
+    import warnings
+    import v_express_amd as vx
+    from v_express_amd import module_base as MB
+    monkeypatch.setattr(MB, "_FP16_WARNED", [False])
+    cfgd = dict(block_out_channels=[64, 128, 256, 256], attention_head_dim=8, cross_attention_dim=768)
+    unet = vx.UNet3DConditionModel.from_config_2d(cfgd, dict(use_motion_module=True))
+    with pytest.warns(UserWarning, match="bfloat16"):
+        unet.to(dtype=torch.float16, device="cpu")
+    assert unet.dtype == torch.float16
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                    # the second request must stay silent
+        unet.half()
+        vx.UNet2DConditionModel.from_config(cfgd).to(torch.float16)
+    monkeypatch.setenv("VX_STRICT_FP16", "1")
+    with pytest.raises(NotImplementedError):
+        unet.to(torch.float16)
+    monkeypatch.delenv("VX_STRICT_FP16")
+    with pytest.raises(TypeError):
+        unet.to(torch.float64)
+    assert MB._norm_device("cuda") == MB._norm_device("cuda:0") == MB._norm_device(0) == torch.device("cuda", 0)
+    unet.to("cuda")
+    unet._released = True                                 # after release_raw_weights() a real move must fail ...
+    unet.to("cuda:0")                                     # ... the other spelling of the same GPU must not
+    with pytest.raises(RuntimeError):
+        unet.to("cpu")
+
+
+def test_bench_reads_the_rocprof_side_of_the_roofline_from_the_committed_trace():
+    """bench.py's `roofline.rocprof`: average launch duration of the dominant kernel from the newest committed
+    rocprofv3 kernel-trace summary (both the 3- and the 5-argument spellings of the kernel's template list)."""
+    import bench
+    r = bench._rocprof_launch_avg("gemm_ring_kernel<256x320x64,8w,STORE,fast>")
+    assert r is not None and r["file"].startswith("profiles/") and r["launches"] > 1000
+    assert 40.0 < r["avg_launch_us"] < 200.0
+    g = bench._rocprof_launch_avg("gemm_ring_kernel<256x320x64,8w,GEGLU,fast>")
+    assert g is not None and g["avg_launch_us"] > r["avg_launch_us"]
+    assert bench._rocprof_launch_avg("gemm_kernel<128x160x64,4w,STORE,fast>") is None
