@@ -412,3 +412,35 @@ def test_bench_reads_the_rocprof_side_of_the_roofline_from_the_committed_trace()
     g = bench._rocprof_launch_avg("gemm_ring_kernel<256x320x64,8w,GEGLU,fast>")
     assert g is not None and g["avg_launch_us"] > r["avg_launch_us"]
     assert bench._rocprof_launch_avg("gemm_kernel<128x160x64,4w,STORE,fast>") is None
+
+
+def test_gelu_tail_polynomial_of_the_kernels_matches_erf_gelu():
+    """vx_common.h::gelu_f (round 3): erf GELU as relu(x) - |x| 2^q(|x|) with q a degree-6 polynomial for the base-2
+    logarithm of the Gaussian tail.  The coefficients are parsed from the kernel header and evaluated here in float32
+    (Horner with fused multiply-adds emulated through float64) against x Phi(x) in float64: absolute error <= 1e-6 over
+    the whole line, relative error <= 1e-3 where |gelu| >= 1e-3 (a bf16 output rounds at 4e-3)."""
+    import re
+    import numpy as np
+    from scipy.special import erfc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "v-express_amd", "csrc", "vx_common.h")).read()
+    body = src[src.index("float gelu_f(float x) {"):src.index("// the Abramowitz-Stegun form")]
+    lead = re.search(r"float q = fmaf\(([-0-9.e+]+)f, u, ([-0-9.e+]+)f\);", body)
+    rest = re.findall(r"q = fmaf\(q, u, ([-0-9.e+]+)f\);", body)
+    coef = [np.float32(lead.group(1)), np.float32(lead.group(2))] + [np.float32(c) for c in rest]
+    assert len(coef) == 7 and "fmed3f(fabsf(x), 0.0f, 8.0f)" in body
+    x = np.concatenate([np.linspace(-12, 12, 200001), np.random.default_rng(0).standard_normal(100000) * 3,
+                        np.array([0.0, -0.0, 1e-8, -1e-8, 50.0, -50.0, 3e4, -3e4])]).astype(np.float32)
+    u = np.minimum(np.abs(x), np.float32(8.0))
+    q = np.full_like(u, coef[0])
+    for c in coef[1:]:
+        q = (q.astype(np.float64) * u + c).astype(np.float32)            # one rounding per FMA
+    got = (np.maximum(x, 0).astype(np.float64) - u.astype(np.float64) * np.exp2(q.astype(np.float64))).astype(np.float32)
+    ref = x.astype(np.float64) * 0.5 * erfc(-x.astype(np.float64) / np.sqrt(2.0))
+    err = np.abs(got - ref)
+    fin = np.abs(ref) < 1e3                                              # beyond: float32 ulp of the result itself
+    assert err[fin].max() <= 1e-6, err[fin].max()
+    big = (np.abs(ref) >= 1e-3) & fin
+    assert (err[big] / np.abs(ref[big])).max() <= 1e-3
+    far = np.abs(x) > 9                                                   # beyond the clamp: relu - 8 T(8) = relu - 5e-15
+    assert np.all(np.isfinite(got)) and np.abs(got[far] - np.maximum(x[far], 0)).max() <= 1e-13

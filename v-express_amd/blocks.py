@@ -73,10 +73,21 @@ def _self_attention(A, ln, h, *, seqs, n_tok, heads, fold=None, item_bias=None, 
     epilogue - the constant contributions of the blocks that follow for that item (see _spatial_transformer_read)."""
     m, c = ln.shape
     d = c // heads
-    q = torch.empty((m, c), device=ln.device, dtype=ops.BF16)
-    k = torch.empty((m, c), device=ln.device, dtype=ops.BF16)
     vt = ops.alloc_vt(seqs, heads, d, n_tok, ln.device)
-    if fold is not None:
+    qk_ring = fold is not None and ops.qk_on_ring(m, c)
+    if not qk_ring:
+        q = torch.empty((m, c), device=ln.device, dtype=ops.BF16)
+        k = torch.empty((m, c), device=ln.device, dtype=ops.BF16)
+    if qk_ring:
+        # Q | K as ONE [m, 2C] GEMM on the persistent ring kernel (q, k = column views of its output; the attention
+        # kernels take row strides), V^T alone through the SPLIT epilogue of the classic tiles: the fused 3C-wide SPLIT
+        # launch runs on the classic 256 x 320 tile at ~500 TFLOP/s at the 64x64 level, the ring kernel at ~700
+        F, stats = fold
+        qk = ops.gemm(ln, F.w[:2 * c], F.b[:2 * c], ln=(stats, F.s[:2 * c]))
+        q, k = qk[:, :c], qk[:, c:]
+        ops.gemm_split(ln, F.w[2 * c:], F.b[2 * c:], [("vt", vt)], part_cols=c, seq_len=n_tok, head_dim=d,
+                       ln=(stats, F.s[2 * c:]))
+    elif fold is not None:
         F, stats = fold
         ops.gemm_split(ln, F.w, F.b, [("rows", q), ("rows", k), ("vt", vt)], part_cols=c, seq_len=n_tok, head_dim=d,
                        ln=(stats, F.s))

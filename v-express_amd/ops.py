@@ -348,6 +348,20 @@ def _ring_hint(p):
     return 1 if (2 * rows_item // 256) * (p.n // 320) >= 192 else -1
 
 
+QK_RING = [os.environ.get("VX_QK_RING", "1") != "0"]
+
+
+def qk_on_ring(m, c):
+    """Whether the Q | K half of a fused, LayerNorm-folded QKV projection ([m, c] -> [m, 2c]) would run on the persistent
+    ring kernel (same batch-independent rule as `_ring_hint`): then blocks._self_attention issues it there and leaves
+    only V^T to the classic SPLIT epilogue."""
+    items = _ITEMS[0]
+    if not QK_RING[0] or items is None or items <= 0 or m % items or (2 * c) % 320 or c % 64:
+        return False
+    rows_item = m // items
+    return rows_item % 256 == 0 and (2 * rows_item // 256) * (2 * c // 320) >= 192 and _lib.vx_gemm_get_ring_mode() != 0
+
+
 def _splitk(p, geom, device, plain):
     """Split-K factor for the 8x8-level problems (M = frames * 64 rows: half the CUs idle otherwise).  A function of
     the per-frame geometry, N and K only - never of the number of frames - so a CFG half or a window computed alone
