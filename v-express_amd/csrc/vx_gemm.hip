@@ -708,7 +708,12 @@ bool use_small64(const vx_gemm_params& p) {
   }
   if (!on || !prefer160(p.n) || p.out_f32) return false;
   const long tiles128 = (long)ceil_div(p.m, 128) * ceil_div(p.n, 160) * (p.splitk > 1 ? p.splitk : 1);
-  return tiles128 < 256 && fast_ok(p);
+  static long lim = -1;   // VX_GEMM_SMALL64_BELOW (A/B knob): the 64-row tile is used while the 128-row tiling has fewer blocks
+  if (lim < 0) {
+    const char* e = getenv("VX_GEMM_SMALL64_BELOW");
+    lim = e ? atol(e) : 256;
+  }
+  return tiles128 < lim && fast_ok(p);
 }
 
 }  // namespace
