@@ -244,7 +244,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
                                                               const float* __restrict__ beta, int silu,
                                                               bf16_t* __restrict__ out, int slices, int slice_pix,
                                                               const float* __restrict__ ws, int width, int w_shift,
-                                                              int out_pad) {
+                                                              int out_pad, int stat_slices) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int C = c1 + c2;
   const int frame = blockIdx.x / slices, slice = blockIdx.x % slices;
@@ -254,7 +254,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
   float* gstat = shift + C;                        // [groups][2] mean, rstd
   double* dpart = reinterpret_cast<double*>(gstat + 2 * groups);   // [GN_SUBS][groups][2]
   const int cg = C / groups;
-  gn_group_stats(ws, frame, slices, groups, cg, hw, eps, gstat, dpart);
+  // `slices` partitions THIS kernel's work; the statistics were written as `stat_slices` partial sums per frame
+  gn_group_stats(ws, frame, stat_slices, groups, cg, hw, eps, gstat, dpart);
   for (int ch = tid; ch < C; ch += GN_THREADS) {
     int g = ch / cg;
     float sc = gamma[ch] * gstat[g * 2 + 1];
@@ -620,9 +621,20 @@ extern "C" int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int 
                      (const bf16_t*)x1, c1, (const bf16_t*)x2, c2, hw, groups, slices, slice_pix, ws);
   int rc = vx_check_launch("vx_groupnorm(stats)");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(frames * slices), dim3(GN_THREADS), smem_apply, stream,
+  // The apply pass may cut a frame into fewer, larger pieces than the statistics pass: every block re-reduces the
+  // frame's partial sums before it streams (a fixed ~2 us prologue), so 64 blocks of 64 pixels per frame pay it 64 times.
+  // VX_GN_APPLY_SLICES (A/B knob): upper bound on the apply pass's pieces per frame; element-wise pass, same bits.
+  static int amax = -1;
+  if (amax < 0) {
+    const char* e = getenv("VX_GN_APPLY_SLICES");
+    amax = e ? atoi(e) : 64;
+    if (amax < 1) amax = 1;
+  }
+  const int aslices = slices < amax ? slices : amax;
+  const int apix = ceil_div(hw, aslices);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(frames * aslices), dim3(GN_THREADS), smem_apply, stream,
                      (const bf16_t*)x1, c1, (const bf16_t*)x2, c2, hw, groups, eps, gamma, beta, silu,
-                     (bf16_t*)out, slices, slice_pix, (const float*)ws, width, w_shift, out_pad);
+                     (bf16_t*)out, aslices, apix, (const float*)ws, width, w_shift, out_pad, slices);
   return vx_check_launch("vx_groupnorm(apply)");
 }
 
