@@ -444,3 +444,30 @@ def test_gelu_tail_polynomial_of_the_kernels_matches_erf_gelu():
     assert (err[big] / np.abs(ref[big])).max() <= 1e-3
     far = np.abs(x) > 9                                                   # beyond the clamp: relu - 8 T(8) = relu - 5e-15
     assert np.all(np.isfinite(got)) and np.abs(got[far] - np.maximum(x[far], 0)).max() <= 1e-13
+
+
+def test_kernel_routing_decisions_do_not_depend_on_the_batch():
+    """The host-side routing rules of round 3 (`ops.gn_fold_applies`: GroupNorm folded into proj_in; `ops.qk_on_ring`:
+    Q | K on the ring kernel) decide from ONE batch item's rows, like `_ring_hint`: a CFG half computed alone on another
+    GPU must take the same kernels as its rows inside the batched call (bit-identity of the sharded loop).  Also pins
+    where they apply: the 64x64 / 96x96 levels for the fold (per-frame weight copies smaller than the tensor), the
+    64x64 ... 16x16 levels for Q | K."""
+    from v_express_amd import ops
+    f = 16
+    for hw, c in ((4096, 320), (1024, 640), (256, 1280), (64, 1280), (9216, 320), (2304, 640)):
+        got = []
+        for b in (1, 2, 4):
+            with ops.frame_rows(hw, items=b):
+                got.append((ops.gn_fold_applies(b * f * hw, hw, c, c), ops.qk_on_ring(b * f * hw, c)))
+        assert got[0] == got[1] == got[2], (hw, c, got)
+    with ops.frame_rows(4096, items=2):
+        assert ops.gn_fold_applies(2 * f * 4096, 4096, 320, 320) and ops.qk_on_ring(2 * f * 4096, 320)
+    with ops.frame_rows(1024, items=2):
+        assert not ops.gn_fold_applies(2 * f * 1024, 1024, 640, 640) and ops.qk_on_ring(2 * f * 1024, 640)
+    with ops.frame_rows(2304, items=2):                                       # 768x768: 48x48 level, C = 640
+        assert ops.gn_fold_applies(2 * f * 2304, 2304, 640, 640)
+    with ops.frame_rows(64, items=2):
+        assert not ops.gn_fold_applies(2 * f * 64, 64, 1280, 1280) and not ops.qk_on_ring(2 * f * 64, 1280)
+    assert not ops.gn_fold_applies(2 * f * 4096, 4096, 320, 320)              # outside a frame_rows context: never
+    with ops.frame_rows(4096, items=2):                                       # a frame-sharded half window (f = 8)
+        assert ops.gn_fold_applies(2 * 8 * 4096, 4096, 320, 320)
