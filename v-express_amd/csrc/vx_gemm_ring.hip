@@ -522,8 +522,8 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
       // gives every lane 8 consecutive columns of one fragment: [x0..x3 y0..y3] = fragment j + (lq & 1), columns
       // 8 (lq >> 1) .. + 7 -> 16-byte residual loads / output stores for fragments 0-3; fragment 4 keeps the native
       // 4 columns per lane (8 bytes).  Items are walked row-block-major (i, then {01, 23, 4}) so that a wave finishes
-      // the 160 contiguous bytes of an output row within one step (partial lines meet in L2 right away), the lane's
-      // 20 bias values (+ the tile's time-embedding row) are loaded once per tile, and the residual loads run
+      // the 160 contiguous bytes of an output row within one step (partial lines meet in L2 right away); bias and the
+      // tile's time-embedding / per-item row are already in the accumulators (pass above), and the residual loads run
       // RES_DEPTH items ahead of their use: the epilogue of a short-K tile is a string of HBM round trips otherwise.
       constexpr int N_ITEMS = 24, RES_DEPTH = LNF ? 4 : VX_RING_RES_DEPTH;   // (LNF + RES: unused by the model, keep it spill-free)
       const int col_p = tile_n * R_BN + 80 * wc + 8 * (lq >> 1) + 16 * (lq & 1);   // + 32 t  (pair t = 0, 1)
