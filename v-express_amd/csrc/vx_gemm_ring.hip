@@ -632,7 +632,9 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
         }
       }
       if constexpr (STATS) {
-        // the four wave columns of a row meet in LDS (fixed order -> deterministic); rows 0..255 of the tile = tid
+        // the four wave columns of a row meet in LDS (fixed order -> deterministic); rows 0..255 of the tile = tid.
+        // ring_barrier() is a bare s_barrier (no fence): the partial sums must have LEFT this wave's LDS queue first
+        ring_wait_lgkm0();
         ring_barrier();
         if (tid < R_BM) {
           const float4 p01 = *reinterpret_cast<const float4*>(smem + STATS_OFF + tid * 32);
