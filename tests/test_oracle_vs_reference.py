@@ -1,6 +1,8 @@
 """Tier A == Tier B, live: the reference's own modules (imported unmodified) against oracle/ on fresh seeds.
 Dev container only (skips where /root/reference is absent).  Also pins the synthetic state_dict schema
 to the reference's own `state_dict()` keys/shapes."""
+import os
+
 import torch
 
 import cases
@@ -109,3 +111,32 @@ def test_audio_windows_and_median_against_live_reference(reference):
     want = VExpressPipeline.prepare_audio_embeddings(stub, torch.zeros(1, 16), F_, pad, False)[0]
     got = OP.audio_windows(inp["wav2vec_states"], F_, pad)
     assert torch.equal(got, want)
+
+
+def test_context_scheduler_own_formulation_equals_the_reference_for_all_parameters(reference):
+    """v_express_amd.context.uniform (round 3: an own formulation - dilation levels, radical-inverse offset, reflection -
+    instead of a transcription) against /root/reference/pipelines/context.py:22-60 for every combination of clip length,
+    window size, overlap, stride, closed_loop and step on a grid that covers one-window clips, exact multiples, reflected
+    last windows and the multi-level (context_stride > 1) schedules the pipeline itself never asks for."""
+    import importlib.util
+    import ref_import
+    from v_express_amd import context as C
+    spec = importlib.util.spec_from_file_location("ref_context", os.path.join(ref_import.REFERENCE_ROOT, "pipelines", "context.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    n = 0
+    for F in list(range(1, 40)) + [64, 124, 128, 200]:
+        for size in (4, 8, 16, 24):
+            for ov in (0, 2, 4):
+                if ov >= size:
+                    continue
+                for stride in (1, 2, 3):
+                    for closed in (False, True):
+                        for step in (0, 1, 2, 3, 5, 8):
+                            a = list(m.uniform(step, F, size, stride, ov, closed))
+                            b = list(C.uniform(step, F, size, stride, ov, closed))
+                            assert a == b, (F, size, ov, stride, closed, step)
+                            n += 1
+    assert n > 10000
+    for v in (0, 1, 2, 3, 6, 255, 2 ** 40 + 7):
+        assert C.radical_inverse_base2(v) == m.ordered_halving(v)
