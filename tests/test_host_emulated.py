@@ -70,6 +70,49 @@ def test_unet_forward_host_composition_vs_reference_golden(emulated, name):
     assert not torch.equal(got8, got) and r8 <= 6e-2 and c8 >= 0.998, (r8, c8)
 
 
+def test_round3_fused_paths_host_composition_vs_reference_golden(emulated, monkeypatch):
+    """The host code of the round-3 fusions, forced on at a size where the routing rules would not pick them
+    (`ops.gn_fold_applies`, `ops.qk_on_ring` want the 64x64-level launch sizes): GroupNorm folded into proj_in through
+    per-frame weights, Q | K as one GEMM with column views + V^T alone, LayerNorm statistics taken from the producing
+    GEMM (`stats_out`), the unconditional half's constant terms as a per-item row bias.  Same reference golden, same
+    bound as the default composition, and both compositions within bf16 rounding of each other."""
+    import v_express_amd as vx
+    from v_express_amd import ops, synth
+    name = "small_f4_8x8"
+    kw, F, h, w, t = cases.FORWARD_CASES[name]
+    cfg = cases.unet_cfg(kw)
+    unet, refnet = vx.UNet3DConditionModel(cfg).to("cpu"), vx.UNet2DConditionModel(cfg).to("cpu")
+    unet.load_state_dict(synth.unet3d_state_dict(cfg), strict=True)
+    refnet.load_state_dict(synth.refnet_state_dict(cfg), strict=True)
+    inp = synth.synthetic_inputs(cfg, F, h, w)
+    writer = vx.ReferenceAttentionControl(refnet, do_classifier_free_guidance=True, mode="write", fusion_blocks="full")
+    reader = vx.ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", fusion_blocks="full",
+                                          reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD)
+    refnet(inp["ref_latents"], timestep=0, encoder_hidden_states=torch.zeros(1, 1, 768), return_dict=False)
+    reader.update(writer, True)
+    x = inp["latents"].repeat(2, 1, 1, 1, 1)
+    ehs = inp["audio_embeddings"].reshape(-1, 5, 768)
+    gold = torch.load(os.path.join(GOLD, f"forward_{name}.pt"), weights_only=False)["pred"]
+    base = unet(x, t, encoder_hidden_states=ehs, kps_features=inp["kps_features"], return_dict=False)[0]
+    used = {"fold": 0, "qk": 0}
+
+    def fold_everywhere(m, hw, c, n):
+        used["fold"] += 1
+        return True
+
+    def qk_everywhere(m, c):
+        used["qk"] += 1
+        return True
+    monkeypatch.setattr(ops, "gn_fold_applies", fold_everywhere)
+    monkeypatch.setattr(ops, "qk_on_ring", qk_everywhere)
+    fused = unet(x, t, encoder_hidden_states=ehs, kps_features=inp["kps_features"], return_dict=False)[0]
+    assert used["fold"] == 16 + 21 and used["qk"] == 16          # every spatial + motion proj_in, every spatial qkv
+    print(f"[round-3 fused composition] vs golden {rel_l2(fused, gold):.4g} (default {rel_l2(base, gold):.4g}), "
+          f"fused vs default {rel_l2(fused, base):.4g}")
+    assert rel_l2(fused, gold) <= 3e-2 and rel_l2(base, gold) <= 3e-2
+    assert not torch.equal(fused, base) and rel_l2(fused, base) <= 2e-2
+
+
 @pytest.mark.parametrize("name", ["aligned_F10_c4o2", "reflected_F11_c4o2", cases.NOCFG_CASE[0]])
 def test_denoising_loop_and_decode_host_composition_vs_reference_golden(emulated, name):
     import v_express_amd as vx
