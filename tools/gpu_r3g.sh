@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 3, GPU call G: the round's total on ONE box - round-2 HEAD (2aec0e9, materialised in tools/r02_tree) against this
-# HEAD, interleaved, default bench configuration (BASELINE configs[1])
+# HEAD, interleaved, default bench configuration (BASELINE configs[1]).  The tree is not kept: recreate it with
+#   mkdir -p tools/r02_tree && git archive 2aec0e9 | tar -x -C tools/r02_tree --exclude=tests/golden --exclude=profiles
+#   make -C tools/r02_tree/v-express_amd/csrc -j8
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
