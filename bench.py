@@ -333,7 +333,7 @@ def main():
     from v_express_amd.distributed import choose_frame_shards, choose_mixed_shards
     fshards = pipe.frame_shards or choose_frame_shards(len(windows), world, ctx, (args.size // 64) ** 2)
     mshards = 1
-    if fshards == 1 and world > 1 and pipe.mixed_shards != 1:
+    if fshards == 1 and world > 1 and pipe.mixed_shards != 1 and not (pipe.frame_shards == 1 and pipe.mixed_shards is None):
         mshards = pipe.mixed_shards or choose_mixed_shards(2 * len(windows), world, ctx, (args.size // 64) ** 2)
 
     result = {

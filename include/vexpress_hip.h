@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 9
+#define VX_ABI_VERSION 10
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
@@ -112,9 +112,25 @@ typedef struct {
    * copy per frame, modules/transformer_3d.py:124-126, modules/motion_module.py:156-158).  Only the persistent 256 x 320
    * kernel implements it: w_group_rows % 256 == 0 and every other ring condition must hold, else VX_ERR_UNSUPPORTED. */
   int32_t w_group_rows;
+  /* GroupNorm partial sums of the OUTPUT (round 4; STORE epilogue into bf16): gn_ws != NULL -> the epilogue adds up the
+   * stored bf16 values per (frame, row slab, group) and writes (sum, sum of squares) into gn_ws in the workspace layout
+   * vx_groupnorm's own statistics pass produces, [frame][slab][group][2] float32 with vx_gemm_gn_slabs(p) slabs per frame
+   * (one slab = the rows one wave row of the launch's tile owns: 128 for the persistent 256 x 320 kernel, 64 for the
+   * classic tiles).  The GroupNorm that reads this tensor next (modules/resnet.py:220-221,235-241: norm2 reads conv1's
+   * output; modules/transformer_3d.py:124 and modules/motion_module.py:156 read the previous block's) then runs its apply
+   * pass only (vx_groupnorm_apply) or folds into its linear layer (vx_groupnorm_fold_linear) without ever re-reading the
+   * tensor for statistics.  gn_groups = group count of that GroupNorm over this tensor's n channels, gn_hw = output rows
+   * per frame.  A launch that cannot produce them (vx_gemm_gn_slabs(p) == 0: split-K, fp32 output, groups straddling
+   * wave columns, ...) is rejected with VX_ERR_UNSUPPORTED - ask first.  Deterministic and batch-invariant (fixed
+   * summation order per slab). */
+  float* gn_ws;
+  int32_t gn_groups, gn_hw;
 } vx_gemm_params;
 
 int vx_gemm(const vx_gemm_params* p, void* stream);
+/* slabs per frame that vx_gemm(p) writes into p->gn_ws (p->gn_groups / gn_hw set), or 0 when the launch p would get
+ * cannot produce GroupNorm partial sums (the caller then leaves gn_ws NULL and runs vx_groupnorm as before) */
+int vx_gemm_gn_slabs(const vx_gemm_params* p);
 int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk);
 /* Kernel-selection knob (process-wide; default 2, or the VX_GEMM_RING environment variable): 0 = never use the
  * persistent ring-staged 256x320 kernel, 1 = only for K <= 1280, 2 = for every eligible problem.  Results differ only by
@@ -152,6 +168,12 @@ int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int frames, int
  * vx_gemm_params.w_group_rows = hw and rowbias = bias_out, and the normalised tensor is never written or re-read. */
 int vx_groupnorm_stats(const void* x1, int c1, const void* x2, int c2, int frames, int hw, int groups, float* ws,
                        int slices, void* stream);
+/* the apply pass of vx_groupnorm alone, over statistics that already sit in ws as `stat_slices` partial sums per frame
+ * (written by vx_groupnorm_stats, or by the GEMM that produced x1: vx_gemm_params.gn_ws / vx_gemm_gn_slabs).  `slices` =
+ * pieces per frame of THIS pass (element-wise: any value gives the same bits). */
+int vx_groupnorm_apply(const void* x1, int c1, const void* x2, int c2, int frames, int hw, int groups, float eps,
+                       const float* gamma, const float* beta, int silu, void* out, const float* ws, int stat_slices,
+                       int slices, int width, int out_pad, void* stream);
 int vx_groupnorm_fold_linear(const float* ws, int frames, int hw, int slices, int groups, float eps, const float* gamma,
                              int c, const void* w, const float* bias_beta, int n, void* w_out, float* bias_out,
                              void* stream);

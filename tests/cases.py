@@ -30,6 +30,10 @@ NOCFG_CASE = ("nocfg_F10_c4o2", 10, 4, 2, 3)          # name, F, context_frames,
 # BASELINE.json configs[1] through the reference itself (make_golden.py fullsize): F, ctx frames, overlap, steps
 FULLSIZE_CASE = (16, 16, 4, 25)
 FULLSIZE_FRAMES = (0, 15)                             # decoded 512x512 frames kept in the golden file
+# the sliding-window path at the benchmarked geometry (make_golden.py fullsize_F28): two overlapping 16-frame windows
+FULLSIZE_F28_CASE = (28, 16, 4, 2)
+# BASELINE configs[4]'s geometry (768x768 = 96x96 latents) through the reference (make_golden.py fullsize_768)
+FULLSIZE_768_CASE = (4, 4, 2, 2)
 
 
 def cond_only(inp):

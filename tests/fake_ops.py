@@ -21,8 +21,19 @@ def wave_conv1d(wave, wt, stride):
     return (wave.double().unfold(0, taps, stride) @ wt.double()).to(BF16)
 
 
+def _gn_ws(x, frames, hw, groups):
+    """Emulated workspace: (mean, variance) per (frame, group) in float64 - opaque to the host code."""
+    xg = x.double().reshape(frames, hw, groups, -1)
+    return torch.stack([xg.mean(dim=(1, 3)), xg.var(dim=(1, 3), unbiased=False)], dim=-1)      # [frames, groups, 2]
+
+
 def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=None, pad_hw=None):
     from v_express_amd import ops as real_ops
+    st = real_ops.gn_of(x1) if x2 is None else None
+    if st is not None:
+        # statistics the producing GEMM attached (vx_gemm_params.gn_ws): they must describe THIS tensor as it is now
+        assert st.fits(frames, hw, groups, x1.shape[-1]), "stale GroupNorm statistics: geometry"
+        assert torch.equal(st.ws, _gn_ws(x1, frames, hw, groups)), "stale GroupNorm statistics: values"
     x = x1.double().view(frames, hw, -1)
     if x2 is not None:
         x = torch.cat([x, x2.double().view(frames, hw, -1)], dim=-1)
@@ -43,16 +54,18 @@ def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=No
 
 
 def groupnorm_stats(x1, *, frames, hw, groups, x2=None):
-    """Emulated workspace: (mean, rstd-less variance) per (frame, group) in float64 - opaque to the host code."""
+    from v_express_amd import ops as real_ops
+    st = real_ops.gn_of(x1) if x2 is None else None
+    if st is not None and st.fits(frames, hw, groups, x1.shape[-1]):
+        assert torch.equal(st.ws, _gn_ws(x1, frames, hw, groups)), "stale GroupNorm statistics: values"
+        return st.ws, st.slabs
     x = x1.double().view(frames, hw, -1)
     if x2 is not None:
         x = torch.cat([x, x2.double().view(frames, hw, -1)], dim=-1)
-    c = x.shape[-1]
-    xg = x.view(frames, hw, groups, c // groups)
-    return torch.stack([xg.mean(dim=(1, 3)), xg.var(dim=(1, 3), unbiased=False)], dim=-1)      # [frames, groups, 2]
+    return _gn_ws(x, frames, hw, groups), 1
 
 
-def groupnorm_fold_linear(ws, gamma, w, bias_beta, *, frames, hw, groups, eps):
+def groupnorm_fold_linear(ws, gamma, w, bias_beta, *, frames, hw, groups, eps, slices=None):
     n, c = w.shape
     mean = ws[..., 0].repeat_interleave(c // groups, dim=1)                                    # [frames, c]
     rstd = torch.rsqrt(ws[..., 1] + eps).repeat_interleave(c // groups, dim=1)
@@ -151,7 +164,7 @@ def _conv_rows(a, a2, w, geom):
 
 
 def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=0, rowbias=None, rows_per_group=0,
-         out=None, out_f32=False, ln=None, stats_out=None, stats_eps=1e-5, w_group_rows=0):
+         out=None, out_f32=False, ln=None, stats_out=None, stats_eps=1e-5, w_group_rows=0, gn=None):
     if w_group_rows:                                   # per-row-group weights [groups, N, K] (vx_gemm_params.w_group_rows)
         assert geom is None and a2 is None and w.dim() == 3 and w.is_contiguous() and a.dtype == BF16
         assert a.shape[0] == w.shape[0] * w_group_rows
@@ -190,7 +203,15 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=0
     if out is not None:
         assert out.shape[-1] == y.shape[-1] and out.stride(-1) == 1
         out.reshape(y.shape).copy_(y) if out.is_contiguous() else out.copy_(y)
-        return out
+        y = out
+    if gn is not None and not out_f32 and not _is_fp8(a):
+        # GroupNorm partial sums of the STORED values ride on the tensor object (vx_gemm_params.gn_ws); the emulation
+        # produces them whenever asked (the kernels only where vx_gemm_gn_slabs allows), one slab per frame
+        from v_express_amd import ops as real_ops
+        groups, hw = gn
+        if real_ops.GN_FUSED[0] and y.shape[0] % hw == 0 and y.shape[1] % groups == 0:
+            frames = y.shape[0] // hw
+            y._vx_gn = real_ops.GnStats(_gn_ws(y, frames, hw, groups), 1, groups, frames, hw, y.shape[1])
     return y
 
 

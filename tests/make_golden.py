@@ -141,6 +141,72 @@ def fullsize(out):
     print("fullsize", {k: (tuple(v.shape) if hasattr(v, "shape") else v) for k, v in g.items()})
 
 
+def fullsize_F28(out):
+    """The sliding-window / merged-call path at the BENCHMARKED geometry (BASELINE.json configs[2] shape, shortened):
+    the reference's own `VExpressPipeline.__call__` (pipelines/v_express_pipeline.py:526-589) at SD-1.5 widths, 64x64
+    latents (512x512), F = 28 with context 16 / overlap 4 -> two windows [0..15], [12..27] sharing four frames, CFG 3.5,
+    2 DDIM steps (4 CFG forwards of 16 frames, ~6 min on 8 cores).  Stores every window's first prediction (fp16) and
+    the latents after each step (fp32): what the b = 4 merged UNet call and the overlap averaging at 64x64 latents are
+    compared with on the GPU (tests/test_gpu_fullsize.py)."""
+    import time
+    cfg = cases.unet_cfg(cases.FULL)
+    unet, refnet = H.build_reference_unets(cfg)
+    vae = H.build_reference_vae(synth.VaeConfig(**cases.SMALL_VAE))     # only its scale factor (8) is used: no decode
+    F, cf, co, steps = cases.FULLSIZE_F28_CASE
+    inp = synth.synthetic_inputs(cfg, F, 64, 64)
+    orig = unet.forward
+    preds = []
+
+    def spy(*a, **k):
+        o = orig(*a, **k)
+        preds.append((o[0] if isinstance(o, tuple) else o.sample).clone())
+        print(f"unet call {len(preds)} done", flush=True)
+        return o
+    unet.forward = spy
+    t0 = time.time()
+    _, trace = H.reference_pipeline_run(unet, refnet, vae, inp, F, steps, cases.GUIDANCE, cf, co, cases.W_REF,
+                                        cases.W_AUD, 512, 512, decode=False)
+    from pipelines.context import uniform
+    wins = list(uniform(step=0, num_frames=F, context_size=cf, context_stride=1, context_overlap=co,
+                        closed_loop=False))
+    per_step = len(preds) // steps
+    first = torch.cat(preds[:per_step], dim=0)           # step 0: [n_windows * 2, 4, 16, 64, 64] in call order
+    g = dict(windows=wins, pred_step0_f16=first.to(torch.float16), calls_per_step=per_step,
+             pred_shapes=[tuple(p.shape) for p in preds[:per_step]],
+             latents_step0=trace[0].clone(), latents=trace[-1].clone(), loop_seconds=time.time() - t0,
+             threads=torch.get_num_threads())
+    torch.save(g, os.path.join(out, "fullsize_F28_512.pt"))
+    print("fullsize_F28", {k: (tuple(v.shape) if hasattr(v, "shape") else v) for k, v in g.items()})
+
+
+def fullsize_768(out):
+    """BASELINE.json configs[4]'s geometry through the reference ITSELF: SD-1.5 widths, 96x96 latents (768x768), one
+    4-frame window, CFG 3.5, 2 DDIM steps of `VExpressPipeline.__call__` (pipelines/v_express_pipeline.py:526-589) -
+    2 CFG forwards of 4 frames (~6 min on 8 cores).  Stores the first prediction (fp16) and the latents after each step."""
+    import time
+    cfg = cases.unet_cfg(cases.FULL)
+    unet, refnet = H.build_reference_unets(cfg)
+    vae = H.build_reference_vae(synth.VaeConfig(**cases.SMALL_VAE))     # only its scale factor (8) is used: no decode
+    F, cf, co, steps = cases.FULLSIZE_768_CASE
+    inp = synth.synthetic_inputs(cfg, F, 96, 96)
+    orig = unet.forward
+    preds = []
+
+    def spy(*a, **k):
+        o = orig(*a, **k)
+        preds.append((o[0] if isinstance(o, tuple) else o.sample).clone())
+        print(f"unet call {len(preds)} done", flush=True)
+        return o
+    unet.forward = spy
+    t0 = time.time()
+    _, trace = H.reference_pipeline_run(unet, refnet, vae, inp, F, steps, cases.GUIDANCE, cf, co, cases.W_REF,
+                                        cases.W_AUD, 768, 768, decode=False)
+    g = dict(pred_step0_f16=preds[0].to(torch.float16), latents_step0=trace[0].clone(), latents=trace[-1].clone(),
+             loop_seconds=time.time() - t0, threads=torch.get_num_threads())
+    torch.save(g, os.path.join(out, "fullsize_768_F4.pt"))
+    print("fullsize_768", {k: (tuple(v.shape) if hasattr(v, "shape") else v) for k, v in g.items()})
+
+
 def main():
     torch.set_num_threads(os.cpu_count())
     out = os.path.join(HERE, "golden")
@@ -153,6 +219,10 @@ def main():
         return nocfg(out)
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":      # ~40 min; not part of the default regeneration
         return fullsize(out)
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize_F28":  # ~6 min; not part of the default regeneration
+        return fullsize_F28(out)
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize_768":  # ~6 min; not part of the default regeneration
+        return fullsize_768(out)
     prologue(out)
     wav2vec2(out)
     built = {}

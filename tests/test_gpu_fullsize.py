@@ -185,3 +185,106 @@ def test_fullsize_vae_decode_512_vs_reference_golden(full):
     print(f"[fullsize VAE decode 512x512] PSNR={p:.1f} dB, MAE={mae:.4g}")
     assert video.shape == (1, 3, len(frames), 512, 512)
     assert p >= 35.0 and mae <= 1e-2, (p, mae)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The sliding-window / merged-call path at the BENCHMARKED geometry (BASELINE.json configs[2] / [3] report it):
+# tests/golden/fullsize_F28_512.pt = the reference's own `VExpressPipeline.__call__` at SD-1.5 widths, 64x64 latents,
+# F = 28, context 16 / overlap 4 (windows [0..15] and [12..27], four frames averaged), CFG 3.5, 2 DDIM steps.
+GOLD_F28 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_F28_512.pt")
+F28_BOUNDS = (1.5e-2, 3e-2)        # relative L2 of the latents after step 1 / step 2 (two LARGE steps: t = 999, 499)
+
+
+def _run_f28(pipe, inp, units_per_call, spy=None):
+    F, cf, co, steps = cases.FULLSIZE_F28_CASE
+    unet = pipe.denoising_unet
+    saved_upc, saved_fwd = pipe.units_per_call, unet.forward_tokens
+    trace = {}
+    if spy is not None:
+        def wrapped(*a, **k):
+            o = saved_fwd(*a, **k)
+            spy.append((k["b"], o.detach().clone()))
+            return o
+        unet.forward_tokens = wrapped
+    pipe.units_per_call = units_per_call
+    try:
+        lat = pipe(None, None, None, 512, 512, F, steps, cases.GUIDANCE, context_frames=cf, context_overlap=co,
+                   reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD,
+                   reference_latents=inp["ref_latents"], kps_features=inp["kps_features"],
+                   audio_embeddings=inp["audio_embeddings"], latents=inp["latents"], decode=False,
+                   callback=lambda i, t, l: trace.__setitem__(i, l.detach().clone()))
+    finally:
+        pipe.units_per_call = saved_upc
+        unet.forward_tokens = saved_fwd
+    return lat, trace
+
+
+def test_fullsize_two_overlapping_windows_one_merged_call_vs_reference_golden(full):
+    """b = 4 UNet calls (both CFG halves of both windows in ONE launch sequence: M = 262 144 rows at the 64x64 level) and
+    the overlap averaging of frames 12-15 at 64x64 latents: every window's first prediction and the latents after each of
+    the two steps against the reference's own run; then the same clip with units_per_call = 2 (one call per window) must
+    give the same BITS (the kernels are batch-invariant).  pipelines/v_express_pipeline.py:526-589."""
+    if not os.path.exists(GOLD_F28):
+        pytest.fail("tests/golden/fullsize_F28_512.pt is missing (python tests/make_golden.py fullsize_F28)")
+    from v_express_amd import synth
+    pipe, cfg = full["pipe"], full["cfg"]
+    g = torch.load(GOLD_F28, weights_only=False)
+    F, cf, co, steps = cases.FULLSIZE_F28_CASE
+    inp = synth.synthetic_inputs(cfg, F, 64, 64)
+    calls = []
+    lat4, trace4 = _run_f28(pipe, inp, 4, spy=calls)
+    assert [b for b, _ in calls] == [4] * steps, [b for b, _ in calls]            # one merged call per step
+    first = calls[0][1].view(4, 16, 64 * 64, -1)[..., :4].permute(0, 3, 1, 2).reshape(4, 4, 16, 64, 64)
+    want = g["pred_step0_f16"].float()
+    for wi in range(2):                      # rows: (window 0: uncond, cond), (window 1: uncond, cond) - the reference's order
+        r, c = rel_l2(first[2 * wi:2 * wi + 2], want[2 * wi:2 * wi + 2]), cosine(first[2 * wi:2 * wi + 2], want[2 * wi:2 * wi + 2])
+        print(f"[F28 merged call] window {wi} first prediction: relL2={r:.4g} cosine={c:.6f}")
+        assert r <= 3e-2 and c >= 0.999, (wi, r, c)
+    for i, key in ((0, "latents_step0"), (1, "latents")):
+        r, rn = rel_l2(trace4[i], g[key]), rel_l2(inp["latents"], g[key])
+        print(f"[F28 merged call] latents after step {i + 1}: relL2={r:.4g} (bound {F28_BOUNDS[i]:.1e}; untouched noise {rn:.3g})")
+        assert r <= F28_BOUNDS[i], (i, r)
+        assert rn > 3 * F28_BOUNDS[i], (i, rn)                                    # the bound rejects a loop that does nothing
+    # one call per window (b = 2) instead of the merged b = 4 call: same bits
+    lat2, trace2 = _run_f28(pipe, inp, 2, spy=(calls2 := []))
+    assert [b for b, _ in calls2] == [2] * (2 * steps)
+    assert torch.equal(lat2, lat4) and torch.equal(trace2[0], trace4[0])
+
+
+GOLD_768 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_768_F4.pt")
+
+
+def test_768_loop_and_decode_at_96x96_latents(full):
+    """BASELINE.json configs[4]'s geometry: a 2-step, 4-frame CFG loop at 96x96 latents against the reference's own run
+    (tests/golden/fullsize_768_F4.pt, make_golden.py fullsize_768), and `decode_latents` of one 768x768 frame against the
+    fp32 oracle (oracle/vae.py, restating the sd-vae-ft-mse decoder the reference calls at
+    pipelines/v_express_pipeline.py:152-166)."""
+    if not os.path.exists(GOLD_768):
+        pytest.fail("tests/golden/fullsize_768_F4.pt is missing (python tests/make_golden.py fullsize_768)")
+    import oracle
+    from oracle import vae as OV
+    from v_express_amd import synth
+    pipe, cfg = full["pipe"], full["cfg"]
+    g = torch.load(GOLD_768, weights_only=False)
+    F, cf, co, steps = cases.FULLSIZE_768_CASE
+    inp = synth.synthetic_inputs(cfg, F, 96, 96)
+    trace = {}
+    lat = pipe(None, None, None, 768, 768, F, steps, cases.GUIDANCE, context_frames=cf, context_overlap=co,
+               reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD,
+               reference_latents=inp["ref_latents"], kps_features=inp["kps_features"],
+               audio_embeddings=inp["audio_embeddings"], latents=inp["latents"], decode=False,
+               callback=lambda i, t, l: trace.__setitem__(i, l.detach().clone()))
+    for i, key in ((0, "latents_step0"), (1, "latents")):
+        r, rn = rel_l2(trace[i], g[key]), rel_l2(inp["latents"], g[key])
+        print(f"[768x768 loop] latents after step {i + 1}: relL2={r:.4g} (bound {F28_BOUNDS[i]:.1e}; untouched noise {rn:.3g})")
+        assert r <= F28_BOUNDS[i] and rn > 3 * F28_BOUNDS[i], (i, r, rn)
+    # decode of ONE 768x768 frame (the reference's final latents) vs the oracle on the host cores (~10-20 s)
+    vcfg = synth.VaeConfig()
+    z = g["latents"][:, :, :1]
+    video = pipe.decode_latents(z.to("cuda")).cpu()
+    sdv = synth.vae_decoder_state_dict(vcfg)
+    with torch.no_grad():
+        ref = OV.decode_latents(sdv, oracle.VaeConfig(), z)                 # [1, 3, 1, 768, 768] in [0, 1]
+    p = psnr(video, ref)
+    print(f"[768x768 VAE decode] PSNR={p:.1f} dB")
+    assert video.shape == (1, 3, 1, 768, 768) and p >= 35.0, p

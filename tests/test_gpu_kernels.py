@@ -795,3 +795,122 @@ def test_grouped_weights_need_the_ring_kernel(ops):
     x, w = rnd(4 * 64, 64), rnd(4, 64, 64, scale=0.1, seed=1)
     with pytest.raises(VxError):
         ops.gemm(x, w, None, w_group_rows=64)
+
+
+def _gn_totals(st):
+    """(sum, sum of squares) per (frame, group) from a GnStats workspace, in float64."""
+    return st.ws.double().sum(dim=1)                     # [frames, groups, 2]
+
+
+def _gn_check(ops, out, frames, hw, groups, what):
+    """The partial sums on `out` against float64 sums of the stored tensor, and the apply pass that consumes them against
+    the GroupNorm that runs its own statistics pass."""
+    st = ops.gn_of(out)
+    assert st is not None and st.fits(frames, hw, groups, out.shape[-1]), f"{what}: no statistics on the output"
+    assert torch.isfinite(st.ws).all()
+    x = out.double().view(frames, hw, groups, -1)
+    want = torch.stack([x.sum(dim=(1, 3)), (x * x).sum(dim=(1, 3))], dim=-1)
+    got = _gn_totals(st)
+    assert torch.allclose(got, want, rtol=2e-6, atol=1e-3), (what, (got - want).abs().max().item())
+    c = out.shape[-1]
+    gamma, beta = 1 + 0.2 * rnd(c, seed=3, dtype=torch.float32), 0.3 * rnd(c, seed=4, dtype=torch.float32)
+    o3 = ops.keep_gn(out.view(frames, hw, c), out)
+    fused = ops.groupnorm(o3, gamma, beta, frames=frames, hw=hw, groups=groups, eps=1e-5, silu=True)
+    plain = ops.groupnorm(out.view(frames, hw, c).clone(), gamma, beta, frames=frames, hw=hw, groups=groups, eps=1e-5,
+                          silu=True)
+    # same apply kernel, statistics equal to ~1e-6: the outputs differ by at most one bf16 rounding here and there
+    assert (fused.float() - plain.float()).abs().max().item() <= 2 ** -6 * plain.float().abs().max().item()
+    assert (fused != plain).float().mean().item() < 1e-3, (fused != plain).float().mean().item()
+    return st
+
+
+@pytest.mark.parametrize("frames,hw,n,k,res", [(48, 1024, 640, 320, True), (13, 4096, 320, 64, False),
+                                               (24, 2304, 320, 128, True), (96, 256, 1280, 128, True)])
+def test_gemm_gn_partial_sums_ring_linear(ops, frames, hw, n, k, res):
+    """vx_gemm_params.gn_ws on the persistent 256 x 320 kernel (proj_out / the motion module's out-projection,
+    modules/transformer_3d.py:154, motion_module.py:177 -> the next block's GroupNorm): per (frame, 128-row slab, group)
+    sums of the stored bf16 values; groups of 10 / 20 / 40 channels; output unchanged; half a batch = same bits."""
+    m = frames * hw
+    a, w = rnd(m, k), rnd(n, k, scale=k ** -0.5, seed=1)
+    bias = rnd(n, seed=2, dtype=torch.float32) + 0.7
+    r = rnd(m, n, seed=3) if res else None
+    with ops.GemmProfile() as prof:
+        out = ops.gemm(a, w, bias, residual=r, gn=(32, hw))
+    assert _ring_used(prof), prof.records[0][3]
+    assert torch.equal(out, ops.gemm(a, w, bias, residual=r))
+    st = _gn_check(ops, out, frames, hw, 32, f"ring linear {frames}x{hw}x{n}")
+    assert st.slabs == hw // 128
+    h = frames // 2
+    if (h * hw // 256) * (n // 320) >= 192:
+        o2 = ops.gemm(a[:h * hw], w, bias, residual=None if r is None else r[:h * hw], gn=(32, hw))
+        assert torch.equal(ops.gn_of(o2).ws, st.ws[:h])
+
+
+def test_gemm_gn_partial_sums_ring_conv(ops):
+    """conv1 of a resnet (modules/resnet.py:223 -> norm2, :235-241): 3x3 over the zero-bordered image with the
+    time-embedding rows, through the ring kernel, leaving norm2's partial sums."""
+    nb, hh, ww, cin, cout = 48, 32, 32, 64, 320
+    x = torch.zeros(nb, hh + 2, ww + 2, cin, device="cuda", dtype=BF)
+    x[:, 1:-1, 1:-1] = rnd(nb, hh, ww, cin)
+    wt = rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=1)
+    bias = rnd(cout, seed=2, dtype=torch.float32)
+    w2d = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    g = ops.ConvGeom(nb, hh + 2, ww + 2, 3, 3, 1, 0)
+    rows = hh * ww * (nb // 2)
+    rowbias = rnd(2, cout, seed=5, dtype=torch.float32)
+    with ops.GemmProfile() as prof:
+        out = ops.gemm(x.view(-1, cin), w2d, bias, geom=g, rowbias=rowbias, rows_per_group=rows, gn=(32, hh * ww))
+    assert _ring_used(prof), prof.records[0][3]
+    ref = _conv_ref(x, wt, bias, 1, 0, 0).reshape(nb * hh * ww, cout) + rowbias.repeat_interleave(rows, 0)
+    check(out, ref, "ring conv with GroupNorm partial sums")
+    _gn_check(ops, out, nb, hh * ww, 32, "ring conv")
+
+
+@pytest.mark.parametrize("frames,hw,n,k,res", [(32, 256, 1280, 1280, True), (6, 256, 640, 192, False),
+                                               (32, 64, 1280, 1280, True), (64, 64, 1280, 640, True),
+                                               (5, 64, 320, 64, False)])
+def test_gemm_gn_partial_sums_classic_tiles(ops, frames, hw, n, k, res):
+    """The same on the classic 128 x 160 / 64 x 160 tiles (16x16 and 8x8 levels): 64-row slabs."""
+    m = frames * hw
+    a, w = rnd(m, k), rnd(n, k, scale=k ** -0.5, seed=1)
+    bias = rnd(n, seed=2, dtype=torch.float32) - 0.4
+    r = rnd(m, n, seed=3) if res else None
+    with ops.frame_rows(hw, items=2 if frames % 2 == 0 else 1), ops.GemmProfile() as prof:
+        out = ops.gemm(a, w, bias, residual=r, alpha=0.9, gn=(32, hw))
+        base = ops.gemm(a, w, bias, residual=r, alpha=0.9)
+    assert not _ring_used(prof), prof.records[0][3]
+    assert torch.equal(out, base)
+    st = _gn_check(ops, out, frames, hw, 32, f"classic {frames}x{hw}x{n}x{k}")
+    assert st.slabs == hw // 64
+
+
+def test_gemm_gn_partial_sums_downsample_conv_and_refusals(ops):
+    """Downsample3D (modules/resnet.py:106-118: 3x3 stride 2 pad 1, the gather addressing) leaves the next resnet's norm1
+    sums; launches that cannot (split-K, fp32 output, groups that straddle a wave's 80 columns, the 128 x 128 tile) simply
+    come back without statistics, and asking the library directly is an error, not a silent no-op."""
+    from v_express_amd import lib as L
+    nb, hh, ww, c = 8, 32, 32, 320
+    x = rnd(nb, hh, ww, c)
+    wt = rnd(c, c, 3, 3, scale=(9 * c) ** -0.5, seed=1)
+    bias = rnd(c, seed=2, dtype=torch.float32)
+    w2d = wt.permute(0, 2, 3, 1).reshape(c, -1).contiguous()
+    g = ops.ConvGeom(nb, hh, ww, 3, 3, 2, 1)
+    out = ops.gemm(x.view(-1, c), w2d, bias, geom=g, gn=(32, g.h_out * g.w_out))
+    check(out, _conv_ref(x, wt, bias, 2, 1, 0).reshape(-1, c), "downsample conv with GroupNorm partial sums")
+    _gn_check(ops, out, nb, g.h_out * g.w_out, 32, "downsample conv")
+    a, w = rnd(8 * 64, 2560), rnd(320, 2560, scale=2560 ** -0.5, seed=4)
+    with ops.frame_rows(64):
+        assert ops.gn_of(ops.gemm(a, w, bias, gn=(32, 64))) is None                 # split-K
+    a, w = rnd(512, 128), rnd(960, 128, scale=0.1, seed=5)
+    assert ops.gn_of(ops.gemm(a, w, None, gn=(32, 64))) is None                     # 30 channels per group
+    a, w = rnd(512, 128), rnd(512, 128, scale=0.1, seed=6)
+    assert ops.gn_of(ops.gemm(a, w, None, gn=(32, 64))) is None                     # the 128 x 128 tile
+    assert ops.gn_of(ops.gemm(a, w, None, gn=(32, 64), out_f32=True)) is None
+    p, _ = ops._base_params(a, w, None)
+    o = torch.empty((512, 512), device="cuda", dtype=BF)
+    ws = torch.empty(8 * 32 * 2, device="cuda")
+    p.epi, p.out, p.ldc, p.alpha = L.VX_EPI_STORE, o.data_ptr(), 512, 1.0
+    p.gn_ws, p.gn_groups, p.gn_hw = ws.data_ptr(), 32, 64
+    assert ops._lib.vx_gemm_gn_slabs(p) == 0
+    with pytest.raises(L.VxError):
+        L.check(ops._lib.vx_gemm(p, ops._stream()), "vx_gemm")

@@ -400,6 +400,19 @@ def test_zero_audio_rows_reduce_to_output_bias():
     r, c = rel_l2(fast[0], full[0]), cosine(fast[0], full[0])
     print(f"[zero-audio shortcut] uncond half vs fully computed: relL2={r:.4g} cosine={c:.6f}")
     assert r <= 2.5e-2 and c >= 0.9995, (r, c)
+    # The tight check of the shortcut's ARITHMETIC (a wrong or missing w_aud * bias term would pass the bound above): with
+    # the constant added by vx_add_row_bias behind the reference attention - the rounding placement of the fully computed
+    # block - the uncond half must agree with it to the round-2 bound, 12x tighter.
+    ops.FOLD_ZERO_AUDIO[0] = False
+    try:
+        same_place = unet.forward_tokens(x, t, ehs, kps, b=2, f=F, H=h, W=w, audio_kv=unet.precompute_audio_kv(ehs),
+                                         audio_zero=[True, False]).view(2, F * h * w, -1)
+    finally:
+        ops.FOLD_ZERO_AUDIO[0] = True
+    assert torch.equal(same_place[1], full[1])
+    r2 = rel_l2(same_place[0], full[0])
+    print(f"[zero-audio shortcut] same rounding placement: relL2={r2:.4g}")
+    assert r2 <= 2e-3, r2
 
 
 def test_bench_two_rank_control_flow_on_one_gpu():

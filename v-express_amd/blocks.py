@@ -30,10 +30,12 @@ def _resnet_block(P, x, frames, H, W, *, groups, eps, temb=None, rows_per_group=
                       pad_hw=(H, W))
     g3 = ConvGeom(frames, H + 2, W + 2, 3, 3, 1, 0)
     hp = (H + 2) * (W + 2)
-    h = ops.gemm(n.view(frames * hp, -1), P.conv1.w, P.conv1.b, geom=g3, rowbias=temb, rows_per_group=rows_per_group)
+    # conv1's epilogue leaves norm2's partial sums on h (ops.gemm(gn=...)): norm2 is an apply pass only
+    h = ops.gemm(n.view(frames * hp, -1), P.conv1.w, P.conv1.b, geom=g3, rowbias=temb, rows_per_group=rows_per_group,
+                 gn=(groups, hw))
     cout = h.shape[-1]
-    n2 = ops.groupnorm(h.view(frames, hw, cout), P.norm2.g, P.norm2.b, frames=frames, hw=hw, groups=groups, eps=eps,
-                       silu=True, pad_hw=(H, W))
+    n2 = ops.groupnorm(ops.keep_gn(h.view(frames, hw, cout), h), P.norm2.g, P.norm2.b, frames=frames, hw=hw,
+                       groups=groups, eps=eps, silu=True, pad_hw=(H, W))
     if P.shortcut is not None:
         sc = ops.gemm(x.view(frames * hw, c1), P.shortcut.w, P.shortcut.b,
                       a2=None if skip is None else skip.view(frames * hw, -1))
@@ -41,15 +43,18 @@ def _resnet_block(P, x, frames, H, W, *, groups, eps, temb=None, rows_per_group=
         if skip is not None:
             raise ValueError("concat input needs a conv_shortcut")
         sc = x.view(frames * hw, c1)
-    out = ops.gemm(n2.view(frames * hp, cout), P.conv2.w, P.conv2.b, geom=g3, residual=sc)
-    return out.view(frames, hw, cout)
+    # every resnet output is read by a GroupNorm next (Transformer3DModel.norm or the motion module's norm)
+    out = ops.gemm(n2.view(frames * hp, cout), P.conv2.w, P.conv2.b, geom=g3, residual=sc, gn=(groups, hw))
+    return ops.keep_gn(out.view(frames, hw, cout), out)
 
 
-def downsample(P, x, frames, H, W):
-    """Downsample3D: conv3x3 stride 2 pad 1 (modules/resnet.py:106-118)."""
+def downsample(P, x, frames, H, W, gn_groups=0):
+    """Downsample3D: conv3x3 stride 2 pad 1 (modules/resnet.py:106-118).  gn_groups: the next block's first resnet
+    normalises this output (norm1): leave its partial sums on the tensor."""
     g = ConvGeom(frames, H, W, 3, 3, 2, 1)
-    out = ops.gemm(x.view(frames * H * W, -1), P.w, P.b, geom=g)
-    return out.view(frames, g.h_out * g.w_out, -1), g.h_out, g.w_out
+    out = ops.gemm(x.view(frames * H * W, -1), P.w, P.b, geom=g,
+                   gn=(gn_groups, g.h_out * g.w_out) if gn_groups else None)
+    return ops.keep_gn(out.view(frames, g.h_out * g.w_out, -1), out), g.h_out, g.w_out
 
 
 def upsample(P, x, frames, H, W):
@@ -115,8 +120,9 @@ def _norm_proj_in(P, x, frames, hw, groups, stats_out=None):
     m = frames * hw
     G = P.get("gn_fold")
     if G is not None and ops.gn_fold_applies(m, hw, c, G.w.shape[0]):
-        ws = ops.groupnorm_stats(x, frames=frames, hw=hw, groups=groups)
-        w_f, b_f = ops.groupnorm_fold_linear(ws, G.g, G.w, G.bb, frames=frames, hw=hw, groups=groups, eps=1e-6)
+        ws, slices = ops.groupnorm_stats(x, frames=frames, hw=hw, groups=groups)      # the producer's own when it left them
+        w_f, b_f = ops.groupnorm_fold_linear(ws, G.g, G.w, G.bb, frames=frames, hw=hw, groups=groups, eps=1e-6,
+                                             slices=slices)
         return ops.gemm(x.view(m, c), w_f, None, rowbias=b_f, rows_per_group=hw, w_group_rows=hw, stats_out=stats_out)
     n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
     return ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b, stats_out=stats_out)
@@ -169,7 +175,8 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
     d = c // heads
     rows = f * hw
     fold_ref = [bank[bi] is None for bi in range(b)]
-    fold_aud = [fold_ref[bi] and audio_zero is not None and bool(audio_zero[bi]) for bi in range(b)]
+    fold_aud = [ops.FOLD_ZERO_AUDIO[0] and fold_ref[bi] and audio_zero is not None and bool(audio_zero[bi])
+                for bi in range(b)]
     item_bias = None
     if any(fold_ref):
         key = ("item_bias", tuple(fold_ref), tuple(fold_aud), float(w_ref), float(w_aud))
@@ -247,8 +254,8 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
                          stats_out=sb if f_ff else None)
     # 3. feed-forward (:247)
     _feed_forward(P, h, st if f_ff else None)
-    out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x2d)
-    return out.view(frames, hw, c)
+    out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x2d, gn=(groups, hw))      # read next by the motion module's norm
+    return ops.keep_gn(out.view(frames, hw, c), out)
 
 
 def spatial_transformer_write(P, x, *, frames, H, W, heads, groups, ehs):
@@ -278,19 +285,21 @@ def _spatial_transformer_write(P, x, *, frames, H, W, heads, groups, ehs):
     return out.view(frames, hw, c), bank
 
 
-def motion_module(P, x, *, b, f, H, W, heads, groups, shard=None):
+def motion_module(P, x, *, b, f, H, W, heads, groups, shard=None, gn_next=False):
     with ops.frame_rows(H * W, items=b):
-        return _motion_module(P, x, b=b, f=f, H=H, W=W, heads=heads, groups=groups, shard=shard)
+        return _motion_module(P, x, b=b, f=f, H=H, W=W, heads=heads, groups=groups, shard=shard, gn_next=gn_next)
 
 
-def _motion_module(P, x, *, b, f, H, W, heads, groups, shard=None):
+def _motion_module(P, x, *, b, f, H, W, heads, groups, shard=None, gn_next=False):
     """VanillaTemporalModule -> TemporalTransformer3DModel.forward (modules/motion_module.py:146-182), one
     TemporalTransformerBlock (:236-259): 2x [LN, +pe, QKV, attention over f, out-proj + residual], LN, GEGLU FF.
     The additive sinusoid table goes through the LayerNorm kernel (pe enters Q, K and V: :365-366).
     shard (distributed.FrameShard): x holds only this rank's f frames of the window.  The GroupNorm (per-frame
     statistics) runs on them; the temporal transformer - per token except the attention over the frame axis - runs on
     all shard.size * f frames of this rank's pixel slice between two all-to-alls; the output projection and the
-    residual add are per token again and run back in the frame-shard layout."""
+    residual add are per token again and run back in the frame-shard layout.
+    gn_next: the output is read by a GroupNorm over these channels next (the following resnet's norm1 without a skip
+    concat, or conv_norm_out): the out-projection leaves that GroupNorm's partial sums on the tensor."""
     frames, hw, c = b * f, H * W, x.shape[-1]
     d = c // heads
     f_all, hw_t = f, hw
@@ -321,8 +330,8 @@ def _motion_module(P, x, *, b, f, H, W, heads, groups, shard=None):
     _feed_forward(P, h, st if folds[-1] else None)
     if shard is not None:
         h = shard.to_frame_shard(h.view(b * f_all, hw_t, c), b, f).view(frames * hw, c)
-    out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x.view(frames * hw, c))
-    return out.view(frames, hw, c)
+    out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x.view(frames * hw, c), gn=(groups, hw) if gn_next else None)
+    return ops.keep_gn(out.view(frames, hw, c), out)
 
 
 def bank_kv(A, bank_tokens, heads):

@@ -69,9 +69,13 @@ __device__ __forceinline__ f32x4_t mfma16_f8(const uint4& a_lo, const uint4& a_h
 
 // LNF: a LayerNorm folded into the GEMM (vx_gemm_params.ln_stats) - a template flag, not a run-time branch: the
 // transform's live values pushed the 256 x 320 instantiations into 150-200 spilled registers when every kernel carried it.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST, bool F8 = false, bool LNF = false>
+// GNS (round 4; STORE into bf16, whole tiles only): the epilogue also writes the GroupNorm partial sums of the stored
+// values to p.gn_ws (vx_gemm_params.gn_ws; one slab = the 64 rows of a wave) - a template flag for the same reason.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST, bool F8 = false, bool LNF = false,
+          bool GNS = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const vx_gemm_params p) {
   static_assert(!F8 || FAST, "fp8 operands use the FAST addressing only");
+  static_assert(!GNS || (EPI == VX_EPI_STORE && !F8 && !LNF), "GroupNorm partial sums come from the plain STORE epilogue");
   static_assert(!LNF || (FAST && !F8), "a folded LayerNorm sits in front of a plain bf16 linear");
   constexpr int ES = F8 ? 1 : 2;            // bytes per operand element
   constexpr int BKE = 128 / ES;             // elements per K-tile (one 128-byte LDS row)
@@ -377,6 +381,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
     const bool do_silu = p.act == VX_ACT_SILU, do_gelu = p.act == VX_ACT_GELU;
     const bool out_is_f32 = p.out_f32 != 0;
     const float alpha = p.alpha;
+    // GNS: this lane's NI x 4 columns, summed over its MI rows
+    float gcs[GNS ? NI * 4 : 1], gcq[GNS ? NI * 4 : 1];
+    if constexpr (GNS) {
+#pragma unroll
+      for (int c = 0; c < NI * 4; ++c) gcs[c] = gcq[c] = 0.f;
+    }
 #pragma unroll
     for (int j0 = 0; j0 < NI; j0 += NJ) {
       int ncol[NJ], nc[NJ];
@@ -428,7 +438,18 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
           for (int e = 0; e < 4; ++e) v[e] *= alpha;
           v[0] += __uint_as_float(rv[j].x << 16); v[1] += __uint_as_float(rv[j].x & 0xffff0000u);
           v[2] += __uint_as_float(rv[j].y << 16); v[3] += __uint_as_float(rv[j].y & 0xffff0000u);
-          if (ABL(1)) {
+          if constexpr (GNS) {
+            // whole tiles, bf16 output (vx_gemm_gn_slabs): statistics of the STORED values, as a read-back would see them
+            const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            *reinterpret_cast<uint2*>((bf16_t*)p.out + (size_t)m * p.ldc + ncol[j]) = pk;
+            const float g[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
+                                __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              gcs[(j0 + j) * 4 + e] += g[e];
+              gcq[(j0 + j) * 4 + e] = fmaf(g[e], g[e], gcq[(j0 + j) * 4 + e]);
+            }
+          } else if (ABL(1)) {
             asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
           } else if (m < p.m && ncol[j] < p.n) {
             if (out_is_f32) {
@@ -440,6 +461,38 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
             }
           }
         }
+      }
+    }
+    if constexpr (GNS) {
+      // The 16 lanes of a DPP row hold the rows lrow of the same columns: rotate-and-add leaves the 64-row column sums in
+      // every lane; lanes lrow == 0 park them in this wave's WN x 8 bytes of LDS BEHIND the pipeline stages (other waves
+      // may still be reading their last K-tile), and lane g < WN / cg adds the cg columns of group g in ascending order
+      // (a group never straddles a wave: WN % cg == 0 is part of vx_gemm_gn_slabs).  Same-wave LDS writes and reads are
+      // ordered in the LDS queue; no barrier.
+#pragma unroll
+      for (int c = 0; c < NI * 4; ++c) {
+        gcs[c] = row16_sum(gcs[c]);
+        gcq[c] = row16_sum(gcq[c]);
+      }
+      float2* scr = reinterpret_cast<float2*>(smem + STAGES * STAGE_BYTES) + wave * WN;
+      if (lrow == 0) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) scr[j * 16 + lq * 4 + e] = make_float2(gcs[j * 4 + e], gcq[j * 4 + e]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int cg = p.n / p.gn_groups;
+      if (lane < WN / cg) {
+        float a = 0.f, b = 0.f;
+        for (int c = 0; c < cg; ++c) {
+          const float2 t = scr[lane * cg + c];
+          a += t.x;
+          b += t.y;
+        }
+        const int frame = wrow0 / p.gn_hw, slab = (wrow0 - frame * p.gn_hw) >> 6, slabs = p.gn_hw >> 6;
+        const int g = wcol0 / cg + lane;
+        reinterpret_cast<float2*>(p.gn_ws)[(size_t)(frame * slabs + slab) * p.gn_groups + g] = make_float2(a, b);
       }
     }
   } else if constexpr (EPI == VX_EPI_GEGLU) {
@@ -611,14 +664,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vx_gemm_params
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST, bool F8 = false, bool LNF = false>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES, int EPI, bool FAST, bool F8 = false, bool LNF = false,
+          bool GNS = false>
 int launch_impl(const vx_gemm_params& p, hipStream_t stream) {
   constexpr int stage_bytes = STAGES * (BM + BN) * 128;
   constexpr int epi_bytes = (EPI == VX_EPI_SPLIT) ? BN * (64 + 4) * 4 : 0;   // V^T transposition slab
-  constexpr int smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+  constexpr int gns_bytes = GNS ? WARPS_M * BN * 8 : 0;                       // column sums of every wave, behind the stages
+  constexpr int smem = (stage_bytes > epi_bytes ? stage_bytes : epi_bytes) + gns_bytes;
   constexpr int nthreads = 64 * WARPS_M * WARPS_N;
   static bool attr_set = false;
-  auto kern = gemm_kernel<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, FAST, F8, LNF>;
+  auto kern = gemm_kernel<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, FAST, F8, LNF, GNS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
@@ -665,6 +720,13 @@ int launch(const vx_gemm_params& p, hipStream_t stream) {
   }
   if (fast_ok(p)) return launch_impl<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, true>(p, stream);
   return launch_impl<BM, BN, WARPS_M, WARPS_N, STAGES, EPI, false>(p, stream);
+}
+
+// STORE launch that also writes GroupNorm partial sums (p.gn_ws): instantiated for the tiles the 16x16 / 8x8 levels use
+template <int BM, int BN, int WARPS_M, int WARPS_N, int STAGES>
+int launch_gns(const vx_gemm_params& p, hipStream_t stream) {
+  if (fast_ok(p)) return launch_impl<BM, BN, WARPS_M, WARPS_N, STAGES, VX_EPI_STORE, true, false, false, true>(p, stream);
+  return launch_impl<BM, BN, WARPS_M, WARPS_N, STAGES, VX_EPI_STORE, false, false, false, true>(p, stream);
 }
 
 // column-tile width with the least padding (ties -> 160: fewer, fatter tiles)
@@ -716,7 +778,40 @@ bool use_small64(const vx_gemm_params& p) {
   return tiles128 < lim && fast_ok(p);
 }
 
+// which classic tile a bf16-operand STORE launch gets (the persistent ring kernel is asked first by the callers)
+enum { T_256x32 = 0, T_BIG, T_SMALL64, T_128x160, T_128x128 };
+int store_tile(const vx_gemm_params& p) {
+  if (p.n <= 32) return T_256x32;
+  if (use_big(p)) return T_BIG;
+  if (use_small64(p)) return T_SMALL64;
+  if (prefer160(p.n)) return T_128x160;
+  return T_128x128;
+}
+
 }  // namespace
+
+// GroupNorm partial sums from the STORE epilogue (vx_gemm_params.gn_ws): slabs per frame the launch of p writes, 0 = it
+// cannot (the caller keeps the separate statistics pass).  Mirrors vx_gemm_dispatch's kernel choice.
+extern "C" int vx_gemm_gn_slabs(const vx_gemm_params* pp) {
+  const vx_gemm_params& p = *pp;
+  if (p.epi != VX_EPI_STORE || p.a_fp8 || p.out_f32 || p.ln_stats != nullptr || p.row_stats_out != nullptr ||
+      p.splitk > 1 || p.w_group_rows != 0)
+    return 0;
+  if (p.gn_groups <= 0 || p.gn_hw <= 0 || p.n <= 0 || (p.n % p.gn_groups) != 0 || (p.m % p.gn_hw) != 0) return 0;
+  if (vx_gemm_ring_eligible(p)) return vx_gemm_ring_gn_slabs(p);
+  const int cg = p.n / p.gn_groups;
+  const int tile = store_tile(p);
+  if (tile != T_SMALL64 && tile != T_128x160) return 0;
+  static int st128 = -1;
+  if (st128 < 0) {
+    const char* e = getenv("VX_GEMM_STAGES128");
+    st128 = e ? atoi(e) : 2;
+  }
+  if (tile == T_128x160 && st128 != 2) return 0;   // (the A/B depth knob has no partial-sum instantiation)
+  const int bm = tile == T_SMALL64 ? 64 : 128;
+  if ((p.m % bm) != 0 || (p.n % 160) != 0 || (p.gn_hw % 64) != 0 || (80 % cg) != 0) return 0;   // whole tiles, wave = 64 x 80
+  return p.gn_hw / 64;
+}
 
 extern "C" int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk) {
   return splitk > 1 ? (int64_t)splitk * m * n * (int64_t)sizeof(float) : 0;
@@ -760,6 +855,11 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
   if (p.w_group_rows != 0)
     VX_REQUIRE(p.w_group_rows > 0 && (p.m % p.w_group_rows) == 0 && p.epi == VX_EPI_STORE && !p.a_fp8 && p.splitk <= 1,
                "vx_gemm: w_group_rows=%d must divide m=%d (STORE epilogue, no fp8 / split-K)", p.w_group_rows, p.m);
+  if (p.gn_ws != nullptr && vx_gemm_gn_slabs(pp) <= 0) {
+    vx_set_error("vx_gemm: this launch cannot produce GroupNorm partial sums (gn_ws set; vx_gemm_gn_slabs() == 0: m=%d "
+                 "n=%d groups=%d hw=%d epi=%d splitk=%d)", p.m, p.n, p.gn_groups, p.gn_hw, p.epi, p.splitk);
+    return VX_ERR_UNSUPPORTED;
+  }
   const int rc = vx_gemm_dispatch(p, stream);
   if (rc != VX_OK || p.row_stats_out == nullptr) return rc;
   if (vx_gemm_ring_eligible(p) && vx_gemm_ring_writes_row_stats(p)) return rc;   // the epilogue wrote them
@@ -815,10 +915,16 @@ static int vx_gemm_dispatch(const vx_gemm_params& p, hipStream_t stream) {
                    "accepts (m %% 256, n %% 320, w_group_rows %% 256, plain addressing)", p.w_group_rows);
       return VX_ERR_UNSUPPORTED;
     }
-    if (p.n <= 32) return launch<256, 32, 4, 1, 2, VX_EPI_STORE>(p, stream);
-    if (use_big(p)) return launch<256, 320, 4, 2, 2, VX_EPI_STORE>(p, stream);
-    if (use_small64(p)) return launch<64, 160, 1, 2, 3, VX_EPI_STORE>(p, stream);
-    if (prefer160(p.n)) {
+    const int tile = store_tile(p);
+    if (p.gn_ws != nullptr) {
+      // (vx_gemm checked vx_gemm_gn_slabs(p) > 0: only these two tiles produce the partial sums)
+      if (tile == T_SMALL64) return launch_gns<64, 160, 1, 2, 3>(p, stream);
+      return launch_gns<128, 160, 2, 2, 2>(p, stream);
+    }
+    if (tile == T_256x32) return launch<256, 32, 4, 1, 2, VX_EPI_STORE>(p, stream);
+    if (tile == T_BIG) return launch<256, 320, 4, 2, 2, VX_EPI_STORE>(p, stream);
+    if (tile == T_SMALL64) return launch<64, 160, 1, 2, 3, VX_EPI_STORE>(p, stream);
+    if (tile == T_128x160) {
       // pipeline depth of the 128 x 160 tile (VX_GEMM_STAGES128 = 2 | 3 | 4; A/B knob): the 16x16-level launches are
       // DMA-latency bound at depth 2 (8192 x 1280 x 1280: 2 us per K-tile against 0.3 us of MFMA work)
       static int st = -1;

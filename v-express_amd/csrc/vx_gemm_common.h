@@ -49,3 +49,18 @@ bool vx_gemm_fast_ok(const vx_gemm_params& p);
 bool vx_gemm_ring_eligible(const vx_gemm_params& p);
 int vx_gemm_ring_launch(const vx_gemm_params& p, hipStream_t stream);
 bool vx_gemm_ring_writes_row_stats(const vx_gemm_params& p);
+int vx_gemm_ring_gn_slabs(const vx_gemm_params& p);
+
+// sum over the 16 lanes of a DPP row (v_add_f32 with row_ror:8 / 4 / 2 / 1): every lane ends with the row's total.  In the
+// C^T accumulator layout the lanes of a DPP row hold 16 consecutive output rows of the same columns.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0x128>(v);
+  v += dpp_mov<0x124>(v);
+  v += dpp_mov<0x122>(v);
+  v += dpp_mov<0x121>(v);
+  return v;
+}

@@ -132,7 +132,10 @@ __device__ __forceinline__ f32x4_t ring_mfma_f8(const uint4& a_lo, const uint4& 
 // GEMM folds (vx_gemm_params.ln_stats), so no separate pass re-reads the tensor.
 // LNF: a LayerNorm is folded into this GEMM (p.ln_stats / p.ln_colsum); a template flag, not a run-time branch: as a
 // branch the epilogue's live values spilled (the lesson of the classic tiles in round 2).
-template <int EPI, bool RES, bool F8 = false, bool STATS = false, bool LNF = false>
+// GNS (round 4; STORE): the epilogue also writes the GroupNorm partial sums of the STORED bf16 values to p.gn_ws in the
+// workspace layout of vx_groupnorm ([frame][slab][group] (sum, sum of squares); one slab = the 128 rows of a wave row),
+// so the statistics pass of the GroupNorm that reads this tensor next never runs (vx_gemm_params.gn_ws).
+template <int EPI, bool RES, bool F8 = false, bool STATS = false, bool LNF = false, bool GNS = false>
 __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params p) {
   constexpr int ES = F8 ? 1 : 2;      // bytes per operand element
   constexpr int BKE = 128 / ES;       // elements per K-tile
@@ -555,6 +558,12 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
         for (int k = 0; k < RES_DEPTH; ++k) load_res(k);
       }
       float st_s = 0.f, st_q = 0.f;   // STATS: this lane's (sum, sum of squares) of row 16 i + lrow, 20 columns
+      // GNS: this lane's 20 columns, summed over its 8 rows (16 i + lrow): [0..7] pair 0, [8..15] pair 1, [16..19] fragment 4
+      float gcs[GNS ? 20 : 1], gcq[GNS ? 20 : 1];
+      if constexpr (GNS) {
+#pragma unroll
+        for (int c = 0; c < 20; ++c) gcs[c] = gcq[c] = 0.f;
+      }
 #pragma unroll
       for (int k = 0; k < N_ITEMS; ++k) {
         if (RES && !RABL(64) && k + RES_DEPTH < N_ITEMS) load_res(k + RES_DEPTH);
@@ -577,6 +586,13 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
           }
           const uint2 pk2 = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
           *reinterpret_cast<uint2*>(outb + out_off(k)) = pk2;
+          if constexpr (GNS) {
+            const float g0 = __uint_as_float(pk2.x << 16), g1 = __uint_as_float(pk2.x & 0xffff0000u);
+            const float g2 = __uint_as_float(pk2.y << 16), g3 = __uint_as_float(pk2.y & 0xffff0000u);
+            gcs[16] += g0; gcs[17] += g1; gcs[18] += g2; gcs[19] += g3;
+            gcq[16] = fmaf(g0, g0, gcq[16]); gcq[17] = fmaf(g1, g1, gcq[17]);
+            gcq[18] = fmaf(g2, g2, gcq[18]); gcq[19] = fmaf(g3, g3, gcq[19]);
+          }
           if constexpr (STATS) {
             // statistics of the STORED (bf16-rounded) values, as vx_row_stats would read them back
             const float r0 = __uint_as_float(pk2.x << 16), r1 = __uint_as_float(pk2.x & 0xffff0000u);
@@ -622,6 +638,15 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
           }
           const uint4 pk8 = pack_bf16x8(v);
           *reinterpret_cast<uint4*>(outb + out_off(k)) = pk8;
+          if constexpr (GNS) {
+            float gg[8];
+            unpack_bf16x8(pk8, gg);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              gcs[kind * 8 + e] += gg[e];
+              gcq[kind * 8 + e] = fmaf(gg[e], gg[e], gcq[kind * 8 + e]);
+            }
+          }
           if constexpr (STATS) {
             float rr[8];
             unpack_bf16x8(pk8, rr);
@@ -646,6 +671,44 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
           reinterpret_cast<float2*>(p.row_stats_out)[tile_m * R_BM + tid] =
               make_float2(mean, 1.0f / sqrtf(var + p.row_stats_eps));
         }
+      }
+      if constexpr (GNS) {
+        // (a) the 16 lanes of a DPP row hold the 16 rows lrow of the same columns: four rotate-and-add steps leave the
+        // 128-row column sums in every lane; (b) lanes lrow == 0 park their 20 columns in this wave's 640 bytes of LDS
+        // behind the K-tile buffers (the wave's own writes and reads are ordered in the LDS queue: no barrier);
+        // (c) lane g < 80 / cg adds the cg columns of group g in ascending order (groups never straddle a wave: 80 % cg
+        // == 0 is part of the eligibility) and writes the slab's (sum, sum of squares).  Fixed order -> same bits for any
+        // batch; the consumer (gn_apply / gn_fold_linear) adds the slabs of a frame in float64.
+#pragma unroll
+        for (int c = 0; c < 20; ++c) {
+          gcs[c] = row16_sum(gcs[c]);
+          gcq[c] = row16_sum(gcq[c]);
+        }
+        float2* scr = reinterpret_cast<float2*>(smem + STATS_OFF) + wave * 80;
+        if (lrow == 0) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              scr[16 * (2 * t + (lq & 1)) + 8 * (lq >> 1) + e] = make_float2(gcs[t * 8 + e], gcq[t * 8 + e]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) scr[64 + 4 * lq + r] = make_float2(gcs[16 + r], gcq[16 + r]);
+        }
+        ring_wait_lgkm0();
+        const int cg = p.n / p.gn_groups;
+        if (lane < 80 / cg) {
+          float a = 0.f, b = 0.f;
+          for (int c = 0; c < cg; ++c) {
+            const float2 t = scr[lane * cg + c];
+            a += t.x;
+            b += t.y;
+          }
+          const int m0w = tile_m * R_BM + 128 * grp;
+          const int frame = m0w / p.gn_hw, slab = (m0w - frame * p.gn_hw) >> 7, slabs = p.gn_hw >> 7;
+          const int g = (tile_n * R_BN + 80 * wc) / cg + lane;
+          reinterpret_cast<float2*>(p.gn_ws)[(size_t)(frame * slabs + slab) * p.gn_groups + g] = make_float2(a, b);
+        }
+        ring_wait_lgkm0();   // the scratch is rewritten by this wave's next tile only after these reads
       }
     } else {   // VX_EPI_GEGLU
       // Weight rows are interleaved in blocks of 8 (weights.py: geglu_interleave): columns 16j..16j+7 of a fragment
@@ -781,10 +844,10 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
   return mode == 2 || p.k <= 1280;
 }
 
-template <int EPI, bool RES, bool F8 = false, bool STATS = false, bool LNF = false>
+template <int EPI, bool RES, bool F8 = false, bool STATS = false, bool LNF = false, bool GNS = false>
 static int ring_launch(const vx_gemm_params& p, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = gemm_ring_kernel<EPI, RES, F8, STATS, LNF>;
+  auto kern = gemm_ring_kernel<EPI, RES, F8, STATS, LNF, GNS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_TOTAL);
     if (e != hipSuccess) {
@@ -822,10 +885,22 @@ int vx_gemm_ring_launch(const vx_gemm_params& p, hipStream_t stream) {
   }
   if (vx_gemm_ring_writes_row_stats(p))
     return res ? ring_launch<VX_EPI_STORE, true, false, true>(p, stream) : ring_launch<VX_EPI_STORE, false, false, true>(p, stream);
+  if (p.gn_ws != nullptr)   // (vx_gemm checked vx_gemm_gn_slabs(p) > 0)
+    return res ? ring_launch<VX_EPI_STORE, true, false, false, false, true>(p, stream)
+               : ring_launch<VX_EPI_STORE, false, false, false, false, true>(p, stream);
   return res ? ring_launch<VX_EPI_STORE, true>(p, stream) : ring_launch<VX_EPI_STORE, false>(p, stream);
 }
 
 // whether the ring launch of p fills p.row_stats_out itself (otherwise vx_gemm runs vx_row_stats on the output)
 bool vx_gemm_ring_writes_row_stats(const vx_gemm_params& p) {
   return p.row_stats_out != nullptr && !p.a_fp8 && p.epi == VX_EPI_STORE && p.n == R_BN;
+}
+
+// GroupNorm partial sums from the STORE epilogue (vx_gemm_params.gn_ws): slabs per frame this launch writes, 0 = cannot
+int vx_gemm_ring_gn_slabs(const vx_gemm_params& p) {
+  if (p.epi != VX_EPI_STORE || p.a_fp8 || p.out_f32 || p.ln_stats != nullptr || p.row_stats_out != nullptr) return 0;
+  if (p.gn_groups <= 0 || p.gn_hw <= 0 || (p.n % p.gn_groups) != 0 || (p.m % p.gn_hw) != 0 || (p.gn_hw % 128) != 0) return 0;
+  const int cg = p.n / p.gn_groups;
+  if (cg <= 0 || (80 % cg) != 0) return 0;
+  return p.gn_hw / 128;
 }

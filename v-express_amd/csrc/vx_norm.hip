@@ -638,6 +638,33 @@ extern "C" int vx_groupnorm(const void* x1, int c1, const void* x2, int c2, int 
   return vx_check_launch("vx_groupnorm(apply)");
 }
 
+extern "C" int vx_groupnorm_apply(const void* x1, int c1, const void* x2, int c2, int frames, int hw, int groups,
+                                  float eps, const float* gamma, const float* beta, int silu, void* out,
+                                  const float* ws, int stat_slices, int slices, int width, int out_pad, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int C = c1 + c2;
+  VX_REQUIRE(x1 != nullptr && out != nullptr && ws != nullptr && gamma != nullptr && beta != nullptr,
+             "vx_groupnorm_apply: null pointer");
+  VX_REQUIRE((c2 == 0) == (x2 == nullptr), "vx_groupnorm_apply: x2/c2 mismatch");
+  VX_REQUIRE(c1 > 0 && (c1 % 8) == 0 && (c2 % 8) == 0, "vx_groupnorm_apply: channels must be multiples of 8");
+  VX_REQUIRE(groups > 0 && (C % groups) == 0, "vx_groupnorm_apply: C=%d not divisible by groups=%d", C, groups);
+  VX_REQUIRE(C <= 8 * GN_THREADS * GN_MAX_SETS, "vx_groupnorm_apply: C=%d too large", C);
+  VX_REQUIRE(frames > 0 && hw > 0 && slices > 0 && slices <= hw && stat_slices > 0, "vx_groupnorm_apply: bad geometry");
+  VX_REQUIRE(silu >= 0 && silu <= 2, "vx_groupnorm_apply: activation code %d (0 none, 1 SiLU, 2 erf-GELU)", silu);
+  VX_REQUIRE(out_pad >= 0 && (out_pad == 0 || (width > 0 && hw % width == 0)),
+             "vx_groupnorm_apply: padded output needs the image width (hw=%d width=%d)", hw, width);
+  if (out_pad == 0) width = hw;
+  int w_shift = -1;
+  for (int sft = 0; sft < 31; ++sft)
+    if ((1 << sft) == width) w_shift = sft;
+  const size_t smem_apply = (size_t)(2 * C + 2 * groups) * sizeof(float) + (size_t)GN_SUBS * groups * 2 * sizeof(double);
+  const int apix = ceil_div(hw, slices);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(frames * slices), dim3(GN_THREADS), smem_apply, stream, (const bf16_t*)x1, c1,
+                     (const bf16_t*)x2, c2, hw, groups, eps, gamma, beta, silu, (bf16_t*)out, slices, apix, ws, width,
+                     w_shift, out_pad, stat_slices);
+  return vx_check_launch("vx_groupnorm_apply");
+}
+
 extern "C" int vx_groupnorm_stats(const void* x1, int c1, const void* x2, int c2, int frames, int hw, int groups,
                                   float* ws, int slices, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -47,6 +47,7 @@ class GemmParams(C.Structure):
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p),
         ("row_stats_out", C.c_void_p), ("row_stats_eps", C.c_float),
         ("w_group_rows", C.c_int32),
+        ("gn_ws", C.c_void_p), ("gn_groups", C.c_int32), ("gn_hw", C.c_int32),
     ]
 
 
@@ -89,6 +90,8 @@ def _load():
     lib.vx_groupnorm_ws_floats.argtypes = [i32, i32, i32]
     lib.vx_groupnorm.argtypes = [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, i32, i32, i32, vp]
     lib.vx_groupnorm_stats.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp]
+    lib.vx_groupnorm_apply.argtypes = [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
+    lib.vx_gemm_gn_slabs.argtypes = [C.POINTER(GemmParams)]
     lib.vx_groupnorm_fold_linear.argtypes = [vp, i32, i32, i32, i32, f32, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.vx_layernorm.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp]
     lib.vx_row_stats.argtypes = [vp, i32, i32, i32, f32, vp, vp]
@@ -116,7 +119,7 @@ def _load():
         if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name",
                         "vx_gemm_splitk_ws_bytes"):
             fn.restype = i32
-    if lib.vx_abi_version() != 9:
+    if lib.vx_abi_version() != 10:
         raise ImportError("libvexpress_hip.so ABI version mismatch")
     return lib
 

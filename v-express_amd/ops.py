@@ -204,6 +204,39 @@ LN_FOLD = [os.environ.get("VX_LN_FOLD", "1") != "0" and os.environ.get("VX_GEMM_
 FUSED_STATS = [os.environ.get("VX_FUSED_STATS", "1") != "0"]
 
 
+# False (tests only): an all-zero-audio batch item gets its constant attn2 term from a vx_add_row_bias pass behind the
+# reference attention - the same rounding placement as the fully computed block - instead of riding in the attn1
+# out-projection's epilogue (blocks._spatial_transformer_read)
+FOLD_ZERO_AUDIO = [True]
+# VX_GN_FUSED=0 (A/B knob): GroupNorm statistics always come from vx_groupnorm's own read pass
+GN_FUSED = [os.environ.get("VX_GN_FUSED", "1") != "0"]
+
+
+class GnStats:
+    """GroupNorm partial sums of a tensor, written by the GEMM that produced it (vx_gemm_params.gn_ws): `ws` float32
+    [frames, slabs, groups, 2] in vx_groupnorm's workspace layout.  Travels as the `_vx_gn` attribute of the tensor
+    object (`keep_gn` carries it across a .view())."""
+
+    def __init__(self, ws, slabs, groups, frames, hw, c):
+        self.ws, self.slabs, self.groups, self.frames, self.hw, self.c = ws, slabs, groups, frames, hw, c
+
+    def fits(self, frames, hw, groups, c):
+        return (self.frames, self.hw, self.groups, self.c) == (frames, hw, groups, c)
+
+
+def gn_of(x):
+    """The GnStats its producer attached to `x`, or None."""
+    return getattr(x, "_vx_gn", None) if GN_FUSED[0] else None
+
+
+def keep_gn(view, src):
+    """`view` is a reshape of `src`: carry the producer's GroupNorm statistics over to the new tensor object."""
+    st = getattr(src, "_vx_gn", None)
+    if st is not None:
+        view._vx_gn = st
+    return view
+
+
 def row_stats(x, eps=1e-5, out=None):
     """float32 [rows, 2] = (mean, rstd) of every row: the statistics of a LayerNorm folded into its consumer GEMM
     (`gemm(..., ln=(stats, colsum))`, weights.fold_layernorm)."""
@@ -386,13 +419,16 @@ def _splitk(p, geom, device, plain):
 
 
 def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L.VX_ACT_NONE, rowbias=None,
-         rows_per_group=0, out=None, out_f32=False, ln=None, stats_out=None, stats_eps=1e-5, w_group_rows=0):
+         rows_per_group=0, out=None, out_f32=False, ln=None, stats_out=None, stats_eps=1e-5, w_group_rows=0, gn=None):
     """out[m, n] = residual + alpha * act(sum_k A[m,k] W[n,k] + bias[n] + rowbias[m // rows_per_group, n]).
     ln=(stats, colsum): a LayerNorm folded into this GEMM - the sum is replaced by rstd[m] * (sum - mean[m] * colsum[n])
     with `w`, `bias` the folded weight / bias of weights.fold_layernorm and `a` the un-normalised rows.
     stats_out: float32 [m, 2] (contiguous) that receives (mean, rstd) of every STORED output row - the `ln` statistics
     of the next GEMM (produced by the epilogue itself at the 64x64 level, by vx_row_stats inside vx_gemm otherwise).
-    w_group_rows > 0: `w` is [m // w_group_rows, N, K]; output rows of group g use w[g] (groupnorm_fold_linear)."""
+    w_group_rows > 0: `w` is [m // w_group_rows, N, K]; output rows of group g use w[g] (groupnorm_fold_linear).
+    gn=(groups, hw): the next reader of `out` is a GroupNorm with `groups` groups over frames of `hw` rows - when the
+    launch can (vx_gemm_gn_slabs), its epilogue also writes that GroupNorm's partial sums and the returned tensor carries
+    them (`gn_of(out)`), so `groupnorm(out, ...)` skips its statistics pass; otherwise nothing changes."""
     plain = geom is None
     if w_group_rows:
         if w.dim() != 3 or not w.is_contiguous():
@@ -434,7 +470,19 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
             raise ValueError("stats_out must be a contiguous float32 [m, 2] tensor (bf16 output only)")
         if FUSED_STATS[0]:
             p.row_stats_out, p.row_stats_eps = stats_out.data_ptr(), float(stats_eps)
+    gst = None
+    if gn is not None and GN_FUSED[0] and not p.a_fp8:
+        groups, hw = gn
+        p.gn_groups, p.gn_hw = int(groups), int(hw)
+        slabs = int(_lib.vx_gemm_gn_slabs(C.byref(p)))
+        if slabs > 0:
+            frames = p.m // hw
+            gst = GnStats(torch.empty((frames, slabs, groups, 2), device=a.device, dtype=torch.float32), slabs, groups,
+                          frames, hw, n)
+            p.gn_ws = gst.ws.data_ptr()
     _launch_gemm(p, "vx_gemm")
+    if gst is not None:
+        out._vx_gn = gst
     if stats_out is not None and not FUSED_STATS[0]:
         row_stats(out, stats_eps, out=stats_out)       # A/B arm: the separate read pass of round 2
     return out
@@ -515,7 +563,8 @@ def padded_buffer(device, frames, H, W, c):
 def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=None, pad_hw=None):
     """x1: [frames, hw, C1] (+ x2: [frames, hw, C2] channel-concatenated) -> [frames, hw, C1+C2];
     pad_hw=(H, W): -> the zero-bordered image [frames, (H+2)*(W+2), C] (see `padded_buffer`), to be convolved with
-    ConvGeom(frames, H+2, W+2, 3, 3, 1, pad=0)."""
+    ConvGeom(frames, H+2, W+2, 3, 3, 1, pad=0).
+    When the GEMM that produced x1 left its GroupNorm partial sums on the tensor (`gn_of`), only the apply pass runs."""
     _chk_bf16(x1, "x1")
     if not x1.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
         raise ValueError("groupnorm inputs must be contiguous")
@@ -531,6 +580,12 @@ def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=No
     elif out is None:
         out = torch.empty((frames, hw, c1 + c2), device=x1.device, dtype=BF16)
     slices = _gn_slices(hw)
+    st = gn_of(x1) if x2 is None else None
+    if st is not None and st.fits(frames, hw, groups, c1):
+        L.check(_lib.vx_groupnorm_apply(_ptr(x1), c1, None, 0, frames, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
+                                        int(silu), _ptr(out), _ptr(st.ws), st.slabs, slices, width, pad, _stream()),
+                "vx_groupnorm_apply")
+        return out
     ws = torch.empty(int(_lib.vx_groupnorm_ws_floats(frames, slices, groups)), device=x1.device,
                      dtype=torch.float32)
     L.check(_lib.vx_groupnorm(_ptr(x1), c1, _ptr(x2), c2, frames, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
@@ -538,7 +593,8 @@ def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=No
     return out
 
 
-GN_FOLD = [os.environ.get("VX_GN_FOLD", "1") != "0"]
+# (like LN_FOLD: the fold needs the persistent kernel, which needs the FAST addressing the VX_GEMM_NOFAST knob turns off)
+GN_FOLD = [os.environ.get("VX_GN_FOLD", "1") != "0" and os.environ.get("VX_GEMM_NOFAST") is None]
 
 
 def gn_fold_applies(m, hw, c, n):
@@ -556,8 +612,12 @@ def gn_fold_applies(m, hw, c, n):
 
 
 def groupnorm_stats(x1, *, frames, hw, groups, x2=None):
-    """The statistics pass of `groupnorm` alone -> workspace for `groupnorm_fold_linear` (slices as in `groupnorm`)."""
+    """The statistics of `groupnorm` alone -> (workspace, partial sums per frame) for `groupnorm_fold_linear`: the
+    producer's own (`gn_of(x1)`) when it left them, else the statistics pass of `groupnorm`."""
     _chk_bf16(x1, "x1")
+    st = gn_of(x1) if x2 is None else None
+    if st is not None and st.fits(frames, hw, groups, x1.shape[-1]):
+        return st.ws, st.slabs
     if not x1.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
         raise ValueError("groupnorm inputs must be contiguous")
     c1 = x1.shape[-1]
@@ -566,10 +626,10 @@ def groupnorm_stats(x1, *, frames, hw, groups, x2=None):
     ws = torch.empty(int(_lib.vx_groupnorm_ws_floats(frames, slices, groups)), device=x1.device, dtype=torch.float32)
     L.check(_lib.vx_groupnorm_stats(_ptr(x1), c1, _ptr(x2), c2, frames, hw, groups, _ptr(ws), slices, _stream()),
             "vx_groupnorm_stats")
-    return ws
+    return ws, slices
 
 
-def groupnorm_fold_linear(ws, gamma, w, bias_beta, *, frames, hw, groups, eps):
+def groupnorm_fold_linear(ws, gamma, w, bias_beta, *, frames, hw, groups, eps, slices=None):
     """GroupNorm (no activation) folded into the linear layer behind it: -> (w_f bf16 [frames, N, C], b_f float32
     [frames, N]) with GN(x) w^T + b == x w_f[f]^T + b_f[f] on the pixels of frame f; bias_beta = b + w beta (float32,
     weights.fold_groupnorm).  Use: gemm(x, w_f, None, rowbias=b_f, rows_per_group=hw, w_group_rows=hw)."""
@@ -579,7 +639,7 @@ def groupnorm_fold_linear(ws, gamma, w, bias_beta, *, frames, hw, groups, eps):
         raise TypeError("groupnorm_fold_linear: float32 gamma / bias_beta, contiguous bf16 weight expected")
     w_f = torch.empty((frames, n, c), device=w.device, dtype=BF16)
     b_f = torch.empty((frames, n), device=w.device, dtype=torch.float32)
-    L.check(_lib.vx_groupnorm_fold_linear(_ptr(ws), frames, hw, _gn_slices(hw), groups, float(eps), _ptr(gamma), c,
+    L.check(_lib.vx_groupnorm_fold_linear(_ptr(ws), frames, hw, slices or _gn_slices(hw), groups, float(eps), _ptr(gamma), c,
                                           _ptr(w), _ptr(bias_beta), n, _ptr(w_f), _ptr(b_f), _stream()),
             "vx_groupnorm_fold_linear")
     return w_f, b_f

@@ -46,8 +46,11 @@ class VExpressPipeline:
         # when the clip has fewer units than ranks, distributed.choose_frame_shards)
         self.frame_shards = None
         # uneven clips (units % world != 0): frame-shard only the left-over units so that every rank carries the same
-        # load (distributed.MixedUnitSchedule); None = automatic, 1 = never (whole units only, round-2 behaviour)
+        # load (distributed.MixedUnitSchedule); None = automatic, 1 = never (whole units only, round-2 behaviour).  An
+        # explicit frame_shards = 1 ("no frame sharding") also means whole units only unless mixed_shards is set as well.
         self.mixed_shards = None
+        # the schedule the last denoise() call chose (for logs / bench.py): dict(kind, frame_shards, mixed_shards, ...)
+        self.last_schedule = {}
         # batch rows per UNet call: 2 = the two CFG halves of one window; 4 (default), 6, ... also merge consecutive
         # windows of this rank into one call.  Every kernel is batch-invariant, so the rows come out bit-identical;
         # merged calls measure 4-5 % faster (profiles/r02e_host_overhead.json: b = 3 74.0 ms vs 49.2 + 28.2 ms,
@@ -200,8 +203,11 @@ class VExpressPipeline:
         #   mixed: floor(units / world) whole units per rank + the left-over units sharded Sm ways (G = Sm): every rank
         #   then carries the same load (the 20 units of the config-4 clip on 8 GPUs: 2 + 1/2 per rank instead of 3 | 2).
         Sm = 1
-        if S == 1 and dc.enabled and self.mixed_shards != 1:
+        whole_units_only = self.mixed_shards == 1 or (self.frame_shards == 1 and self.mixed_shards is None)
+        if S == 1 and dc.enabled and not whole_units_only:
             Sm = self.mixed_shards or choose_mixed_shards(nW * halves_n, dc.world_size, f, min_hw)
+        self.last_schedule = dict(kind="mixed" if Sm > 1 else ("frame-sharded" if S > 1 else "whole units"),
+                                  frame_shards=S, mixed_shards=Sm, units=nW * halves_n, world=dc.world_size)
         if Sm > 1:
             sched_m = MixedUnitSchedule(nW, dc.world_size, Sm, halves_n)
             G, max_slots, unit_slots = Sm, sched_m.max_slots, sched_m.slots

@@ -259,7 +259,7 @@ class UNet3DConditionModel(_UNetBase):
         skips = [(x, H, W)]
         h_, w_ = H, W
 
-        def layer(p, j, attn, x, skip):
+        def layer(p, j, attn, x, skip, gn_next=False):
             x = B.resnet_block(P[f"{p}.resnets.{j}"], x, frames, h_, w_, groups=g, eps=eps,
                                temb=self._temb(rows, f"{p}.resnets.{j}"), rows_per_group=rpg_scale * h_ * w_,
                                skip=skip, items=b)
@@ -269,15 +269,18 @@ class UNet3DConditionModel(_UNetBase):
                                                bank=[banks[ap][r] for r in rowsel], w_ref=w_ref, w_aud=w_aud,
                                                kv=None if audio_kv is None else audio_kv[ap], audio_zero=audio_zero)
             return B.motion_module(P[f"{p}.motion_modules.{j}"], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g,
-                                   shard=frame_shard)
+                                   shard=frame_shard, gn_next=gn_next)
 
+        # gn_next / gn_groups: the tensor is read next by a GroupNorm over exactly its own channels (a resnet's norm1
+        # without a skip concat, conv_norm_out) - its producer then leaves that GroupNorm's partial sums on it
         for blk in plan["down"]:
             p = blk["prefix"]
+            last = len(blk["layers"]) - 1
             for j, _ in enumerate(blk["layers"]):
-                x = layer(p, j, blk["attn"], x, None)
+                x = layer(p, j, blk["attn"], x, None, gn_next=(j < last or not blk["sampler"]))
                 skips.append((x, h_, w_))
             if blk["sampler"]:
-                x, h_, w_ = B.downsample(P[f"{p}.downsamplers.0"], x, frames, h_, w_)
+                x, h_, w_ = B.downsample(P[f"{p}.downsamplers.0"], x, frames, h_, w_, gn_groups=g)
                 skips.append((x, h_, w_))
         # mid (unet_3d_blocks.py:269-293)
         x = B.resnet_block(P["mid_block.resnets.0"], x, frames, h_, w_, groups=g, eps=eps,
@@ -288,16 +291,18 @@ class UNet3DConditionModel(_UNetBase):
                                        kv=None if audio_kv is None else audio_kv["mid_block.attentions.0"],
                                        audio_zero=audio_zero)
         x = B.motion_module(P["mid_block.motion_modules.0"], x, b=b, f=f, H=h_, W=w_, heads=heads, groups=g,
-                            shard=frame_shard)
+                            shard=frame_shard, gn_next=True)
         x = B.resnet_block(P["mid_block.resnets.1"], x, frames, h_, w_, groups=g, eps=eps,
                            temb=self._temb(rows, "mid_block.resnets.1"), rows_per_group=rpg_scale * h_ * w_, items=b)
-        for blk in plan["up"]:
+        for bi_, blk in enumerate(plan["up"]):
             p = blk["prefix"]
             for j, _ in enumerate(blk["layers"]):
                 skip, sh, sw = skips.pop()
                 if (sh, sw) != (h_, w_):
                     raise RuntimeError("skip resolution mismatch (sample size must be a multiple of 8 latents)")
-                x = layer(p, j, blk["attn"], x, skip)
+                # (up-block resnets normalise the concat [x, skip]: only the very last output meets a plain GroupNorm)
+                x = layer(p, j, blk["attn"], x, skip,
+                          gn_next=(bi_ == len(plan["up"]) - 1 and j == len(blk["layers"]) - 1 and not blk["sampler"]))
             if blk["sampler"]:
                 x, h_, w_ = B.upsample(P[f"{p}.upsamplers.0"], x, frames, h_, w_)
         n = ops.groupnorm(x, P.conv_norm_out.g, P.conv_norm_out.b, frames=frames, hw=hw, groups=g, eps=eps, silu=True,
