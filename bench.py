@@ -59,51 +59,54 @@ def flop_per_frame(num_frames, windows, steps, scale):
     return steps * 2 * fwd * (16 * windows / num_frames) + vae
 
 
-def _pmc_traffic(kernel_key):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (tools/exp_pmc_bench.sh:
+def _lib_sha():
+    from v_express_amd import lib
+    return lib.LIB_SHA256
+
+
+def _pmc_traffic(symbol):
+    """HBM-side bytes per launch of one kernel instantiation from a committed rocprofv3 PMC file (tools/exp_pmc_bench.sh:
     FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; the
-    counter sits on the L2's fabric side, so Infinity-Cache hits are included).  None when no profile is committed."""
+    counter sits on the L2's fabric side, so Infinity-Cache hits are included) - only a file taken with THIS build of the
+    kernel library (its `lib_sha256` equals the loaded library's) is quoted; (None, reason) otherwise."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None, None
-    want = "gemm_ring_kernel<0," if "STORE" in kernel_key else ("gemm_ring_kernel<1," if "GEGLU" in kernel_key else None)
-    if want is None or "gemm_ring" not in kernel_key:
-        return None, None
-    for path in reversed(files):                       # newest profile that actually holds both passes for this kernel
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True)
+    sha = _lib_sha()
+    seen_other = None
+    for path in files:
         with open(path) as f:
             d = json.load(f)
-        n = b = 0.0
-        for k, v in d.items():
-            if want in k and v["launches"] and v["fetch_bytes_per_launch"] > 0:
-                n += v["launches"]
-                b += v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
-        if n:
-            return b / n, os.path.relpath(path, ROOT)
-    return None, None
+        if d.get("lib_sha256") != sha:
+            seen_other = seen_other or os.path.relpath(path, ROOT)
+            continue
+        v = d.get("kernels", {}).get(symbol)
+        if v and v.get("launches") and v.get("fetch_bytes_per_launch", 0) > 0:
+            return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, (f"no counter file for library build {sha}" + (f" (newest other build: {seen_other})" if seen_other else ""))
 
 
-def _rocprof_launch_avg(kernel_key):
-    """Average launch duration of the dominant kernel in the newest committed rocprofv3 kernel-trace summary
-    (profiles/*_trace_summary.txt, written by tools/trace_summary.py from `rocprofv3 --kernel-trace --stats` of this
-    command): the number the HIP-event figure of this run is to be read against (events include ~8 us of event overhead
-    per launch pair, so the event-based fraction is the conservative one).  None when no summary is committed."""
+def _rocprof_launch_avg(symbol):
+    """Average launch duration of one kernel instantiation in a committed rocprofv3 kernel-trace summary
+    (profiles/*_trace_summary.txt, tools/trace_summary.py over `rocprofv3 --kernel-trace --stats` of this command) taken
+    with THIS build of the kernel library (header `# lib_sha256=`): same command + same library = the same launch
+    population, so this run's algorithmic work per launch of the instantiation over that duration is a like-for-like
+    figure without the HIP-event overhead.  None when no summary of this build is committed."""
     import glob
     import re
-    if "gemm_ring" not in kernel_key:
-        return None
-    want = "gemm_ring_kernel<0," if "STORE" in kernel_key else "gemm_ring_kernel<1,"
+    sha = _lib_sha()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_trace_summary.txt")), reverse=True):
-        n = t = 0.0
         with open(path) as f:
-            for ln in f:
-                m = re.search(r"n=\s*(\d+)\s+avg=\s*([0-9.]+) us\s+void gemm_ring_kernel<(\d), (true|false), (true|false)", ln)
-                if m and f"gemm_ring_kernel<{m.group(3)}," == want and m.group(5) == "false":
-                    n += int(m.group(1))
-                    t += int(m.group(1)) * float(m.group(2))
-        if n:
-            return dict(avg_launch_us=t / n, launches=int(n), file=os.path.relpath(path, ROOT))
+            lines = f.read().splitlines()
+        if not lines or f"lib_sha256={sha}" not in lines[0]:
+            continue
+        for ln in lines:
+            m = re.search(r"n=\s*(\d+)\s+avg=\s*([0-9.]+) us\s+void (.*)$", ln)
+            if m and m.group(3).startswith(symbol + "("):
+                return dict(avg_launch_us=float(m.group(2)), launches=int(m.group(1)), file=os.path.relpath(path, ROOT))
     return None
+
+
+HBM_PEAK_GBS = 8000.0              # HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy reaches
 
 
 def _pick_threads():
@@ -322,10 +325,15 @@ def main():
         video = one_clip()
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = None
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+        # every rank's own wall time of the K clips (they leave the last barrier together, so the spread shows up in the
+        # per-rank GPU-busy time below, not here) and the max that defines the reported value
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        rank_ms = [1e3 * t.item() / args.steps for t in allt]
+        elapsed = max(t.item() for t in allt)
     assert video.shape == (1, 3, F, args.size, args.size) and torch.isfinite(video).all()
     fps = F * args.steps / elapsed
     scale = (args.size / 512.0) ** 2
@@ -349,9 +357,35 @@ def main():
                                    (f", {fshards} frame shards per unit" if fshards > 1 else "") +
                                    (f", {2 * len(windows) // world} whole units per GPU + the {2 * len(windows) % world} "
                                     f"left-over units frame-sharded {mshards} ways" if mshards > 1 else ""))},
-        "prologue_ms": 1e3 * prologue_s, "model_build_s": t_build,
+        "prologue_ms": 1e3 * prologue_s, "model_build_s": t_build, "lib_sha256": _lib_sha(),
     }
     if world > 1:
+        # One more clip with every collective of the data path timed (events on the launch stream) and this rank's own
+        # compute time between the collectives: what a first real 8-GPU run needs to be diagnosable from this one line.
+        from v_express_amd.distributed import CommTimer
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with CommTimer() as ct:
+            ev0.record()
+            one_clip()
+            ev1.record()
+        torch.cuda.synchronize()
+        comm = ct.summary()
+        clip_ms = ev0.elapsed_time(ev1)
+        comm_ms = sum(v["ms"] for v in comm.values())
+        mine = torch.tensor([clip_ms, comm_ms], device=dev, dtype=torch.float64)
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        result["per_rank"] = {
+            "ms_per_step_wall": rank_ms, "ms_per_step_min": min(rank_ms), "ms_per_step_max": max(rank_ms),
+            "instrumented_clip_gpu_ms": [t[0].item() for t in allc],
+            "instrumented_clip_collective_ms": [t[1].item() for t in allc],
+            "compute_ms_min": min(t[0].item() - t[1].item() for t in allc),
+            "compute_ms_max": max(t[0].item() - t[1].item() for t in allc),
+            "note": "one extra clip after the timed region; collective_ms includes the wait for the slowest peer"}
+        result["collectives_rank0"] = {k: {"calls": v["calls"], "ms": v["ms"], "mb": v["bytes"] / 1e6,
+                                            "share_of_clip": v["ms"] / clip_ms} for k, v in comm.items()}
+        result["schedule"] = dict(pipe.last_schedule)
         result["collective_backend"] = backend
         if backend != "nccl":
             # VX_DIST_BACKEND=gloo folds ranks onto the visible GPU(s) and stages every collective through the host: it
@@ -366,7 +400,9 @@ def main():
         # (denoise contains the per-timestep all-gather); only rank 0 records and reports.
         import contextlib
         prof = ops.GemmProfile() if rank == 0 else None
-        with (prof if prof is not None else contextlib.nullcontext()):
+        opprof = ops.OpProfile() if rank == 0 else None
+        with (prof if prof is not None else contextlib.nullcontext()), \
+                (opprof if opprof is not None else contextlib.nullcontext()):
             lat = inp["latents"].clone()
             pipe.denoise(lat, kps_tokens, audio, timesteps[:1], windows, 3.5)
             if rank == 0:
@@ -374,6 +410,7 @@ def main():
         torch.cuda.synchronize()
     if rank == 0 and not args.no_roofline:
         summ = prof.summary()
+        syms = prof.by_symbol()
         if args.gemm_shapes:
             with open(args.gemm_shapes, "w") as fsh:
                 for (m_, n_, k_, kern), (cnt, sec, fl) in prof.by_shape().items():
@@ -381,28 +418,53 @@ def main():
                               f"{fl / sec / 1e12:7.1f} TF/s  {kern}\n")
         tot_s = sum(v["seconds"] for v in summ.values())
         tot_f = sum(v["flops"] for v in summ.values())
-        dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
+        # dominant kernel = the ONE instantiation with the most time (pairs with one row of a rocprofv3 trace)
+        dom = max(syms.items(), key=lambda kv: kv[1]["seconds"])
         ach = dom[1]["flops"] / dom[1]["seconds"] / 1e12
         traffic, traffic_src = _pmc_traffic(dom[0])
         rp = _rocprof_launch_avg(dom[0])
         if rp is not None:
-            # same algorithmic work per launch, the profiler's duration instead of the event pair's
+            # this run's algorithmic work per launch of the instantiation / the profiler's duration of the same launches
             rp["achieved"] = dom[1]["flops"] / dom[1]["launches"] / (rp["avg_launch_us"] * 1e-6) / 1e12
             rp["frac"] = rp["achieved"] / PEAK_BF16_TFLOPS
-            rp["note"] = ("committed rocprofv3 --kernel-trace --stats summary of this command on an earlier box; "
-                          "durations without the HIP-event overhead")
+            rp["note"] = ("committed rocprofv3 --kernel-trace --stats summary of this command with this library build "
+                          "(another box); durations without the HIP-event overhead")
+        # the family the instantiation belongs to (all instantiations of the same kernel template and epilogue kind)
+        fam_key = dom[0].split(",")[0]                         # e.g. "gemm_ring_kernel<0"
+        fam = [v for k, v in syms.items() if k.startswith(fam_key + ",")]
+        fam_fl, fam_s, fam_n = sum(v["flops"] for v in fam), sum(v["seconds"] for v in fam), sum(v["launches"] for v in fam)
+        # HBM-bound kernels: achieved GB/s = algorithmic bytes / HIP-event time against 8 TB/s
+        hbm = {}
+        for name, v in opprof.summary().items():
+            hbm[name] = {"launches": v["launches"], "avg_us": 1e6 * v["seconds"] / v["launches"],
+                         "algorithmic_mb_per_launch": v["bytes"] / v["launches"] / 1e6,
+                         "gbs": v["bytes"] / v["seconds"] / 1e9, "frac": v["bytes"] / v["seconds"] / 1e9 / HBM_PEAK_GBS}
+        short = [(shape, t) for shape, t in prof.by_shape().items() if shape[2] <= 640 and shape[0] >= 16384]
+        if short:
+            sb = sum(prof.shape_bytes.get(shape, 0.0) for shape, _ in short)
+            ss = sum(t[1] for _, t in short)
+            sl = sum(t[0] for _, t in short)
+            hbm["gemm K<=640 (M>=16384)"] = {"launches": sl, "avg_us": 1e6 * ss / sl, "algorithmic_mb_per_launch": sb / sl / 1e6,
+                                            "gbs": sb / ss / 1e9, "frac": sb / ss / 1e9 / HBM_PEAK_GBS,
+                                            "tflops": sum(t[2] for _, t in short) / ss / 1e12}
         result["roofline"] = {
             "bound": "mfma", "kernel": dom[0], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / PEAK_BF16_TFLOPS, "frac_source": "HIP events of this run (launch stream)", "rocprof": rp,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": dom[1].get("bytes", 0.0) / max(dom[1]["launches"], 1),
             "avg_launch_us": 1e6 * dom[1]["seconds"] / dom[1]["launches"], "launches": dom[1]["launches"],
+            "family": {"kernels": fam_key + ", ...>", "launches": fam_n, "avg_launch_us": 1e6 * fam_s / fam_n,
+                       "achieved": fam_fl / fam_s / 1e12, "frac": fam_fl / fam_s / 1e12 / PEAK_BF16_TFLOPS},
             "all_gemm_tflops": tot_f / tot_s / 1e12,
             "per_kernel": {k: {"launches": v["launches"], "avg_us": 1e6 * v["seconds"] / v["launches"],
                                "tflops": v["flops"] / v["seconds"] / 1e12,
                                # fp8 launches are priced against the dense fp8 MFMA peak (K incl. the zero padding)
                                "frac_of_peak": v["flops"] / v["seconds"] / 1e12 /
                                (PEAK_FP8_TFLOPS if "fp8" in k else PEAK_BF16_TFLOPS)} for k, v in summ.items()},
+            "per_instantiation": {k: {"launches": v["launches"], "avg_us": 1e6 * v["seconds"] / v["launches"],
+                                      "tflops": v["flops"] / v["seconds"] / 1e12} for k, v in syms.items()},
+            "hbm_kernels": {"peak_gbs": HBM_PEAK_GBS, "note": "algorithmic bytes / HIP-event time of this run; "
+                            "~6300 GB/s is what a streaming copy reaches on this part", "kernels": hbm},
             "whole_path": {"tflop_per_frame": fpf, "achieved": fps * fpf / world, "frac": fps * fpf / world / PEAK_BF16_TFLOPS,
                            "note": "fps x algorithmic TFLOP/frame (SURVEY.md 8d) per GPU / 2.5 PFLOP/s"},
         }

@@ -143,6 +143,10 @@ int vx_gemm_get_ring_mode(void);   /* the mode in force (0 / 1 / 2): callers tha
 int vx_gemm_set_fp8_ring(int on);
 /* name of the tile configuration vx_gemm would launch for p (profiling / roofline reports); thread-local storage */
 const char* vx_gemm_config_name(const vx_gemm_params* p);
+/* the kernel instantiation the LAST vx_gemm call of this thread launched, spelled as rocprofv3 prints it without the
+ * namespace ("gemm_ring_kernel<0, true, false, false, false, true>"): lets bench.py pair its HIP-event figures with the
+ * rows of a committed kernel trace one to one.  "" before the first launch. */
+const char* vx_gemm_last_kernel(void);
 
 /* ---- GroupNorm (+SiLU), per-frame statistics, NHWC, optional dual (concat) source --------------------------
  * Replaces F.group_norm via InflatedGroupNorm (modules/resnet.py:20-28; :220-221,:235,:241), Transformer3DModel.norm

@@ -210,3 +210,85 @@ def test_mixed_schedule_whole_units_plus_sharded_leftovers():
     assert D.MixedUnitSchedule(10, 8, 2).rounds() == 2.5
     with pytest.raises(ValueError):
         D.MixedUnitSchedule(10, 8, 4)
+
+
+def test_subgroup_creation_order_is_identical_on_every_rank_at_world_8(monkeypatch):
+    """`dist.new_group` is collective over the WHOLE world and must be called by every rank in the same order with the
+    same rank lists (the classic RCCL deadlock when a rank skips or reorders one).  Replays, for each of the 8 ranks of
+    the config-4 clip's mixed schedule (and the uniform frame-shard schedules), exactly the `DistContext.frame_shard`
+    calls `VExpressPipeline.denoise` makes, with `dist.new_group` recorded instead of executed."""
+    D = distributed
+    world = 8
+
+    def calls_of(rank, shard_requests):
+        seq = []
+        monkeypatch.setattr(dist, "new_group", lambda ranks: (seq.append(tuple(ranks)), ("grp", tuple(ranks)))[1])
+        dc = D.DistContext(rank, world, None)
+        mine = []
+        for S in shard_requests:
+            fs = dc.frame_shard(S)
+            mine.append(None if fs is None else (fs.index, fs.size, fs.group))
+        return seq, mine
+
+    # mixed schedule of pipeline.denoise: plan_calls = [(whole units, 1), (the shared unit, Sm)] -> frame_shard(1), frame_shard(Sm)
+    for requests in ([1, 2], [1, 4], [2], [4], [8], [2, 2, 4, 2]):
+        seqs = [calls_of(r, requests) for r in range(world)]
+        first = seqs[0][0]
+        for r, (seq, mine) in enumerate(seqs):
+            assert seq == first, f"rank {r} creates its sub-groups in a different order: {seq} vs {first}"
+            for S, got in zip(requests, mine):
+                if S == 1:
+                    assert got is None
+                else:
+                    g0 = (r // S) * S
+                    assert got == (r % S, S, ("grp", tuple(range(g0, g0 + S)))), (r, S, got)
+        # every group of every size is created exactly once, in ascending order of its first rank
+        want = []
+        for S in dict.fromkeys(s for s in requests if s > 1):
+            want += [tuple(range(g * S, (g + 1) * S)) for g in range(world // S)]
+        assert list(first) == want
+
+
+def _worker_groups8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dc = distributed.DistContext.from_env()
+    got = []
+    with distributed.CommTimer() as ct:
+        for S in (1, 2, 4):                                   # the mixed schedule asks for 1 then Sm; 4 = the 5-window clip
+            fs = dc.frame_shard(S)
+            if fs is None:
+                continue
+            b, f_loc, hw, c = 2, 8 // S, 8, 3
+            x = torch.arange(b * f_loc * hw * c, dtype=torch.float32).view(b * f_loc, hw, c) + 1000.0 * rank
+            px = fs.to_pixel_shard(x, b, f_loc)
+            back = fs.to_frame_shard(px, b, f_loc)
+            got.append((S, torch.equal(back, x), tuple(px.shape)))
+        gathered = dc.all_gather_units(torch.full((2, 4), float(rank)), 2)
+    q.put((rank, got, gathered[:, 0, 0].tolist(), {k: v["calls"] for k, v in ct.summary().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_8_sub_groups_and_exchanges_over_gloo():
+    """8 real processes: sub-groups of 2 and 4 consecutive ranks created through DistContext.frame_shard in the order the
+    pipeline uses, a layout round trip through each group's all-to-all, the world-wide all-gather, and CommTimer's
+    bookkeeping (what bench.py --gpus N reports as the collectives' share of a step)."""
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_groups8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, *_ in results) == list(range(world))
+    for rank, got, owners, calls in results:
+        assert got == [(2, True, (2 * 8, 4, 3)), (4, True, (2 * 8, 2, 3))], (rank, got)
+        assert owners == [float(r) for r in range(world)]
+        assert calls == {"all_to_all": 4, "all_gather": 1}, calls

@@ -20,7 +20,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for n in names:
         assert hasattr(so, n), n
-    assert lib.lib.vx_abi_version() == 9
+    assert lib.lib.vx_abi_version() == 10
     assert ctypes.sizeof(lib.GemmParams) % 8 == 0
     # argument validation happens before any launch, so it works without a GPU and never aborts the process
     p = lib.GemmParams()
@@ -280,8 +280,44 @@ def test_bench_algorithmic_flops_match_the_survey_figures():
     assert abs(bench.flop_per_frame(64, 5, 25, 1.0) - 82.3) < 0.05
     assert abs(bench.flop_per_frame(124, 10, 25, 1.0) - 84.9) < 0.05
     assert abs(bench.flop_per_frame(16, 1, 25, 2.25) - 183.8) < 0.1
-    traffic, src = bench._pmc_traffic("gemm_ring_kernel<256x320x64,8w,STORE,fast>")
-    assert traffic and traffic > 1e8 and src.startswith("profiles/")
+
+
+def test_bench_quotes_committed_profiles_only_for_the_loaded_kernel_build(tmp_path, monkeypatch):
+    """bench.py's `roofline.traffic` / `roofline.rocprof` come from files under profiles/ - but only from files that carry
+    the identity of the kernel sources the loaded library was built from (`lib_sha256`); anything else is refused with a
+    reason instead of being quoted next to a live number (the round-3 line mixed two commits)."""
+    import importlib.util
+    import json
+    from v_express_amd import lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vx_bench2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sym = "gemm_ring_kernel<0, true, false, false, false, false>"
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    kernels = {sym: dict(launches=7, fetch_bytes_per_launch=2.0e8, write_bytes_per_launch=0.5e8)}
+    (prof / "r98_pmc_traffic.json").write_text(json.dumps(dict(lib_sha256="0" * 16, kernels=kernels)))
+    (prof / "r98_trace_summary.txt").write_text("# lib_sha256=0000000000000000 command=x\n"
+                                                f"   10.00 ms  5.0% n=   100 avg=    99.0 us  void {sym}(vx_gemm_params)\n")
+    traffic, why = bench._pmc_traffic(sym)
+    assert traffic is None and "no counter file" in why and "r98" in why
+    assert bench._rocprof_launch_avg(sym) is None
+    (prof / "r99_pmc_traffic.json").write_text(json.dumps(dict(lib_sha256=lib.LIB_SHA256, kernels=kernels)))
+    (prof / "r99_trace_summary.txt").write_text(f"# lib_sha256={lib.LIB_SHA256} command=x\n"
+                                                "total kernel time 1.0 ms over 3 launches\n"
+                                                f"   10.00 ms  5.0% n=   100 avg=    80.5 us  void {sym}(vx_gemm_params)\n"
+                                                f"    1.00 ms  0.5% n=    10 avg=    11.0 us  void {sym[:-6]}true>(vx_gemm_params)\n")
+    traffic, src = bench._pmc_traffic(sym)
+    assert traffic == 2.5e8 and src == os.path.join("profiles", "r99_pmc_traffic.json")
+    rp = bench._rocprof_launch_avg(sym)
+    assert rp == dict(avg_launch_us=80.5, launches=100, file=os.path.join("profiles", "r99_trace_summary.txt"))
+    assert bench._pmc_traffic("gemm_ring_kernel<1, false, false, false, true, false>")[0] is None
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "lib_id.py")], capture_output=True, text=True)
+    assert out.stdout.strip() == lib.LIB_SHA256          # the scripts stamp profiles with the value bench.py checks
 
 
 def test_audio_encoder_directory_loader(tmp_path, monkeypatch):
@@ -402,18 +438,6 @@ def test_float16_is_an_io_dtype_and_device_spellings_compare_equal(monkeypatch):
         unet.to("cpu")
 
 
-def test_bench_reads_the_rocprof_side_of_the_roofline_from_the_committed_trace():
-    """bench.py's `roofline.rocprof`: average launch duration of the dominant kernel from the newest committed
-    rocprofv3 kernel-trace summary (both the 3- and the 5-argument spellings of the kernel's template list)."""
-    import bench
-    r = bench._rocprof_launch_avg("gemm_ring_kernel<256x320x64,8w,STORE,fast>")
-    assert r is not None and r["file"].startswith("profiles/") and r["launches"] > 1000
-    assert 40.0 < r["avg_launch_us"] < 200.0
-    g = bench._rocprof_launch_avg("gemm_ring_kernel<256x320x64,8w,GEGLU,fast>")
-    assert g is not None and g["avg_launch_us"] > r["avg_launch_us"]
-    assert bench._rocprof_launch_avg("gemm_kernel<128x160x64,4w,STORE,fast>") is None
-
-
 def test_gelu_tail_polynomial_of_the_kernels_matches_erf_gelu():
     """vx_common.h::gelu_f (round 3): erf GELU as relu(x) - |x| 2^q(|x|) with q a degree-6 polynomial for the base-2
     logarithm of the Gaussian tail.  The coefficients are parsed from the kernel header and evaluated here in float32
@@ -424,11 +448,16 @@ def test_gelu_tail_polynomial_of_the_kernels_matches_erf_gelu():
     from scipy.special import erfc
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "v-express_amd", "csrc", "vx_common.h")).read()
-    body = src[src.index("float gelu_f(float x) {"):src.index("// the Abramowitz-Stegun form")]
+    body = src[src.index("float gelu_f(float x) {"):src.index("// value * gelu(gate) for four (value, gate) pairs")]
     lead = re.search(r"float q = fmaf\(([-0-9.e+]+)f, u, ([-0-9.e+]+)f\);", body)
     rest = re.findall(r"q = fmaf\(q, u, ([-0-9.e+]+)f\);", body)
     coef = [np.float32(lead.group(1)), np.float32(lead.group(2))] + [np.float32(c) for c in rest]
     assert len(coef) == 7 and "fmed3f(fabsf(x), 0.0f, 8.0f)" in body
+    # the packed-FMA A/B form (VX_GELU_PK) carries the same seven coefficients, in Horner order, in its register pairs
+    pk = src[src.index("struct GeluPk {"):src.index("__device__ __forceinline__ void mul2(")]
+    pairs = re.findall(r"[ABCD] = vx_f2\{([-0-9.e+]+)f, ([-0-9.e+]+)f\};", pk)
+    flat = [np.float32(v) for pr in pairs for v in pr]
+    assert len(pairs) == 4 and flat[:7] == coef
     x = np.concatenate([np.linspace(-12, 12, 200001), np.random.default_rng(0).standard_normal(100000) * 3,
                         np.array([0.0, -0.0, 1e-8, -1e-8, 50.0, -50.0, 3e4, -3e4])]).astype(np.float32)
     u = np.minimum(np.abs(x), np.float32(8.0))

@@ -1,4 +1,7 @@
-"""Summarise a rocprofv3 kernel_trace.csv: per-kernel count / total / avg, with template args kept short."""
+"""Summarise a rocprofv3 kernel_trace.csv: per-kernel count / total / avg, with template args kept short.
+    python tools/trace_summary.py kernel_trace.csv [lib_sha256 [command...]]
+The first output line carries the identity of the kernel library the trace was taken with (`# lib_sha256=...`): bench.py
+quotes a committed summary next to a live number only when it matches the library it has loaded."""
 import csv
 import re
 import sys
@@ -14,6 +17,8 @@ with open(sys.argv[1]) as f:
         name = name[:110]
         rows[name][0] += 1
         rows[name][1] += (e - s) * 1e-3
+if len(sys.argv) > 2:
+    print(f"# lib_sha256={sys.argv[2]} command={' '.join(sys.argv[3:])}")
 tot = sum(v[1] for v in rows.values())
 print(f"total kernel time {tot/1e3:.1f} ms over {sum(v[0] for v in rows.values())} launches")
 for k, v in sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]:

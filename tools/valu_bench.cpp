@@ -23,6 +23,26 @@ __global__ void k(float* out, int iters, float seed) {
       if (MODE == 6) asm volatile("v_exp_f16 %0, %0" : "+v"(a[i]));
       if (MODE == 7) asm volatile("v_ldexp_f32 %0, %0, %0" : "+v"(a[i]));
       if (MODE == 8) asm volatile("v_lshl_add_u32 %0, %0, 23, %0" : "+v"(a[i]));
+      // round 4: the GELU polynomial of the GEGLU epilogue is six v_fmaak_f32 (8-byte encoding, 32-bit literal) per
+      // element; as v_pk_fma_f32 over element pairs (coefficients in register pairs, broadcast by op_sel) it is three
+      if (MODE == 10) asm volatile("v_fmaak_f32 %0, %0, %0, 0x3c0464fb" : "+v"(a[i]));
+      if (MODE == 12) asm volatile("v_fma_f32 %0, %0, %0, %1" : "+v"(a[i]) : "s"(seed));
+    }
+    if (MODE == 9 || MODE == 11 || MODE == 13) {
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f2* p2 = reinterpret_cast<f2*>(a);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (MODE == 9) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(p2[i]));
+        if (MODE == 11) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(p2[i]));
+        if (MODE == 13) asm volatile("v_pk_fma_f32 %0, %0, %0, %1 op_sel_hi:[1,1,0]" : "+v"(p2[i]) : "v"(p2[(i + 1) & 3]));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (MODE == 9) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(p2[i]));
+        if (MODE == 11) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(p2[i]));
+        if (MODE == 13) asm volatile("v_pk_fma_f32 %0, %0, %0, %1 op_sel_hi:[1,1,0]" : "+v"(p2[i]) : "v"(p2[(i + 1) & 3]));
+      }
     }
   }
   float s = 0;
@@ -55,5 +75,7 @@ int main() {
   run<0>("v_fma_f32", 8); run<1>("v_exp_f32", 8); run<2>("v_max3_f32", 8); run<3>("v_cvt_pk_bf16_f32", 8);
   run<4>("v_exp_f32 + v_fma_f32 pair", 16); run<5>("v_rcp_f32", 8); run<6>("v_exp_f16", 8); run<7>("v_ldexp_f32", 8);
   run<8>("v_lshl_add_u32", 8);
+  run<10>("v_fmaak_f32 (literal)", 8); run<12>("v_fma_f32 (sgpr operand)", 8);
+  run<9>("v_pk_fma_f32 (2 fma each)", 8); run<13>("v_pk_fma_f32 op_sel bcast", 8); run<11>("v_pk_mul_f32", 8);
   return 0;
 }

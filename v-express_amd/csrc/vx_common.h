@@ -96,6 +96,42 @@ __device__ __forceinline__ float gelu_f(float x) {
 #endif
   return fmaf(-u, __builtin_amdgcn_exp2f(q), relu);
 }
+// value * gelu(gate) for four (value, gate) pairs - the inner step of both GEGLU epilogues.
+// VX_GELU_PK (A/B build, round 4): the degree-6 polynomial runs as v_pk_fma_f32 over element PAIRS - six packed FMAs per two
+// elements instead of six v_fmaak_f32 (8-byte encodings with a 32-bit literal) per element.  The coefficients sit in four
+// register pairs that are made opaque to the compiler (it would re-materialise literal pairs in front of every use) and are
+// broadcast to both halves by op_sel; same arithmetic (fp32 FMA chain in the same order), same bits.
+typedef float vx_f2 __attribute__((ext_vector_type(2)));
+#ifdef VX_GELU_PK
+struct GeluPk {
+  vx_f2 A, B, C, D;   // {c6, c5}, {c4, c3}, {c2, c1}, {c0, -}
+  __device__ __forceinline__ void init() {
+    A = vx_f2{3.309281237e-05f, -7.692196523e-04f};
+    B = vx_f2{8.080716245e-03f, -5.341210216e-02f};
+    C = vx_f2{-4.587709606e-01f, -1.151201725e+00f};
+    D = vx_f2{-9.999930859e-01f, 0.0f};
+    asm volatile("" : "+v"(A), "+v"(B), "+v"(C), "+v"(D));
+  }
+  __device__ __forceinline__ void mul2(float v0, float v1, float g0, float g1, float& o0, float& o1) const {
+    const vx_f2 u = {__builtin_amdgcn_fmed3f(fabsf(g0), 0.0f, 8.0f), __builtin_amdgcn_fmed3f(fabsf(g1), 0.0f, 8.0f)};
+    vx_f2 q;
+    asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(q) : "v"(A), "v"(u));   // c6 u + c5
+    asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,1,0]" : "+v"(q) : "v"(u), "v"(B));                  // q u + c4
+    asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,1]" : "+v"(q) : "v"(u), "v"(B));   // q u + c3
+    asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,1,0]" : "+v"(q) : "v"(u), "v"(C));                  // q u + c2
+    asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,1]" : "+v"(q) : "v"(u), "v"(C));   // q u + c1
+    asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,1,0]" : "+v"(q) : "v"(u), "v"(D));                  // q u + c0
+    float r0, r1;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r0) : "v"(g0));
+    asm("v_max_f32 %0, 0, %1" : "=v"(r1) : "v"(g1));
+    const vx_f2 e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+    const vx_f2 gl = vx_f2{r0, r1} - u * e;
+    const vx_f2 o = vx_f2{v0, v1} * gl;
+    o0 = o.x;
+    o1 = o.y;
+  }
+};
+#endif
 // the Abramowitz-Stegun form (kept for A/B builds: -DVX_GELU_AS)
 __device__ __forceinline__ float gelu_as_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 #ifdef VX_GELU_AS

@@ -684,6 +684,13 @@ int launch_impl(const vx_gemm_params& p, hipStream_t stream) {
   }
   const int nsplit = (EPI == VX_EPI_STORE && p.splitk > 1) ? p.splitk : 1;
   long tiles = (long)ceil_div(p.m, BM) * ceil_div(p.n, BN) * nsplit;
+  static char sym[112] = "";
+  if (!sym[0]) {
+    auto b = [](bool v) { return v ? "true" : "false"; };
+    snprintf(sym, sizeof(sym), "gemm_kernel<%d, %d, %d, %d, %d, %d, %s, %s, %s, %s>", BM, BN, WARPS_M, WARPS_N, STAGES, EPI,
+             b(FAST), b(F8), b(LNF), b(GNS));
+  }
+  g_vx_last_kernel = sym;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(nthreads), smem, stream, p);
   int rc = vx_check_launch("vx_gemm");
   if (rc != 0 || nsplit == 1) return rc;
@@ -779,11 +786,23 @@ bool use_small64(const vx_gemm_params& p) {
 }
 
 // which classic tile a bf16-operand STORE launch gets (the persistent ring kernel is asked first by the callers)
-enum { T_256x32 = 0, T_BIG, T_SMALL64, T_128x160, T_128x128 };
+enum { T_256x32 = 0, T_BIG, T_SMALL64, T_128x160, T_128x128, T_128x320 };
+// VX_GEMM_T128X320=1 (experiment, round 4): the 16x16-level launches (n % 320 == 0, too few 256-row tiles for the big
+// kernels) on a 128 x 320 tile, 8 waves as 2 x 4, one block per CU: 10.9 KB of operands per MFLOP through the CU's L1
+// instead of the 128 x 160 tile's 14.1
+bool use_128x320(const vx_gemm_params& p) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("VX_GEMM_T128X320");
+    on = e && !strcmp(e, "1");
+  }
+  return on && (p.n % 320) == 0 && p.splitk <= 1 && !p.out_f32;
+}
 int store_tile(const vx_gemm_params& p) {
   if (p.n <= 32) return T_256x32;
   if (use_big(p)) return T_BIG;
   if (use_small64(p)) return T_SMALL64;
+  if (use_128x320(p)) return T_128x320;
   if (prefer160(p.n)) return T_128x160;
   return T_128x128;
 }
@@ -813,6 +832,9 @@ extern "C" int vx_gemm_gn_slabs(const vx_gemm_params* pp) {
   return p.gn_hw / 64;
 }
 
+thread_local const char* g_vx_last_kernel = "";
+extern "C" const char* vx_gemm_last_kernel(void) { return g_vx_last_kernel; }
+
 extern "C" int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk) {
   return splitk > 1 ? (int64_t)splitk * m * n * (int64_t)sizeof(float) : 0;
 }
@@ -834,6 +856,7 @@ extern "C" const char* vx_gemm_config_name(const vx_gemm_params* pp) {
   if (p.epi == VX_EPI_STORE && p.n <= 32) tile = "256x32x64,4w";
   else if (use_big(p)) tile = "256x320x64,8w";
   else if (p.epi == VX_EPI_STORE && use_small64(p)) tile = "64x160x64,2w";
+  else if (p.epi == VX_EPI_STORE && use_128x320(p)) tile = "128x320x64,8w";
   else if (p.epi != VX_EPI_GEGLU && prefer160(p.n)) tile = "128x160x64,4w";
   else tile = "128x128x64,4w";
   static thread_local char buf[96];
@@ -922,6 +945,7 @@ static int vx_gemm_dispatch(const vx_gemm_params& p, hipStream_t stream) {
       return launch_gns<128, 160, 2, 2, 2>(p, stream);
     }
     if (tile == T_256x32) return launch<256, 32, 4, 1, 2, VX_EPI_STORE>(p, stream);
+    if (tile == T_128x320) return launch<128, 320, 2, 4, 2, VX_EPI_STORE>(p, stream);
     if (tile == T_BIG) return launch<256, 320, 4, 2, 2, VX_EPI_STORE>(p, stream);
     if (tile == T_SMALL64) return launch<64, 160, 1, 2, 3, VX_EPI_STORE>(p, stream);
     if (tile == T_128x160) {

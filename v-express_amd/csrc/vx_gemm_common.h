@@ -43,6 +43,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// name of the kernel instantiation the last vx_gemm of this thread launched, as rocprofv3 prints it (vx_gemm_last_kernel):
+// set by the launch templates themselves, so it is exact by construction
+extern thread_local const char* g_vx_last_kernel;
+
 // FAST addressing eligibility (see gemm_kernel in vx_gemm.hip)
 bool vx_gemm_fast_ok(const vx_gemm_params& p);
 // persistent ring-staged kernel (vx_gemm_ring.hip)

@@ -35,6 +35,7 @@
 #include "vx_gemm_common.h"
 #include "../../include/vexpress_hip.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -719,6 +720,10 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
       const int ocol_base = (tile_n * R_BN + 80 * wc) / 2 + 4 * (lq & 1);    // + 8 j (+ r)
       const int orow = row_base + 16 * (lane >> 5);                          // + 16 i  (i even)
       bf16_t* __restrict__ outp = (bf16_t*)p.out;
+#ifdef VX_GELU_PK
+      GeluPk gpk;
+      gpk.init();
+#endif
 #pragma unroll
       for (int jp = 0; jp < 5; jp += 2) {
         const int nj = jp + 1 < 5 ? 2 : 1;
@@ -728,6 +733,18 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
 #pragma unroll
           for (int jj = 0; jj < nj; ++jj) {
             float o[4];
+#ifdef VX_GELU_PK
+            float val[4], gat[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][jp + jj][r]),
+                                                         __float_as_uint(acc[i + 1][jp + jj][r]), false, false);
+              val[r] = __uint_as_float(sw[0]);
+              gat[r] = __uint_as_float(sw[1]);
+            }
+            gpk.mul2(val[0], val[1], gat[0], gat[1], o[0], o[1]);
+            gpk.mul2(val[2], val[3], gat[2], gat[3], o[2], o[3]);
+#else
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][jp + jj][r]),
@@ -736,6 +753,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
               const float gat = __uint_as_float(sw[1]);   // (biases were added before the pairing)
               o[r] = val * (RABL(64) ? gat : gelu_f(gat));
             }
+#endif
             pk[jj][0] = pack_bf16x2(o[0], o[1]);
             pk[jj][1] = pack_bf16x2(o[2], o[3]);
           }
@@ -863,6 +881,12 @@ static int ring_launch(const vx_gemm_params& p, hipStream_t stream) {
   }
   const long tiles = (long)(p.m / R_BM) * (p.n / R_BN);
   const unsigned grid = (unsigned)(tiles < g_cu_count ? tiles : g_cu_count);
+  static char sym[96] = "";
+  if (!sym[0]) {
+    auto b = [](bool v) { return v ? "true" : "false"; };
+    snprintf(sym, sizeof(sym), "gemm_ring_kernel<%d, %s, %s, %s, %s, %s>", EPI, b(RES), b(F8), b(STATS), b(LNF), b(GNS));
+  }
+  g_vx_last_kernel = sym;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(R_NT), R_LDS_TOTAL, stream, p);
   return vx_check_launch("vx_gemm(ring)");
 }

@@ -21,6 +21,54 @@ import torch
 import torch.distributed as dist
 
 
+class CommTimer:
+    """Optional timing of every collective of the data path (bench.py --gpus N: the all-gather of a timestep's
+    predictions, the decode's frame gather, the frame-shard all-to-alls): `with CommTimer() as t:` records a pair of
+    events on the current stream around each call; `t.summary()` -> {kind: dict(calls, ms, bytes)}.  Off (no events, no
+    overhead) outside the context."""
+    active = None
+
+    def __init__(self):
+        self.records = []          # (kind, bytes, start_event, end_event)
+
+    def __enter__(self):
+        CommTimer.active = self
+        return self
+
+    def __exit__(self, *a):
+        CommTimer.active = None
+
+    def summary(self):
+        if self.records and self.records[0][2] is not None:
+            torch.cuda.synchronize()
+        out = {}
+        for kind, nbytes, s, e in self.records:
+            d = out.setdefault(kind, dict(calls=0, ms=0.0, bytes=0))
+            d["calls"] += 1
+            d["bytes"] += nbytes
+            if s is not None:
+                d["ms"] += s.elapsed_time(e)
+        return out
+
+
+class _timed_collective:
+    def __init__(self, kind, t):
+        self.t = CommTimer.active
+        self.kind, self.bytes, self.cuda = kind, t.numel() * t.element_size(), t.is_cuda
+
+    def __enter__(self):
+        self.s = self.e = None
+        if self.t is not None and self.cuda:
+            self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if self.t is not None:
+            if self.e is not None:
+                self.e.record()
+            self.t.records.append((self.kind, self.bytes, self.s, self.e))
+
+
 def partition_units(num_windows: int, world_size: int, halves: int = 2) -> List[List[Tuple[int, int]]]:
     """Assignment of the (window, cfg_half) units of one timestep to the ranks (sizes differ by at most one).
 
@@ -201,13 +249,14 @@ class DistContext:
 
     def _all_gather(self, local: torch.Tensor) -> torch.Tensor:
         out = torch.empty((self.world_size,) + tuple(local.shape), device=local.device, dtype=local.dtype)
-        if local.is_cuda and dist.get_backend(self.group) != "nccl":
-            # control-flow testing on a single-GPU box (gloo): stage through the host; never the measured path
-            host = torch.empty(out.shape, dtype=local.dtype)
-            dist.all_gather_into_tensor(host.view(-1), local.detach().cpu().contiguous().view(-1), group=self.group)
-            out.copy_(host)
-            return out
-        dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1), group=self.group)
+        with _timed_collective("all_gather", out):
+            if local.is_cuda and dist.get_backend(self.group) != "nccl":
+                # control-flow testing on a single-GPU box (gloo): stage through the host; never the measured path
+                host = torch.empty(out.shape, dtype=local.dtype)
+                dist.all_gather_into_tensor(host.view(-1), local.detach().cpu().contiguous().view(-1), group=self.group)
+                out.copy_(host)
+            else:
+                dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1), group=self.group)
         return out
 
     def broadcast(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
@@ -263,14 +312,15 @@ class FrameShard:
     def _all_to_all(self, send: torch.Tensor) -> torch.Tensor:
         """send[r] goes to member r; the result's [s] came from member s."""
         recv = torch.empty_like(send)
-        if send.is_cuda and dist.get_backend(self.group) != "nccl":
-            # control-flow testing on a single-GPU box (gloo): stage through the host; never the measured path
-            hs = send.cpu()
-            hr = torch.empty_like(hs)
-            dist.all_to_all_single(hr, hs, group=self.group)
-            recv.copy_(hr)
-            return recv
-        dist.all_to_all_single(recv, send, group=self.group)
+        with _timed_collective("all_to_all", send):
+            if send.is_cuda and dist.get_backend(self.group) != "nccl":
+                # control-flow testing on a single-GPU box (gloo): stage through the host; never the measured path
+                hs = send.cpu()
+                hr = torch.empty_like(hs)
+                dist.all_to_all_single(hr, hs, group=self.group)
+                recv.copy_(hr)
+            else:
+                dist.all_to_all_single(recv, send, group=self.group)
         return recv
 
     def to_pixel_shard(self, x: torch.Tensor, b: int, f_loc: int) -> torch.Tensor:

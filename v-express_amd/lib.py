@@ -84,6 +84,7 @@ def _load():
     lib.vx_gemm.argtypes = [C.POINTER(GemmParams), vp]
     lib.vx_gemm_config_name.argtypes = [C.POINTER(GemmParams)]
     lib.vx_gemm_config_name.restype = C.c_char_p
+    lib.vx_gemm_last_kernel.restype = C.c_char_p
     lib.vx_gemm_splitk_ws_bytes.argtypes = [i32, i32, i32]
     lib.vx_gemm_splitk_ws_bytes.restype = i64
     lib.vx_groupnorm_ws_floats.restype = i64
@@ -117,7 +118,7 @@ def _load():
     for name in declared_symbols():
         fn = getattr(lib, name)
         if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name",
-                        "vx_gemm_splitk_ws_bytes"):
+                        "vx_gemm_splitk_ws_bytes", "vx_gemm_last_kernel"):
             fn.restype = i32
     if lib.vx_abi_version() != 10:
         raise ImportError("libvexpress_hip.so ABI version mismatch")
@@ -125,6 +126,27 @@ def _load():
 
 
 lib = _load()
+
+
+def source_id():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from - csrc/*.hip / *.h / *.cpp and the
+    C ABI header, in name order.  (Of the sources, not of the .so: a rebuild on another machine need not be
+    byte-identical, the sources it was built from are.  tools/lib_id.py prints the same value without importing torch.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) +
+                   glob.glob(os.path.join(CSRC, "*.cpp")) + [os.path.join(CSRC, "Makefile"), HEADER])
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+# identity of the kernel build: measurements committed under profiles/ carry it, and bench.py quotes a committed trace /
+# counter file next to a live number only when it was taken with the SAME kernel sources
+LIB_SHA256 = source_id()
 
 
 class VxError(RuntimeError):

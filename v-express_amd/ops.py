@@ -27,6 +27,7 @@ class GemmProfile:
     def __init__(self):
         self.records = []          # (start_event, end_event, flops, tile_key, shape)
         self.bytes_of = {}         # id(start_event) -> algorithmic bytes of that launch (operands read once + output)
+        self.shape_bytes = {}      # (m, n, k, tile key) -> algorithmic bytes summed over its launches
 
     def __enter__(self):
         GemmProfile.active = self
@@ -38,7 +39,7 @@ class GemmProfile:
     def summary(self):
         torch.cuda.synchronize()
         by = {}
-        for s, e, fl, key, _ in self.records:
+        for s, e, fl, key, _, _ in self.records:
             d = by.setdefault(key, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += s.elapsed_time(e) * 1e-3
@@ -46,16 +47,73 @@ class GemmProfile:
             d[3] += self.bytes_of.get(id(s), 0.0)
         return {k: dict(launches=v[0], seconds=v[1], flops=v[2], bytes=v[3]) for k, v in by.items()}
 
+    def by_symbol(self):
+        """{kernel instantiation as rocprofv3 names it: dict(launches, seconds, flops, bytes)} - pairs one to one with
+        the rows of a committed kernel trace / counter file of the same library build."""
+        torch.cuda.synchronize()
+        by = {}
+        for rec in self.records:
+            s, e, fl, sym = rec[0], rec[1], rec[2], rec[5]
+            d = by.setdefault(sym, dict(launches=0, seconds=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["seconds"] += s.elapsed_time(e) * 1e-3
+            d["flops"] += fl
+            d["bytes"] += self.bytes_of.get(id(s), 0.0)
+        return by
+
     def by_shape(self):
         """{(m, n, k, kernel): [launches, seconds, flops]} sorted by time (tools / tuning)."""
         torch.cuda.synchronize()
         by = {}
-        for s, e, fl, key, shape in self.records:
+        for s, e, fl, key, shape, _ in self.records:
             d = by.setdefault(shape + (key,), [0, 0.0, 0.0])
             d[0] += 1
             d[1] += s.elapsed_time(e) * 1e-3
             d[2] += fl
         return dict(sorted(by.items(), key=lambda kv: -kv[1][1]))
+
+
+class OpProfile:
+    """Optional per-call HIP-event timing of the HBM-bound (non-GEMM) wrappers with their algorithmic bytes - bench.py's
+    `roofline.hbm_kernels` table (achieved GB/s against the 8 TB/s of HBM3E).  Same stream as the launches."""
+    active = None
+
+    def __init__(self):
+        self.records = []          # (name, algorithmic bytes, start_event, end_event)
+
+    def __enter__(self):
+        OpProfile.active = self
+        return self
+
+    def __exit__(self, *a):
+        OpProfile.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        by = {}
+        for name, nbytes, s, e in self.records:
+            d = by.setdefault(name, dict(launches=0, seconds=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["seconds"] += s.elapsed_time(e) * 1e-3
+            d["bytes"] += nbytes
+        return by
+
+
+class _hbm_op:
+    """`with _hbm_op(name, bytes):` around ONE library call (no-op unless an OpProfile is active)."""
+
+    def __init__(self, name, nbytes):
+        self.prof, self.name, self.nbytes = OpProfile.active, name, nbytes
+
+    def __enter__(self):
+        if self.prof is not None:
+            self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if self.prof is not None:
+            self.e.record()
+            self.prof.records.append((self.name, float(self.nbytes), self.s, self.e))
 
 
 def _tile_key(p):
@@ -71,12 +129,16 @@ def _launch_gemm(p, what):
     s.record()
     L.check(_lib.vx_gemm(C.byref(p), _stream()), what)
     e.record()
-    prof.records.append((s, e, 2.0 * p.m * p.n * p.k, _tile_key(p), (p.m, p.n, p.k)))   # fp8: k incl. the zero padding
+    prof.records.append((s, e, 2.0 * p.m * p.n * p.k, _tile_key(p), (p.m, p.n, p.k),     # fp8: k incl. the zero padding
+                         _lib.vx_gemm_last_kernel().decode()))
     # algorithmic bytes: every input row once (c1 + c2 channels), the weights once, the output once, residual once
     rows_in = p.nb * p.h_in * p.w_in
     n_out = p.n // 2 if p.epi == L.VX_EPI_GEGLU else p.n
-    prof.bytes_of[id(s)] = 2.0 * (rows_in * (p.c1 + p.c2) + p.n * p.k + p.m * n_out * (2 if p.out_f32 else 1) +
-                                  (p.m * p.n if p.residual else 0))
+    nbytes = 2.0 * (rows_in * (p.c1 + p.c2) + p.n * p.k + p.m * n_out * (2 if p.out_f32 else 1) +
+                    (p.m * p.n if p.residual else 0))
+    prof.bytes_of[id(s)] = nbytes
+    skey = (p.m, p.n, p.k, prof.records[-1][3])
+    prof.shape_bytes[skey] = prof.shape_bytes.get(skey, 0.0) + nbytes
 
 
 def _ptr(t):
@@ -246,7 +308,8 @@ def row_stats(x, eps=1e-5, out=None):
         out = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
     elif out.dtype != torch.float32 or not out.is_contiguous() or tuple(out.shape) != (rows, 2):
         raise ValueError("row_stats: out must be a contiguous float32 [rows, 2] tensor")
-    L.check(_lib.vx_row_stats(_ptr(x), ldx, rows, x.shape[-1], float(eps), _ptr(out), _stream()), "vx_row_stats")
+    with _hbm_op("row_stats", rows * (2 * x.shape[-1] + 8)):
+        L.check(_lib.vx_row_stats(_ptr(x), ldx, rows, x.shape[-1], float(eps), _ptr(out), _stream()), "vx_row_stats")
     return out
 
 
@@ -581,15 +644,18 @@ def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=No
         out = torch.empty((frames, hw, c1 + c2), device=x1.device, dtype=BF16)
     slices = _gn_slices(hw)
     st = gn_of(x1) if x2 is None else None
+    elems = frames * hw * (c1 + c2)
     if st is not None and st.fits(frames, hw, groups, c1):
-        L.check(_lib.vx_groupnorm_apply(_ptr(x1), c1, None, 0, frames, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
-                                        int(silu), _ptr(out), _ptr(st.ws), st.slabs, slices, width, pad, _stream()),
-                "vx_groupnorm_apply")
+        with _hbm_op("groupnorm_apply", 4 * elems):                     # read 2 B + write 2 B per element
+            L.check(_lib.vx_groupnorm_apply(_ptr(x1), c1, None, 0, frames, hw, groups, float(eps), _ptr(gamma),
+                                            _ptr(beta), int(silu), _ptr(out), _ptr(st.ws), st.slabs, slices, width, pad,
+                                            _stream()), "vx_groupnorm_apply")
         return out
     ws = torch.empty(int(_lib.vx_groupnorm_ws_floats(frames, slices, groups)), device=x1.device,
                      dtype=torch.float32)
-    L.check(_lib.vx_groupnorm(_ptr(x1), c1, _ptr(x2), c2, frames, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
-                              int(silu), _ptr(out), _ptr(ws), slices, width, pad, _stream()), "vx_groupnorm")
+    with _hbm_op("groupnorm_stats+apply", 6 * elems):                   # two reads + one write
+        L.check(_lib.vx_groupnorm(_ptr(x1), c1, _ptr(x2), c2, frames, hw, groups, float(eps), _ptr(gamma), _ptr(beta),
+                                  int(silu), _ptr(out), _ptr(ws), slices, width, pad, _stream()), "vx_groupnorm")
     return out
 
 
@@ -624,8 +690,9 @@ def groupnorm_stats(x1, *, frames, hw, groups, x2=None):
     c2 = x2.shape[-1] if x2 is not None else 0
     slices = _gn_slices(hw)
     ws = torch.empty(int(_lib.vx_groupnorm_ws_floats(frames, slices, groups)), device=x1.device, dtype=torch.float32)
-    L.check(_lib.vx_groupnorm_stats(_ptr(x1), c1, _ptr(x2), c2, frames, hw, groups, _ptr(ws), slices, _stream()),
-            "vx_groupnorm_stats")
+    with _hbm_op("groupnorm_stats", 2 * frames * hw * (c1 + c2)):
+        L.check(_lib.vx_groupnorm_stats(_ptr(x1), c1, _ptr(x2), c2, frames, hw, groups, _ptr(ws), slices, _stream()),
+                "vx_groupnorm_stats")
     return ws, slices
 
 
@@ -651,9 +718,10 @@ def layernorm(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_e
     c = x.shape[-1]
     if out is None:
         out = torch.empty((rows, c), device=x.device, dtype=BF16)
-    L.check(_lib.vx_layernorm(_ptr(x), ldx, rows, c, float(eps), _ptr(gamma), _ptr(beta), _ptr(add),
-                              add_rows_per_entry, add_entries, _ptr(out), _row_stride(out)[0], _stream()),
-            "vx_layernorm")
+    with _hbm_op("layernorm", 4 * rows * c):
+        L.check(_lib.vx_layernorm(_ptr(x), ldx, rows, c, float(eps), _ptr(gamma), _ptr(beta), _ptr(add),
+                                  add_rows_per_entry, add_entries, _ptr(out), _row_stride(out)[0], _stream()),
+                "vx_layernorm")
     return out
 
 
@@ -664,8 +732,9 @@ def key_norm_max(k, *, kv_batches, heads, n_kv, head_dim):
     """float32 [kv_batches * heads]: max over the keys of |k_j| per (kv batch, head) - the Kmax of the bounded softmax."""
     ldk, _ = _row_stride(k)
     out = torch.empty((kv_batches * heads,), device=k.device, dtype=torch.float32)
-    L.check(_lib.vx_key_norm_max(_ptr(k), ldk, kv_batches, heads, n_kv, head_dim, _ptr(out), _stream()),
-            "vx_key_norm_max")
+    with _hbm_op("key_norm_max", 2 * kv_batches * n_kv * heads * head_dim):
+        L.check(_lib.vx_key_norm_max(_ptr(k), ldk, kv_batches, heads, n_kv, head_dim, _ptr(out), _stream()),
+                "vx_key_norm_max")
     return out
 
 
@@ -701,8 +770,9 @@ def temporal_attention(qkv, *, b, f, hw, heads, head_dim, out=None):
         raise ValueError("qkv rows != b*f*hw")
     if out is None:
         out = torch.empty((rows, heads * head_dim), device=qkv.device, dtype=BF16)
-    L.check(_lib.vx_temporal_attention(_ptr(qkv), ld, _ptr(out), _row_stride(out)[0], b, f, hw, heads, head_dim,
-                                       head_dim ** -0.5, _stream()), "vx_temporal_attention")
+    with _hbm_op("temporal_attention", 2 * rows * 4 * heads * head_dim):     # reads q | k | v, writes out (bf16)
+        L.check(_lib.vx_temporal_attention(_ptr(qkv), ld, _ptr(out), _row_stride(out)[0], b, f, hw, heads, head_dim,
+                                           head_dim ** -0.5, _stream()), "vx_temporal_attention")
     return out
 
 
@@ -713,9 +783,10 @@ def small_kv_attention(q, kv, *, batch, n_q, n_kv, heads, head_dim, out=None):
     c = heads * head_dim
     if out is None:
         out = torch.empty((batch * n_q, c), device=q.device, dtype=BF16)
-    L.check(_lib.vx_small_kv_attention(_ptr(q), ldq, _ptr(kv), ldkv, c, _ptr(out), _row_stride(out)[0], batch, n_q,
-                                       n_kv, heads, head_dim, head_dim ** -0.5, _stream()),
-            "vx_small_kv_attention")
+    with _hbm_op("small_kv_attention", 2 * (2 * batch * n_q * c + 2 * batch * n_kv * c)):   # q + out, K | V
+        L.check(_lib.vx_small_kv_attention(_ptr(q), ldq, _ptr(kv), ldkv, c, _ptr(out), _row_stride(out)[0], batch, n_q,
+                                           n_kv, heads, head_dim, head_dim ** -0.5, _stream()),
+                "vx_small_kv_attention")
     return out
 
 
