@@ -401,12 +401,14 @@ def main():
         import contextlib
         prof = ops.GemmProfile() if rank == 0 else None
         opprof = ops.OpProfile() if rank == 0 else None
+        n_dec = min(F, 4)
         with (prof if prof is not None else contextlib.nullcontext()), \
                 (opprof if opprof is not None else contextlib.nullcontext()):
             lat = inp["latents"].clone()
             pipe.denoise(lat, kps_tokens, audio, timesteps[:1], windows, 3.5)
+            n_unet_records = len(prof.records) if prof is not None else 0
             if rank == 0:
-                pipe.vae.decode_video(lat[:, :, :min(F, 4)].contiguous(), chunk=4)
+                pipe.vae.decode_video(lat[:, :, :n_dec].contiguous(), chunk=4)
         torch.cuda.synchronize()
     if rank == 0 and not args.no_roofline:
         summ = prof.summary()
@@ -418,8 +420,15 @@ def main():
                               f"{fl / sec / 1e12:7.1f} TF/s  {kern}\n")
         tot_s = sum(v["seconds"] for v in summ.values())
         tot_f = sum(v["flops"] for v in summ.values())
-        # dominant kernel = the ONE instantiation with the most time (pairs with one row of a rocprofv3 trace)
-        dom = max(syms.items(), key=lambda kv: kv[1]["seconds"])
+        # dominant kernel = the ONE instantiation with the most time over a whole clip (pairs with one row of a rocprofv3
+        # trace): the instrumented leg ran 1 of the clip's DDIM steps and decoded n_dec of its F frames - weight accordingly
+        clip_s = {}
+        for i, rec in enumerate(prof.records):
+            wgt = float(args.ddim_steps) if i < n_unet_records else F / float(n_dec)
+            clip_s[rec[5]] = clip_s.get(rec[5], 0.0) + wgt * rec[0].elapsed_time(rec[1]) * 1e-3
+        dom_sym = max(clip_s.items(), key=lambda kv: kv[1])[0]
+        dom = (dom_sym, syms[dom_sym])
+        clip_total = sum(clip_s.values())
         ach = dom[1]["flops"] / dom[1]["seconds"] / 1e12
         traffic, traffic_src = _pmc_traffic(dom[0])
         rp = _rocprof_launch_avg(dom[0])
@@ -453,6 +462,7 @@ def main():
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": dom[1].get("bytes", 0.0) / max(dom[1]["launches"], 1),
             "avg_launch_us": 1e6 * dom[1]["seconds"] / dom[1]["launches"], "launches": dom[1]["launches"],
+            "share_of_clip_gemm_time": clip_s[dom_sym] / clip_total,
             "family": {"kernels": fam_key + ", ...>", "launches": fam_n, "avg_launch_us": 1e6 * fam_s / fam_n,
                        "achieved": fam_fl / fam_s / 1e12, "frac": fam_fl / fam_s / 1e12 / PEAK_BF16_TFLOPS},
             "all_gemm_tflops": tot_f / tot_s / 1e12,

@@ -248,6 +248,14 @@ def test_fullsize_two_overlapping_windows_one_merged_call_vs_reference_golden(fu
     # one call per window (b = 2) instead of the merged b = 4 call: same bits
     lat2, trace2 = _run_f28(pipe, inp, 2, spy=(calls2 := []))
     assert [b for b, _ in calls2] == [2] * (2 * steps)
+    # (diagnostic first: the raw UNet outputs of step 1, window by window, then the latents)
+    merged = calls[0][1].view(4, -1)
+    for wi in range(2):
+        sep = calls2[wi][1].view(2, -1)
+        same = torch.equal(sep, merged[2 * wi:2 * wi + 2])
+        print(f"[F28] step 1, window {wi}: b = 2 call vs rows of the b = 4 call: {'bit-identical' if same else 'DIFFERENT'}"
+              f" (max |diff| {(sep - merged[2 * wi:2 * wi + 2]).abs().max().item():.3g})")
+        assert same, f"window {wi}: the merged b = 4 call is not bit-identical to the b = 2 call"
     assert torch.equal(lat2, lat4) and torch.equal(trace2[0], trace4[0])
 
 

@@ -760,8 +760,8 @@ def test_groupnorm_folded_into_linear(ops, frames, hw, c, n):
     ref = ref @ w.float().t() + bias
     with ops.frame_rows(hw, items=1):
         assert ops.gn_fold_applies(frames * hw, hw, c, n)
-        ws = ops.groupnorm_stats(x, frames=frames, hw=hw, groups=groups)
-        w_f, b_f = ops.groupnorm_fold_linear(ws, G.g, G.w, G.bb, frames=frames, hw=hw, groups=groups, eps=eps)
+        ws, sl = ops.groupnorm_stats(x, frames=frames, hw=hw, groups=groups)
+        w_f, b_f = ops.groupnorm_fold_linear(ws, G.g, G.w, G.bb, frames=frames, hw=hw, groups=groups, eps=eps, slices=sl)
         st = torch.empty((frames * hw, 2), device="cuda")
         with ops.GemmProfile() as prof:
             out = ops.gemm(x.view(frames * hw, c), w_f, None, rowbias=b_f, rows_per_group=hw, w_group_rows=hw,
@@ -782,8 +782,8 @@ def test_groupnorm_folded_into_linear(ops, frames, hw, c, n):
     half = frames // 2
     with ops.frame_rows(hw, items=1):
         if ops.gn_fold_applies(half * hw, hw, c, n):
-            ws2 = ops.groupnorm_stats(x[:half], frames=half, hw=hw, groups=groups)
-            w2, b2 = ops.groupnorm_fold_linear(ws2, G.g, G.w, G.bb, frames=half, hw=hw, groups=groups, eps=eps)
+            ws2, sl2 = ops.groupnorm_stats(x[:half], frames=half, hw=hw, groups=groups)
+            w2, b2 = ops.groupnorm_fold_linear(ws2, G.g, G.w, G.bb, frames=half, hw=hw, groups=groups, eps=eps, slices=sl2)
             o2 = ops.gemm(x[:half].reshape(half * hw, c), w2, None, rowbias=b2, rows_per_group=hw, w_group_rows=hw)
             assert torch.equal(o2, out[:half * hw])
 
@@ -882,6 +882,14 @@ def test_gemm_gn_partial_sums_classic_tiles(ops, frames, hw, n, k, res):
     assert torch.equal(out, base)
     st = _gn_check(ops, out, frames, hw, 32, f"classic {frames}x{hw}x{n}x{k}")
     assert st.slabs == hw // 64
+    # twice the batch (at the 16x16 level that is enough rows for the 256 x 320 tile, which writes no partial sums): the
+    # request keeps the launch on the 128 x 160 tile, so the first half of the doubled launch gives the same bits
+    a2 = torch.cat([a, rnd(m, k, seed=11)], dim=0)
+    r2 = None if r is None else torch.cat([r, rnd(m, n, seed=12)], dim=0)
+    with ops.frame_rows(hw, items=4 if frames % 2 == 0 else 2):
+        out2 = ops.gemm(a2, w, bias, residual=r2, alpha=0.9, gn=(32, hw))
+    st2 = ops.gn_of(out2)
+    assert st2 is not None and torch.equal(out2[:m], out) and torch.equal(st2.ws[:frames], st.ws)
 
 
 def test_gemm_gn_partial_sums_downsample_conv_and_refusals(ops):

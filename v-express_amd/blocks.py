@@ -130,14 +130,33 @@ def _norm_proj_in(P, x, frames, hw, groups, stats_out=None):
 
 def _feed_forward(P, h, stats=None):
     """h += FF(LN(h)): GEGLU fused in the first GEMM's epilogue (with the LayerNorm folded into that GEMM when the
-    weights carry the fold), residual in the second's.  stats: the row statistics of h when its producer emitted them."""
+    weights carry the fold), residual in the second's.  stats: the row statistics of h when its producer emitted them.
+    ops.FF_SLAB_BYTES: the [rows, 4C] GEGLU result of a whole launch (335 MB at the 64x64 level) is larger than the 256 MB
+    Infinity Cache, so the second GEMM re-reads all of it from HBM; run in row slabs whose intermediate fits, each slab's
+    second GEMM right behind its first, it reads what the first just wrote.  Rows are independent: same bits."""
     F = P.get("ln_ff")
-    if F is not None and ops.LN_FOLD[0]:
-        g = ops.geglu(h, F.w, F.b, ln=(stats if stats is not None else ops.row_stats(h), F.s))
-    else:
-        ln = ops.layernorm(h, P.norm3.g if "norm3" in P else P.ff_norm.g, P.norm3.b if "norm3" in P else P.ff_norm.b)
-        g = ops.geglu(ln, P.ff.w1, P.ff.b1)
-    ops.gemm(g, P.ff.out.w, P.ff.out.b, residual=h, out=h)
+    fold = F is not None and ops.LN_FOLD[0]
+    m, c = h.shape
+    n_hidden = (F.w if fold else P.ff.w1).shape[0] // 2
+    slabs = 1
+    if ops.FF_SLAB_BYTES[0] > 0:
+        # whole 256-row tiles per slab and, when the launches run on the persistent kernel, at least one tile per CU in
+        # the narrower (second) GEMM: slab rows = a multiple of 256 * 256 / (c / 320)
+        unit = 256 * max(1, 256 // max(1, c // 320))
+        want = -(-(m * n_hidden * 2) // ops.FF_SLAB_BYTES[0])
+        while slabs < want and m % (2 * slabs * unit) == 0:
+            slabs *= 2
+    if fold and stats is None:
+        stats = ops.row_stats(h)
+    rows = m // slabs
+    for i in range(slabs):
+        hs = h[i * rows:(i + 1) * rows]
+        if fold:
+            g = ops.geglu(hs, F.w, F.b, ln=(stats[i * rows:(i + 1) * rows], F.s))
+        else:
+            ln = ops.layernorm(hs, P.norm3.g if "norm3" in P else P.ff_norm.g, P.norm3.b if "norm3" in P else P.ff_norm.b)
+            g = ops.geglu(ln, P.ff.w1, P.ff.b1)
+        ops.gemm(g, P.ff.out.w, P.ff.out.b, residual=hs, out=hs)
 
 
 def audio_kv(P, ehs):

@@ -798,8 +798,13 @@ bool use_128x320(const vx_gemm_params& p) {
   }
   return on && (p.n % 320) == 0 && p.splitk <= 1 && !p.out_f32;
 }
-int store_tile(const vx_gemm_params& p) {
+// gn: the launch is asked for GroupNorm partial sums (vx_gemm_params.gn_ws).  Only the 64-row-per-wave 64 x 160 and
+// 128 x 160 tiles produce them, and WHETHER a launch produces them must not depend on how many frames share it (the sums
+// then come from a differently grouped statistics pass: other bits) - so a request for them takes the launch off the
+// 256 x 320 tile, whose use depends on the row count.
+int store_tile(const vx_gemm_params& p, bool gn = false) {
   if (p.n <= 32) return T_256x32;
+  if (gn && (p.n % 160) == 0) return use_small64(p) ? T_SMALL64 : T_128x160;
   if (use_big(p)) return T_BIG;
   if (use_small64(p)) return T_SMALL64;
   if (use_128x320(p)) return T_128x320;
@@ -819,7 +824,7 @@ extern "C" int vx_gemm_gn_slabs(const vx_gemm_params* pp) {
   if (p.gn_groups <= 0 || p.gn_hw <= 0 || p.n <= 0 || (p.n % p.gn_groups) != 0 || (p.m % p.gn_hw) != 0) return 0;
   if (vx_gemm_ring_eligible(p)) return vx_gemm_ring_gn_slabs(p);
   const int cg = p.n / p.gn_groups;
-  const int tile = store_tile(p);
+  const int tile = store_tile(p, true);
   if (tile != T_SMALL64 && tile != T_128x160) return 0;
   static int st128 = -1;
   if (st128 < 0) {
@@ -938,7 +943,7 @@ static int vx_gemm_dispatch(const vx_gemm_params& p, hipStream_t stream) {
                    "accepts (m %% 256, n %% 320, w_group_rows %% 256, plain addressing)", p.w_group_rows);
       return VX_ERR_UNSUPPORTED;
     }
-    const int tile = store_tile(p);
+    const int tile = store_tile(p, p.gn_ws != nullptr);
     if (p.gn_ws != nullptr) {
       // (vx_gemm checked vx_gemm_gn_slabs(p) > 0: only these two tiles produce the partial sums)
       if (tile == T_SMALL64) return launch_gns<64, 160, 1, 2, 3>(p, stream);

@@ -270,6 +270,8 @@ FUSED_STATS = [os.environ.get("VX_FUSED_STATS", "1") != "0"]
 # reference attention - the same rounding placement as the fully computed block - instead of riding in the attn1
 # out-projection's epilogue (blocks._spatial_transformer_read)
 FOLD_ZERO_AUDIO = [True]
+# VX_FF_SLAB_MB (A/B knob, default 0 = whole launches): see blocks._feed_forward
+FF_SLAB_BYTES = [int(float(os.environ.get("VX_FF_SLAB_MB", "0")) * (1 << 20))]
 # VX_GN_FUSED=0 (A/B knob): GroupNorm statistics always come from vx_groupnorm's own read pass
 GN_FUSED = [os.environ.get("VX_GN_FUSED", "1") != "0"]
 
