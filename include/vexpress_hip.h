@@ -148,6 +148,31 @@ const char* vx_gemm_config_name(const vx_gemm_params* p);
  * rows of a committed kernel trace one to one.  "" before the first launch. */
 const char* vx_gemm_last_kernel(void);
 
+/* ---- Fused GEGLU feed-forward of the 64x64 level (round 4 prototype) ---------------------------------------------
+ * out = residual + (value * gelu(gate)) W2^T + bias2,  [value | gate] = LN(x) W1^T + b1   in ONE launch: the [m, 4C]
+ * intermediate of diffusers FeedForward(activation_fn="geglu") (modules/mutual_self_attention.py:247,
+ * modules/motion_module.py:256) never leaves the CU.  C = 320, hidden = 1280 only (x fragments of a 128-row tile live in
+ * registers).  The LayerNorm in front is folded in exactly as vx_gemm_params.ln_stats does it: w1 = the folded,
+ * value/gate-interleaved weight, bias1 / ln_colsum its bias and column sums (float32 [2 hidden], interleaved order),
+ * ln_stats = (mean, rstd) per row.  w1t / w2t = the two weights re-tiled by vx_ff_pack_weights (MFMA-fragment-major:
+ * a 32-channel hidden chunk is one contiguous 40 KB / 20 KB block).  m % 128 == 0. */
+typedef struct {
+  const void* x;             /* bf16 [m, ldx]: the un-normalised rows */
+  int32_t ldx, m, c, hidden;
+  const void* w1t;           /* bf16, vx_ff_pack_weights layout of the [2 hidden, c] interleaved weight */
+  const void* w2t;           /* bf16, vx_ff_pack_weights layout of the [c, hidden] weight */
+  const float* bias1;        /* [2 hidden] or NULL */
+  const float* ln_colsum;    /* [2 hidden] */
+  const float* ln_stats;     /* [m][2] */
+  const float* bias2;        /* [c] or NULL */
+  const void* residual;      /* bf16 [m, ldr] or NULL (may alias out) */
+  int32_t ldr;
+  void* out;                 /* bf16 [m, ldo] */
+  int32_t ldo;
+} vx_ff_params;
+int vx_ff_pack_weights(const void* w1_interleaved, const void* w2, void* w1t, void* w2t, int c, int hidden, void* stream);
+int vx_ff_fused(const vx_ff_params* p, void* stream);
+
 /* ---- GroupNorm (+SiLU), per-frame statistics, NHWC, optional dual (concat) source --------------------------
  * Replaces F.group_norm via InflatedGroupNorm (modules/resnet.py:20-28; :220-221,:235,:241), Transformer3DModel.norm
  * (modules/transformer_3d.py:124), motion-module norm (modules/motion_module.py:156), conv_norm_out + SiLU

@@ -922,3 +922,31 @@ def test_gemm_gn_partial_sums_downsample_conv_and_refusals(ops):
     assert ops._lib.vx_gemm_gn_slabs(p) == 0
     with pytest.raises(L.VxError):
         L.check(ops._lib.vx_gemm(p, ops._stream()), "vx_gemm")
+
+
+@pytest.mark.parametrize("m", [128 * 3, 128 * 600])
+def test_ff_fused_prototype_matches_the_two_launches(ops, m):
+    """vx_ff_fused (round-4 prototype, C = 320): GEGLU feed-forward with the folded LayerNorm and the residual in ONE launch
+    (diffusers FeedForward via modules/mutual_self_attention.py:247) against the product's two vx_gemm launches - the same
+    arithmetic chain in the same order, so all but a few elements agree bit for bit - and against float32 math."""
+    c, hidden = 320, 1280
+    x = rnd(m, c) + 0.3
+    w1 = rnd(2 * hidden, c, scale=c ** -0.5, seed=1)             # (already value / gate interleaved in blocks of 8)
+    w2 = rnd(c, hidden, scale=hidden ** -0.5, seed=2)
+    b1, b2 = rnd(2 * hidden, seed=3, dtype=torch.float32) * 0.3, rnd(c, seed=4, dtype=torch.float32) * 0.3
+    colsum = w1.float().sum(dim=1).contiguous()
+    stats = ops.row_stats(x)
+    g = ops.geglu(x, w1, b1, ln=(stats, colsum))
+    want = ops.gemm(g, w2, b2, residual=x)
+    got = ops.ff_fused(x.clone(), w1, b1, colsum, stats, w2, b2)
+    diff = (got.float() - want.float()).abs()
+    frac = (got != want).float().mean().item()
+    print(f"[ff_fused m={m}] max|diff| vs two launches {diff.max().item():.4g}, differing elements {100 * frac:.3g} %")
+    assert diff.max().item() <= 2 ** -7 * want.float().abs().max().item() and frac < 0.02, (diff.max().item(), frac)
+    xf = x.float()
+    mean, var = xf.mean(dim=1, keepdim=True), xf.var(dim=1, unbiased=False, keepdim=True)
+    p = ((xf - mean) * torch.rsqrt(var + 1e-5)) @ w1.float().t() + b1
+    p = p.view(m, 2 * hidden // 16, 2, 8)
+    h = (p[:, :, 0] * F.gelu(p[:, :, 1])).reshape(m, hidden)
+    ref = xf + h.to(BF).float() @ w2.float().t() + b2
+    check(got, ref, f"ff_fused {m} rows vs float32", rel=8e-3)

@@ -148,6 +148,9 @@ def _feed_forward(P, h, stats=None):
             slabs *= 2
     if fold and stats is None:
         stats = ops.row_stats(h)
+    if fold and ops.ff_fused_applies(m, c, n_hidden):
+        ops.ff_fused(h, F.w, F.b, F.s, stats, P.ff.out.w, P.ff.out.b)      # one launch, no [m, 4C] intermediate
+        return
     rows = m // slabs
     for i in range(slabs):
         hs = h[i * rows:(i + 1) * rows]

@@ -20,6 +20,16 @@ VX_PART_ROWS, VX_PART_VT = 0, 1
 VX_ACT_NONE, VX_ACT_SILU, VX_ACT_GELU = 0, 1, 2
 
 
+class FfParams(C.Structure):
+    """Mirror of `vx_ff_params` (include/vexpress_hip.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int32), ("m", C.c_int32), ("c", C.c_int32), ("hidden", C.c_int32),
+        ("w1t", C.c_void_p), ("w2t", C.c_void_p), ("bias1", C.c_void_p), ("ln_colsum", C.c_void_p),
+        ("ln_stats", C.c_void_p), ("bias2", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int32),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+    ]
+
+
 class GemmParams(C.Structure):
     """Mirror of `vx_gemm_params` (include/vexpress_hip.h)."""
     _fields_ = [
@@ -93,6 +103,8 @@ def _load():
     lib.vx_groupnorm_stats.argtypes = [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp]
     lib.vx_groupnorm_apply.argtypes = [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]
     lib.vx_gemm_gn_slabs.argtypes = [C.POINTER(GemmParams)]
+    lib.vx_ff_fused.argtypes = [C.POINTER(FfParams), vp]
+    lib.vx_ff_pack_weights.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     lib.vx_groupnorm_fold_linear.argtypes = [vp, i32, i32, i32, i32, f32, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.vx_layernorm.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp]
     lib.vx_row_stats.argtypes = [vp, i32, i32, i32, f32, vp, vp]

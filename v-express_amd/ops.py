@@ -411,6 +411,7 @@ def clear_caches():
     _SPLITK_WS.clear()
     _PADDED.clear()
     _FP8_W.clear()
+    _FF_PACKED.clear()
 
 
 _ITEMS = [None]
@@ -565,6 +566,39 @@ def geglu(a, w_interleaved, bias_interleaved, out=None, ln=None):
     _set_ln(p, ln)
     _launch_gemm(p, "vx_gemm(geglu)")
     return out
+
+
+# VX_FF_FUSED=1 (A/B knob, default off): the 64x64-level feed-forward as ONE launch (vx_ff_fused, round-4 prototype)
+FF_FUSED = [os.environ.get("VX_FF_FUSED", "0") == "1"]
+_FF_PACKED = {}
+
+
+def ff_fused_applies(m, c, hidden):
+    return FF_FUSED[0] and c == 320 and hidden == 1280 and m % 128 == 0 and not FP8_PROJ[0]
+
+
+def ff_fused(h, w1_folded, b1, colsum, stats, w2, b2):
+    """h += (value * gelu(gate)) w2^T + b2 with [value | gate] = LN(h) w1^T + b1, LayerNorm folded as in `geglu(ln=...)`;
+    in place on h (rows are independent).  The two weights are re-tiled once per weight tensor (vx_ff_pack_weights)."""
+    _chk_bf16(h, "h")
+    ldx, m = _row_stride(h)
+    c, hidden = h.shape[-1], w2.shape[1]
+    key = (w1_folded.data_ptr(), w2.data_ptr())
+    hit = _FF_PACKED.get(key)
+    if hit is None:
+        w1t, w2t = torch.empty_like(w1_folded), torch.empty_like(w2)
+        L.check(_lib.vx_ff_pack_weights(_ptr(w1_folded), _ptr(w2), _ptr(w1t), _ptr(w2t), c, hidden, _stream()),
+                "vx_ff_pack_weights")
+        hit = _FF_PACKED[key] = (w1_folded, w2, w1t, w2t)          # keep the sources alive: the key is their address
+    p = L.FfParams()
+    p.x, p.ldx, p.m, p.c, p.hidden = h.data_ptr(), ldx, m, c, hidden
+    p.w1t, p.w2t = hit[2].data_ptr(), hit[3].data_ptr()
+    p.bias1 = b1.data_ptr() if b1 is not None else None
+    p.ln_colsum, p.ln_stats = colsum.data_ptr(), stats.data_ptr()
+    p.bias2 = b2.data_ptr() if b2 is not None else None
+    p.residual, p.ldr, p.out, p.ldo = h.data_ptr(), ldx, h.data_ptr(), ldx
+    L.check(_lib.vx_ff_fused(C.byref(p), _stream()), "vx_ff_fused")
+    return h
 
 
 def vt_pitch(n):
