@@ -24,10 +24,11 @@
 #include "../../include/vexpress_hip.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
-constexpr int FF_C = 320, FF_H = 1280, FF_BM = 128, FF_HC = 32, FF_NT = 256;
+constexpr int FF_C = 320, FF_H = 1280, FF_BM = 128, FF_HC = 32;
 constexpr int FF_CHUNKS = FF_H / FF_HC;            // 40
 constexpr int FF_KS = FF_C / 32;                   // 10 k-steps of 32 in stage 1
 constexpr int W1_CHUNK = 2 * FF_HC * FF_C * 2;     // 40960 B: 64 interleaved rows x 320 k
@@ -36,7 +37,15 @@ constexpr int W1_OFF = 0, W2_OFF = 2 * W1_CHUNK, H_OFF = W2_OFF + 2 * W2_CHUNK; 
 constexpr int H_BUF = FF_BM * FF_HC * 2;           // 8192 B
 constexpr int TAB_OFF = H_OFF + 2 * H_BUF;         // 139264: bias1 [2560], colsum [2560], bias2 [320] (fp32)
 constexpr int FF_LDS = TAB_OFF + (2 * FF_H + 2 * FF_H + FF_C) * 4;   // 161024 <= 163840
-constexpr int W1_PER_WAVE = W1_CHUNK / 1024 / 4, W2_PER_WAVE = W2_CHUNK / 1024 / 4;   // 10, 5 copies per wave and chunk
+
+// Compile-time ablation switches (tools/build_ff_variants.sh: one library per mask; the product library is built without):
+//   1 no weight copies inside the chunk loop   2 GEGLU without the GELU (value * gate)   4 no LayerNorm fold / bias
+//   8 no stage-2 MFMAs   16 no stage-1 MFMAs   32 no h round trip through LDS (no write, reads stale)
+#ifdef VX_FF_ABLATE
+#define FABL(bit) (((VX_FF_ABLATE) & (bit)) != 0)
+#else
+#define FABL(bit) false
+#endif
 
 template <int N>
 __device__ __forceinline__ void ff_wait_vm() {
@@ -50,23 +59,30 @@ __device__ __forceinline__ void ff_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-__global__ __launch_bounds__(FF_NT, 1) void ff_fused_kernel(const vx_ff_params p) {
+// MI = 16-row blocks per wave: 4 -> four waves (one per SIMD, up to 512 VGPRs: everything of a chunk has to be interleaved
+// by hand inside ONE instruction stream), 2 -> eight waves as 4 (M) x 2 (N), two per SIMD (<= 256 VGPRs: x 80 + Y 80 +
+// P 16), where the hardware interleaves one wave's MFMAs with its partner's GEGLU arithmetic, LDS waits and copy issue.
+template <int MI>
+__global__ __launch_bounds__(64 * (16 / MI), MI == 4 ? 1 : 2) void ff_fused_kernel(const vx_ff_params p) {
+  constexpr int NW = 16 / MI, NT = 64 * NW;             // waves / threads per workgroup
+  constexpr int W1_BLOCKS = W1_CHUNK / 1024, W2_BLOCKS = W2_CHUNK / 1024;            // 40, 20 one-KiB copies per chunk
+  constexpr int W1_PER_WAVE = (W1_BLOCKS + NW - 1) / NW, W2_PER_WAVE = (W2_BLOCKS + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 1, wn = wave & 1;              // wave = rows 16 MI wm .., columns: half wn
   const int lrow = lane & 15, lq = lane >> 4;
   const uint32_t lds0 = lds_addr_of(smem);
   const uint32_t lane16 = (uint32_t)lane * 16u;
 
   // ---- tables: bias1 | colsum | bias2 (fp32) once per workgroup
   {
-    float* tab = reinterpret_cast<float*>(smem + TAB_OFF);
-    for (int i = tid; i < 2 * FF_H; i += FF_NT) {
-      tab[i] = p.bias1 != nullptr ? p.bias1[i] : 0.f;
-      tab[2 * FF_H + i] = p.ln_colsum[i];
+    float* tabw = reinterpret_cast<float*>(smem + TAB_OFF);
+    for (int i = tid; i < 2 * FF_H; i += NT) {
+      tabw[i] = p.bias1 != nullptr ? p.bias1[i] : 0.f;
+      tabw[2 * FF_H + i] = p.ln_colsum[i];
     }
-    for (int i = tid; i < FF_C; i += FF_NT) tab[4 * FF_H + i] = p.bias2 != nullptr ? p.bias2[i] : 0.f;
+    for (int i = tid; i < FF_C; i += NT) tabw[4 * FF_H + i] = p.bias2 != nullptr ? p.bias2[i] : 0.f;
   }
   __syncthreads();
 
@@ -76,9 +92,8 @@ __global__ __launch_bounds__(FF_NT, 1) void ff_fused_kernel(const vx_ff_params p
   const char* __restrict__ w1t = (const char*)p.w1t;
   const char* __restrict__ w2t = (const char*)p.w2t;
 
-  // weight stream: global chunk counter g (chunk = g % 40, ring buffer = g & 1); this wave copies blocks wave, wave + 4, ...
-  // One copy per call, spread over the k-steps of stage 1 (a burst of 15 back-to-back copies stalls the issuing wave -
-  // the only wave of its SIMD - for ~1000 cycles; profiles/r01d_dma_ingest_microbench.txt: 4 issuing waves = 72 GB/s).
+  // weight stream: global chunk counter g (chunk = g % 40, ring buffer = g & 1); this wave copies blocks wave, wave + NW, ...
+  // one copy per call, spread over the k-steps of stage 1 (a burst of back-to-back copies stalls the issuing wave)
   const char* w1src = nullptr;
   const char* w2src = nullptr;
   uint32_t w1dst = 0, w2dst = 0;
@@ -88,8 +103,15 @@ __global__ __launch_bounds__(FF_NT, 1) void ff_fused_kernel(const vx_ff_params p
     w2src = w2t + (size_t)(g % FF_CHUNKS) * W2_CHUNK + wave * 1024;
     w2dst = lds0 + W2_OFF + (g & 1) * W2_CHUNK + wave * 1024;
   };
-  auto issue_w1 = [&](int q) { glds16_s(w1src + q * 4096, lane16, w1dst + q * 4096); };
-  auto issue_w2 = [&](int q) { glds16_s(w2src + q * 4096, lane16, w2dst + q * 4096); };
+  bool in_loop = false;
+  auto issue_w1 = [&](int q) {
+    if (FABL(1) && in_loop) return;
+    if (wave + NW * q < W1_BLOCKS) glds16_s(w1src + q * (NW * 1024), lane16, w1dst + q * (NW * 1024));
+  };
+  auto issue_w2 = [&](int q) {
+    if (FABL(1) && in_loop) return;
+    if (wave + NW * q < W2_BLOCKS) glds16_s(w2src + q * (NW * 1024), lane16, w2dst + q * (NW * 1024));
+  };
   // prologue: W1(0)
   {
     w1src = w1t + wave * 1024;
@@ -102,13 +124,14 @@ __global__ __launch_bounds__(FF_NT, 1) void ff_fused_kernel(const vx_ff_params p
   const float2* __restrict__ st = reinterpret_cast<const float2*>(p.ln_stats);
   const float* tab = reinterpret_cast<const float*>(smem + TAB_OFF);
   int g = 0;
+  in_loop = true;
   for (int ti = 0; ti < my_tiles; ++ti) {
-    const int m0 = ((int)blockIdx.x + ti * G) * FF_BM + 64 * wm;   // first row of this wave
-    // ---- x fragments of the wave's 64 rows (second MFMA operand: lane = row lrow, k group lq) and their LayerNorm scalars
-    uint4 xa[4][FF_KS];
-    float rs[4], rm[4];
+    const int m0 = ((int)blockIdx.x + ti * G) * FF_BM + 16 * MI * wm;   // first row of this wave
+    // ---- x fragments of the wave's rows (second MFMA operand: lane = row lrow, k group lq) and their LayerNorm scalars
+    uint4 xa[MI][FF_KS];
+    float rs[MI], rm[MI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const bf16_t* row = x + (size_t)(m0 + 16 * i + lrow) * p.ldx + 8 * lq;
 #pragma unroll
       for (int ks = 0; ks < FF_KS; ++ks) xa[i][ks] = *reinterpret_cast<const uint4*>(row + 32 * ks);
@@ -116,27 +139,31 @@ __global__ __launch_bounds__(FF_NT, 1) void ff_fused_kernel(const vx_ff_params p
       rs[i] = t.y;
       rm[i] = -t.x * t.y;
     }
-    f32x4_t Y[4][10];
+    f32x4_t Y[MI][10];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 10; ++j) Y[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // stage 2 of chunk (g - 1): Y[64 rows, 160 columns] += h W2c^T, as five groups of 8 MFMAs (two column blocks each)
-    // that the caller interleaves with the GEGLU arithmetic of chunk g (independent work for the VALU beside the MFMAs)
-    uint4 ha[4];
+    // stage 2 of chunk (g - 1): Y[16 MI rows, 160 columns] += h W2c^T, as five groups of two column blocks that the
+    // caller interleaves with the GEGLU arithmetic of chunk g
+    uint4 ha[MI];
     const char* w2b = nullptr;
     auto stage2_begin = [&](int gp) {
-      const char* hr = smem + H_OFF + (gp & 1) * H_BUF + (4 * wm) * 1024 + lane * 16;
+      const char* hr = smem + H_OFF + (gp & 1) * H_BUF + (MI * wm) * 1024 + lane * 16;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ha[i] = *reinterpret_cast<const uint4*>(hr + i * 1024);
+      for (int i = 0; i < MI; ++i) ha[i] = *reinterpret_cast<const uint4*>(hr + i * 1024);
       w2b = smem + W2_OFF + (gp & 1) * W2_CHUNK + (10 * wn) * 1024 + lane * 16;
     };
     auto stage2_group = [&](int jg) {      // column blocks 2 jg, 2 jg + 1
       const uint4 bw0 = *reinterpret_cast<const uint4*>(w2b + (2 * jg) * 1024);
       const uint4 bw1 = *reinterpret_cast<const uint4*>(w2b + (2 * jg + 1) * 1024);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MI; ++i) {
+        if (FABL(8)) {
+          asm volatile("" ::"v"(bw0.x), "v"(bw1.x), "v"(ha[i].x));
+          continue;
+        }
         Y[i][2 * jg] = mfma16(bw0, ha[i], Y[i][2 * jg]);
         Y[i][2 * jg + 1] = mfma16(bw1, ha[i], Y[i][2 * jg + 1]);
       }
@@ -145,47 +172,23 @@ __global__ __launch_bounds__(FF_NT, 1) void ff_fused_kernel(const vx_ff_params p
     for (int c = 0; c < FF_CHUNKS; ++c, ++g) {
       // W1(g) [issued during iteration g - 1] and W2(g - 1) landed; h(g - 1) written by every wave; everyone is done with
       // the buffers this iteration's copies refill (W1 ring slot of g - 1, W2 ring slot of g - 2).  The weights are
-      // L2-resident (2.4 MB, every CU streams the same bytes), so one chunk (~2500 cycles) of lookahead covers the copies.
+      // L2-resident (2.4 MB, every CU streams the same bytes), so one chunk of lookahead covers the copies.
       ff_wait_vm<0>();
       ff_barrier();
       stream_setup(g);
-      // ------------------------------------------------ stage 1: P[64 rows, 32 interleaved columns] = x W1c^T
       const char* w1b = smem + W1_OFF + (g & 1) * W1_CHUNK + (2 * wn) * 1024 + lane * 16;
-      f32x4_t P[4][2];
+      f32x4_t P[MI][2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) P[i][0] = P[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      uint4 bq[3][2];      // W1 fragments, read two k-steps ahead of their MFMAs
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        bq[d][0] = *reinterpret_cast<const uint4*>(w1b + d * 4096);
-        bq[d][1] = *reinterpret_cast<const uint4*>(w1b + d * 4096 + 1024);
-      }
-#pragma unroll
-      for (int ks = 0; ks < FF_KS; ++ks) {
-        if (ks + 2 < FF_KS) {
-          bq[(ks + 2) % 3][0] = *reinterpret_cast<const uint4*>(w1b + (ks + 2) * 4096);
-          bq[(ks + 2) % 3][1] = *reinterpret_cast<const uint4*>(w1b + (ks + 2) * 4096 + 1024);
-        }
-        issue_w1(ks);                       // one copy of W1(g + 1) per k-step ...
-        if ((ks & 1) == 0) issue_w2(ks >> 1);   // ... and one of W2(g) every other
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          P[i][0] = mfma16(bq[ks % 3][0], xa[i][ks], P[i][0]);
-          P[i][1] = mfma16(bq[ks % 3][1], xa[i][ks], P[i][1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ------------------------------------------------ folded LayerNorm + bias, GEGLU, h -> LDS (A-fragment-major),
-      // interleaved with stage 2 of the previous chunk
+      for (int i = 0; i < MI; ++i) P[i][0] = P[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       const bool prev = c > 0;
-      if (prev) stage2_begin(g - 1);
       char* hb = smem + H_OFF + (g & 1) * H_BUF;
       auto ln_fold = [&](int jj) {
+        if (FABL(4)) return;
         const int col = 64 * c + 16 * (2 * wn + jj) + 4 * lq;      // interleaved W1 row of this lane's 4 columns
         const float4 b4 = *reinterpret_cast<const float4*>(tab + col);
         const float4 s4 = *reinterpret_cast<const float4*>(tab + 2 * FF_H + col);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
           P[i][jj][0] = fmaf(rs[i], P[i][jj][0], fmaf(rm[i], s4.x, b4.x));
           P[i][jj][1] = fmaf(rs[i], P[i][jj][1], fmaf(rm[i], s4.y, b4.y));
           P[i][jj][2] = fmaf(rs[i], P[i][jj][2], fmaf(rm[i], s4.z, b4.z));
@@ -200,24 +203,71 @@ __global__ __launch_bounds__(FF_NT, 1) void ff_fused_kernel(const vx_ff_params p
           // 0-31 have value AND gate of row block 2 ip, lanes 32-63 those of row block 2 ip + 1
           auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(P[2 * ip][jj][r]),
                                                      __float_as_uint(P[2 * ip + 1][jj][r]), false, false);
-          o[r] = __uint_as_float(sw[0]) * gelu_f(__uint_as_float(sw[1]));
+          o[r] = __uint_as_float(sw[0]) * (FABL(2) ? __uint_as_float(sw[1]) : gelu_f(__uint_as_float(sw[1])));
         }
-        const int I = 4 * wm + 2 * ip + (lane >> 5);                 // 16-row block of the tile
+        const int I = MI * wm + 2 * ip + (lane >> 5);                // 16-row block of the tile
+        if (FABL(32)) {
+          asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+          return;
+        }
         *reinterpret_cast<uint2*>(hb + I * 1024 + ((2 * wn + jj) * 16 + lrow) * 16 + (lq & 1) * 8) =
             make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
       };
-      // five groups of 8 MFMAs of the previous chunk's stage 2 between the six arithmetic blocks of this chunk's GEGLU
-      ln_fold(0);
-      if (prev) stage2_group(0);
-      gelu_block(0, 0);
-      if (prev) stage2_group(1);
-      gelu_block(0, 1);
-      if (prev) stage2_group(2);
+      auto s1_mfma = [&](int jj, int ks, const uint4& bfrag) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (FABL(16)) {
+            asm volatile("" ::"v"(bfrag.x), "v"(xa[i][ks].x));
+            continue;
+          }
+          P[i][jj] = mfma16(bfrag, xa[i][ks], P[i][jj]);
+        }
+      };
+      // Three MFMA segments per iteration, each carrying one share of the other work (with one wave per SIMD VALU work only
+      // overlaps the matrix pipe when it sits BETWEEN this wave's own MFMAs; with two the partner wave helps as well):
+      //   (a) columns 0-15 of P over the 10 k-steps            + the weight copies of this iteration
+      //   (b) columns 16-31 of P                               + LayerNorm fold / GEGLU / h write of columns 0-15
+      //   (c) stage 2 of the previous chunk                    + LayerNorm fold / GEGLU / h write of columns 16-31
+      {
+        uint4 bq[3];      // W1 fragments of column block 0, read two k-steps ahead of their MFMAs
+        bq[0] = *reinterpret_cast<const uint4*>(w1b);
+        bq[1] = *reinterpret_cast<const uint4*>(w1b + 4096);
+#pragma unroll
+        for (int ks = 0; ks < FF_KS; ++ks) {
+          if (ks + 2 < FF_KS) bq[(ks + 2) % 3] = *reinterpret_cast<const uint4*>(w1b + (ks + 2) * 4096);
+          if (NW == 4) {
+            issue_w1(ks);                            // one copy of W1(g + 1) per k-step ...
+            if ((ks & 1) == 0) issue_w2(ks >> 1);    // ... and one of W2(g) every other
+          } else {
+            if ((ks & 1) == 0) issue_w1(ks >> 1);    // five copies of W1(g + 1) per wave ...
+            else if ((ks >> 1) < W2_PER_WAVE) issue_w2(ks >> 1);   // ... and up to three of W2(g)
+          }
+          s1_mfma(0, ks, bq[ks % 3]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      {
+        uint4 bq[3];
+        bq[0] = *reinterpret_cast<const uint4*>(w1b + 1024);
+        bq[1] = *reinterpret_cast<const uint4*>(w1b + 4096 + 1024);
+#pragma unroll
+        for (int ks = 0; ks < FF_KS; ++ks) {
+          if (ks + 2 < FF_KS) bq[(ks + 2) % 3] = *reinterpret_cast<const uint4*>(w1b + (ks + 2) * 4096 + 1024);
+          s1_mfma(1, ks, bq[ks % 3]);
+          if (ks == 0) ln_fold(0);
+          if (ks == 3) gelu_block(0, 0);
+          if (MI == 4 && ks == 6) gelu_block(0, MI == 4 ? 1 : 0);
+        }
+      }
+      if (prev) stage2_begin(g - 1);
       ln_fold(1);
-      if (prev) stage2_group(3);
+      if (prev) stage2_group(0);
+      if (prev) stage2_group(1);
       gelu_block(1, 0);
+      if (prev) stage2_group(2);
+      if (prev) stage2_group(3);
+      if (MI == 4) gelu_block(1, MI == 4 ? 1 : 0);
       if (prev) stage2_group(4);
-      gelu_block(1, 1);
     }
     // ---- stage 2 of the tile's last chunk
     ff_wait_vm<0>();
@@ -229,20 +279,20 @@ __global__ __launch_bounds__(FF_NT, 1) void ff_fused_kernel(const vx_ff_params p
     // ---------------------------------------------------- epilogue: out = x + Y + b2   (8-byte stores, C^T fragments)
     const bf16_t* __restrict__ res = (const bf16_t*)p.residual;
     bf16_t* __restrict__ out = (bf16_t*)p.out;
-    // all 40 residual loads of the lane first (the x fragments are dead: registers are free), then the arithmetic and the
+    // all residual loads of the lane first (the x fragments are dead: registers are free), then the arithmetic and the
     // stores - a load -> use -> store chain per item would drain the store queue at every step (vmcnt counts stores too)
-    uint2 rv[4][10];
+    uint2 rv[MI][10];
 #pragma unroll
     for (int j = 0; j < 10; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
         rv[i][j] = *reinterpret_cast<const uint2*>(res + (size_t)(m0 + 16 * i + lrow) * p.ldr + 160 * wn + 16 * j + 4 * lq);
 #pragma unroll
     for (int j = 0; j < 10; ++j) {
       const int col = 160 * wn + 16 * j + 4 * lq;
       const float4 b4 = *reinterpret_cast<const float4*>(tab + 4 * FF_H + col);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MI; ++i) {
         const size_t row = (size_t)(m0 + 16 * i + lrow);
         const uint2 r2 = rv[i][j];
         const float v0 = Y[i][j][0] + b4.x + __uint_as_float(r2.x << 16);
@@ -294,9 +344,14 @@ extern "C" int vx_ff_fused(const vx_ff_params* pp, void* stream_) {
   VX_REQUIRE(p.m > 0 && (p.m % FF_BM) == 0, "vx_ff_fused: m=%d must be a multiple of %d", p.m, FF_BM);
   VX_REQUIRE((p.ldx % 8) == 0 && (p.ldo % 4) == 0 && (p.ldr % 4) == 0, "vx_ff_fused: row strides");
   static bool attr_set = false;
-  static int cus = 256;
+  static int cus = 256, four_waves = 0;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)ff_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+    // VX_FF_WAVES=4 (A/B knob): the four-wave, one-per-SIMD form; default: eight waves
+    const char* ev = getenv("VX_FF_WAVES");
+    four_waves = ev && atoi(ev) == 4;
+    hipError_t e = hipFuncSetAttribute((const void*)ff_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)ff_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
     if (e != hipSuccess) {
       vx_set_error("vx_ff_fused: hipFuncSetAttribute(%d B LDS) failed: %s", FF_LDS, hipGetErrorString(e));
       return VX_ERR_HIP;
@@ -308,6 +363,9 @@ extern "C" int vx_ff_fused(const vx_ff_params* pp, void* stream_) {
     attr_set = true;
   }
   const int tiles = p.m / FF_BM;
-  hipLaunchKernelGGL(ff_fused_kernel, dim3(tiles < cus ? tiles : cus), dim3(FF_NT), FF_LDS, (hipStream_t)stream_, p);
+  if (four_waves)
+    hipLaunchKernelGGL(ff_fused_kernel<4>, dim3(tiles < cus ? tiles : cus), dim3(256), FF_LDS, (hipStream_t)stream_, p);
+  else
+    hipLaunchKernelGGL(ff_fused_kernel<2>, dim3(tiles < cus ? tiles : cus), dim3(512), FF_LDS, (hipStream_t)stream_, p);
   return vx_check_launch("vx_ff_fused");
 }
