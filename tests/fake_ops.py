@@ -227,6 +227,12 @@ def geglu(a, w_interleaved, bias_interleaved, out=None, ln=None):
     return r
 
 
+def ff_fused(h, w1_folded, b1, colsum, stats, w2, b2):
+    """vx_ff_fused = the two launches it replaces, in place on h (the kernel is bit-identical to them on the GPU)."""
+    g = geglu(h, w1_folded, b1, ln=(stats, colsum))
+    return gemm(g, w2, b2, residual=h, out=h)
+
+
 def alloc_vt(seqs, heads, head_dim, n, device):
     return torch.zeros((seqs, heads, head_dim, (n + 7) // 8 * 8), device=device, dtype=BF16)
 
@@ -357,7 +363,7 @@ def vae_postprocess(x, n, c, h, w):
     return (x[:, :c].float().reshape(n, h, w, c).permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1).contiguous()
 
 
-ALL = ("wave_conv1d", "groupnorm", "groupnorm_stats", "groupnorm_fold_linear", "layernorm", "row_stats", "layernorm_fp8", "quantize_fp8", "gemm", "geglu", "alloc_vt", "gemm_split", "key_norm_max", "attention",
+ALL = ("wave_conv1d", "groupnorm", "groupnorm_stats", "groupnorm_fold_linear", "layernorm", "row_stats", "layernorm_fp8", "quantize_fp8", "gemm", "geglu", "ff_fused", "alloc_vt", "gemm_split", "key_norm_max", "attention",
        "temporal_attention", "small_kv_attention", "add_row_bias", "gather_latents", "cfg_combine", "pack_rows", "combine_units", "overlap_ddim_step",
        "ncfhw_to_nhwc", "nhwc_to_ncfhw", "vae_postprocess")
 

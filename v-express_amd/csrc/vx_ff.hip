@@ -41,11 +41,22 @@ constexpr int FF_LDS = TAB_OFF + (2 * FF_H + 2 * FF_H + FF_C) * 4;   // 161024 <
 // Compile-time ablation switches (tools/build_ff_variants.sh: one library per mask; the product library is built without):
 //   1 no weight copies inside the chunk loop   2 GEGLU without the GELU (value * gate)   4 no LayerNorm fold / bias
 //   8 no stage-2 MFMAs   16 no stage-1 MFMAs   32 no h round trip through LDS (no write, reads stale)
+//   64 no LDS fragment reads at all (weights / h fragments are whatever the registers hold)   128 no barrier / copy wait
 #ifdef VX_FF_ABLATE
 #define FABL(bit) (((VX_FF_ABLATE) & (bit)) != 0)
 #else
 #define FABL(bit) false
 #endif
+// experiment knobs (tools/build_ff_variants.sh): VX_FF_PF = k-steps the W1 fragment reads run ahead of their MFMAs
+// (product 2), VX_FF_NOSB = no scheduling barrier between the k-steps of segment (a)
+#ifndef VX_FF_PF
+#define VX_FF_PF 2
+#endif
+
+__device__ __forceinline__ uint4 ff_frag(const char* p) {
+  if (FABL(64)) return make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+  return *reinterpret_cast<const uint4*>(p);
+}
 
 template <int N>
 __device__ __forceinline__ void ff_wait_vm() {
@@ -152,12 +163,12 @@ __global__ __launch_bounds__(64 * (16 / MI), MI == 4 ? 1 : 2) void ff_fused_kern
     auto stage2_begin = [&](int gp) {
       const char* hr = smem + H_OFF + (gp & 1) * H_BUF + (MI * wm) * 1024 + lane * 16;
 #pragma unroll
-      for (int i = 0; i < MI; ++i) ha[i] = *reinterpret_cast<const uint4*>(hr + i * 1024);
+      for (int i = 0; i < MI; ++i) ha[i] = ff_frag(hr + i * 1024);
       w2b = smem + W2_OFF + (gp & 1) * W2_CHUNK + (10 * wn) * 1024 + lane * 16;
     };
     auto stage2_group = [&](int jg) {      // column blocks 2 jg, 2 jg + 1
-      const uint4 bw0 = *reinterpret_cast<const uint4*>(w2b + (2 * jg) * 1024);
-      const uint4 bw1 = *reinterpret_cast<const uint4*>(w2b + (2 * jg + 1) * 1024);
+      const uint4 bw0 = ff_frag(w2b + (2 * jg) * 1024);
+      const uint4 bw1 = ff_frag(w2b + (2 * jg + 1) * 1024);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         if (FABL(8)) {
@@ -173,8 +184,10 @@ __global__ __launch_bounds__(64 * (16 / MI), MI == 4 ? 1 : 2) void ff_fused_kern
       // W1(g) [issued during iteration g - 1] and W2(g - 1) landed; h(g - 1) written by every wave; everyone is done with
       // the buffers this iteration's copies refill (W1 ring slot of g - 1, W2 ring slot of g - 2).  The weights are
       // L2-resident (2.4 MB, every CU streams the same bytes), so one chunk of lookahead covers the copies.
-      ff_wait_vm<0>();
-      ff_barrier();
+      if (!FABL(128)) {
+        ff_wait_vm<0>();
+        ff_barrier();
+      }
       stream_setup(g);
       const char* w1b = smem + W1_OFF + (g & 1) * W1_CHUNK + (2 * wn) * 1024 + lane * 16;
       f32x4_t P[MI][2];
@@ -229,12 +242,13 @@ __global__ __launch_bounds__(64 * (16 / MI), MI == 4 ? 1 : 2) void ff_fused_kern
       //   (b) columns 16-31 of P                               + LayerNorm fold / GEGLU / h write of columns 0-15
       //   (c) stage 2 of the previous chunk                    + LayerNorm fold / GEGLU / h write of columns 16-31
       {
-        uint4 bq[3];      // W1 fragments of column block 0, read two k-steps ahead of their MFMAs
-        bq[0] = *reinterpret_cast<const uint4*>(w1b);
-        bq[1] = *reinterpret_cast<const uint4*>(w1b + 4096);
+        constexpr int PF = VX_FF_PF;
+        uint4 bq[PF + 1];      // W1 fragments of column block 0, read PF k-steps ahead of their MFMAs
+#pragma unroll
+        for (int d = 0; d < PF; ++d) bq[d] = ff_frag(w1b + d * 4096);
 #pragma unroll
         for (int ks = 0; ks < FF_KS; ++ks) {
-          if (ks + 2 < FF_KS) bq[(ks + 2) % 3] = *reinterpret_cast<const uint4*>(w1b + (ks + 2) * 4096);
+          if (ks + PF < FF_KS) bq[(ks + PF) % (PF + 1)] = ff_frag(w1b + (ks + PF) * 4096);
           if (NW == 4) {
             issue_w1(ks);                            // one copy of W1(g + 1) per k-step ...
             if ((ks & 1) == 0) issue_w2(ks >> 1);    // ... and one of W2(g) every other
@@ -242,18 +256,21 @@ __global__ __launch_bounds__(64 * (16 / MI), MI == 4 ? 1 : 2) void ff_fused_kern
             if ((ks & 1) == 0) issue_w1(ks >> 1);    // five copies of W1(g + 1) per wave ...
             else if ((ks >> 1) < W2_PER_WAVE) issue_w2(ks >> 1);   // ... and up to three of W2(g)
           }
-          s1_mfma(0, ks, bq[ks % 3]);
+          s1_mfma(0, ks, bq[ks % (PF + 1)]);
+#ifndef VX_FF_NOSB
           __builtin_amdgcn_sched_barrier(0);
+#endif
         }
       }
       {
-        uint4 bq[3];
-        bq[0] = *reinterpret_cast<const uint4*>(w1b + 1024);
-        bq[1] = *reinterpret_cast<const uint4*>(w1b + 4096 + 1024);
+        constexpr int PF = VX_FF_PF;
+        uint4 bq[PF + 1];
+#pragma unroll
+        for (int d = 0; d < PF; ++d) bq[d] = ff_frag(w1b + d * 4096 + 1024);
 #pragma unroll
         for (int ks = 0; ks < FF_KS; ++ks) {
-          if (ks + 2 < FF_KS) bq[(ks + 2) % 3] = *reinterpret_cast<const uint4*>(w1b + (ks + 2) * 4096 + 1024);
-          s1_mfma(1, ks, bq[ks % 3]);
+          if (ks + PF < FF_KS) bq[(ks + PF) % (PF + 1)] = ff_frag(w1b + (ks + PF) * 4096 + 1024);
+          s1_mfma(1, ks, bq[ks % (PF + 1)]);
           if (ks == 0) ln_fold(0);
           if (ks == 3) gelu_block(0, 0);
           if (MI == 4 && ks == 6) gelu_block(0, MI == 4 ? 1 : 0);
