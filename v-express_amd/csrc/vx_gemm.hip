@@ -786,7 +786,18 @@ bool use_small64(const vx_gemm_params& p) {
 }
 
 // which classic tile a bf16-operand STORE launch gets (the persistent ring kernel is asked first by the callers)
-enum { T_256x32 = 0, T_BIG, T_SMALL64, T_128x160, T_128x128, T_128x320 };
+enum { T_256x32 = 0, T_BIG, T_SMALL64, T_128x160, T_128x128, T_128x320, T_256x256 };
+// 256 x 256 tile, 8 waves as 4 x 2 (wave 64 x 128), one block per CU: the VAE decoder's 256- and 512-channel convolutions
+// (M = 65536 ... 1048576 rows): 7.8 KB of operands per MFLOP through the CU's L1 instead of the 128 x 128 tile's 15.6.
+// VX_GEMM_T256X256=0 keeps them on the 128 x 128 tile (A/B knob).
+bool use_256x256(const vx_gemm_params& p) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("VX_GEMM_T256X256");
+    on = !(e && !strcmp(e, "0"));
+  }
+  return on && (p.n % 256) == 0 && p.n <= 1024 && p.splitk <= 1 && !p.out_f32 && (long)ceil_div(p.m, 256) * (p.n / 256) >= 256;
+}
 // VX_GEMM_T128X320=1 (experiment, round 4): the 16x16-level launches (n % 320 == 0, too few 256-row tiles for the big
 // kernels) on a 128 x 320 tile, 8 waves as 2 x 4, one block per CU: 10.9 KB of operands per MFLOP through the CU's L1
 // instead of the 128 x 160 tile's 14.1
@@ -809,6 +820,7 @@ int store_tile(const vx_gemm_params& p, bool gn = false) {
   if (use_small64(p)) return T_SMALL64;
   if (use_128x320(p)) return T_128x320;
   if (prefer160(p.n)) return T_128x160;
+  if (use_256x256(p)) return T_256x256;
   return T_128x128;
 }
 
@@ -862,6 +874,7 @@ extern "C" const char* vx_gemm_config_name(const vx_gemm_params* pp) {
   else if (use_big(p)) tile = "256x320x64,8w";
   else if (p.epi == VX_EPI_STORE && use_small64(p)) tile = "64x160x64,2w";
   else if (p.epi == VX_EPI_STORE && use_128x320(p)) tile = "128x320x64,8w";
+  else if (p.epi == VX_EPI_STORE && !prefer160(p.n) && use_256x256(p)) tile = "256x256x64,8w";
   else if (p.epi != VX_EPI_GEGLU && prefer160(p.n)) tile = "128x160x64,4w";
   else tile = "128x128x64,4w";
   static thread_local char buf[96];
@@ -951,6 +964,7 @@ static int vx_gemm_dispatch(const vx_gemm_params& p, hipStream_t stream) {
     }
     if (tile == T_256x32) return launch<256, 32, 4, 1, 2, VX_EPI_STORE>(p, stream);
     if (tile == T_128x320) return launch<128, 320, 2, 4, 2, VX_EPI_STORE>(p, stream);
+    if (tile == T_256x256) return launch<256, 256, 4, 2, 2, VX_EPI_STORE>(p, stream);
     if (tile == T_BIG) return launch<256, 320, 4, 2, 2, VX_EPI_STORE>(p, stream);
     if (tile == T_SMALL64) return launch<64, 160, 1, 2, 3, VX_EPI_STORE>(p, stream);
     if (tile == T_128x160) {
