@@ -52,6 +52,15 @@ constexpr int FF_LDS = TAB_OFF + (2 * FF_H + 2 * FF_H + FF_C) * 4;   // 161024 <
 #ifndef VX_FF_PF
 #define VX_FF_PF 2
 #endif
+// VX_FF_S2SPLIT = 1: the eight-wave form runs stage 2 as 2 (M) x 4 (N) (wave = 64 rows x 80 columns: 9 fragment reads per
+// chunk instead of 12 - the kernel is bound by its LDS fragment reads, profiles/r04e_*);  VX_FF_XPF = 1: the next tile's x
+// fragments are loaded before the tail of the current tile (stage 2 of the last chunk + epilogue) instead of after it
+#ifndef VX_FF_S2SPLIT
+#define VX_FF_S2SPLIT 1
+#endif
+#ifndef VX_FF_XPF
+#define VX_FF_XPF 1
+#endif
 
 __device__ __forceinline__ uint4 ff_frag(const char* p) {
   if (FABL(64)) return make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
@@ -136,47 +145,60 @@ __global__ __launch_bounds__(64 * (16 / MI), MI == 4 ? 1 : 2) void ff_fused_kern
   const float* tab = reinterpret_cast<const float*>(smem + TAB_OFF);
   int g = 0;
   in_loop = true;
-  for (int ti = 0; ti < my_tiles; ++ti) {
-    const int m0 = ((int)blockIdx.x + ti * G) * FF_BM + 16 * MI * wm;   // first row of this wave
-    // ---- x fragments of the wave's rows (second MFMA operand: lane = row lrow, k group lq) and their LayerNorm scalars
-    uint4 xa[MI][FF_KS];
-    float rs[MI], rm[MI];
+  // stage-2 / epilogue ownership: like stage 1 (rows 16 MI wm, columns 160 wn), or - eight waves - 2 (M) x 4 (N)
+  constexpr bool S24 = (MI == 2) && (VX_FF_S2SPLIT != 0);
+  constexpr int SMI = S24 ? 4 : MI, SNJ = S24 ? 5 : 10;
+  const int s2_row0 = S24 ? 64 * (wave >> 2) : 16 * MI * wm;
+  const int s2_col0 = S24 ? 80 * (wave & 3) : 160 * wn;
+  // ---- x fragments of the wave's rows (second MFMA operand: lane = row lrow, k group lq) and their LayerNorm scalars
+  uint4 xa[MI][FF_KS];
+  float rs[MI], rm[MI];
+  auto load_x = [&](int ti) {
+    const int r0 = ((int)blockIdx.x + ti * G) * FF_BM + 16 * MI * wm;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      const bf16_t* row = x + (size_t)(m0 + 16 * i + lrow) * p.ldx + 8 * lq;
+      const bf16_t* row = x + (size_t)(r0 + 16 * i + lrow) * p.ldx + 8 * lq;
 #pragma unroll
       for (int ks = 0; ks < FF_KS; ++ks) xa[i][ks] = *reinterpret_cast<const uint4*>(row + 32 * ks);
-      const float2 t = st[m0 + 16 * i + lrow];
+      const float2 t = st[r0 + 16 * i + lrow];
       rs[i] = t.y;
       rm[i] = -t.x * t.y;
     }
-    f32x4_t Y[MI][10];
+  };
+  constexpr bool XPF = (VX_FF_XPF != 0) && MI == 2;   // (the four-wave form has no registers to spare)
+  if (XPF) load_x(0);
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    const int tile0 = ((int)blockIdx.x + ti * G) * FF_BM;    // first row of the tile
+    if (!XPF) load_x(ti);
+    f32x4_t Y[SMI][SNJ];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < SMI; ++i)
 #pragma unroll
-      for (int j = 0; j < 10; ++j) Y[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < SNJ; ++j) Y[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // stage 2 of chunk (g - 1): Y[16 MI rows, 160 columns] += h W2c^T, as five groups of two column blocks that the
-    // caller interleaves with the GEGLU arithmetic of chunk g
-    uint4 ha[MI];
+    // stage 2 of chunk (g - 1): Y += h W2c^T, as five groups of SMI * SNJ / 5 MFMAs that the caller interleaves with the GEGLU
+    // arithmetic of chunk g
+    uint4 ha[SMI];
     const char* w2b = nullptr;
     auto stage2_begin = [&](int gp) {
-      const char* hr = smem + H_OFF + (gp & 1) * H_BUF + (MI * wm) * 1024 + lane * 16;
+      const char* hr = smem + H_OFF + (gp & 1) * H_BUF + (s2_row0 >> 4) * 1024 + lane * 16;
 #pragma unroll
-      for (int i = 0; i < MI; ++i) ha[i] = ff_frag(hr + i * 1024);
-      w2b = smem + W2_OFF + (gp & 1) * W2_CHUNK + (10 * wn) * 1024 + lane * 16;
+      for (int i = 0; i < SMI; ++i) ha[i] = ff_frag(hr + i * 1024);
+      w2b = smem + W2_OFF + (gp & 1) * W2_CHUNK + (s2_col0 >> 4) * 1024 + lane * 16;
     };
-    auto stage2_group = [&](int jg) {      // column blocks 2 jg, 2 jg + 1
-      const uint4 bw0 = ff_frag(w2b + (2 * jg) * 1024);
-      const uint4 bw1 = ff_frag(w2b + (2 * jg + 1) * 1024);
+    auto stage2_group = [&](int jg) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        if (FABL(8)) {
-          asm volatile("" ::"v"(bw0.x), "v"(bw1.x), "v"(ha[i].x));
-          continue;
+      for (int jj = 0; jj < SNJ / 5; ++jj) {
+        const int j = jg * (SNJ / 5) + jj;
+        const uint4 bw = ff_frag(w2b + j * 1024);
+#pragma unroll
+        for (int i = 0; i < SMI; ++i) {
+          if (FABL(8)) {
+            asm volatile("" ::"v"(bw.x), "v"(ha[i].x));
+            continue;
+          }
+          Y[i][j] = mfma16(bw, ha[i], Y[i][j]);
         }
-        Y[i][2 * jg] = mfma16(bw0, ha[i], Y[i][2 * jg]);
-        Y[i][2 * jg + 1] = mfma16(bw1, ha[i], Y[i][2 * jg + 1]);
       }
     };
 
@@ -286,9 +308,11 @@ __global__ __launch_bounds__(64 * (16 / MI), MI == 4 ? 1 : 2) void ff_fused_kern
       if (MI == 4) gelu_block(1, MI == 4 ? 1 : 0);
       if (prev) stage2_group(4);
     }
-    // ---- stage 2 of the tile's last chunk
-    ff_wait_vm<0>();
-    ff_barrier();
+    // ---- the next tile's x fragments (the registers are free from here on), then stage 2 of the tile's last chunk
+    // (the copy wait comes FIRST: vmcnt retires in order, a wait behind the x loads would wait for them as well)
+    if (!FABL(128)) ff_wait_vm<0>();
+    if (XPF && ti + 1 < my_tiles) load_x(ti + 1);
+    if (!FABL(128)) ff_barrier();
     stage2_begin(g - 1);
 #pragma unroll
     for (int jg = 0; jg < 5; ++jg) stage2_group(jg);
@@ -296,20 +320,21 @@ __global__ __launch_bounds__(64 * (16 / MI), MI == 4 ? 1 : 2) void ff_fused_kern
     // ---------------------------------------------------- epilogue: out = x + Y + b2   (8-byte stores, C^T fragments)
     const bf16_t* __restrict__ res = (const bf16_t*)p.residual;
     bf16_t* __restrict__ out = (bf16_t*)p.out;
-    // all residual loads of the lane first (the x fragments are dead: registers are free), then the arithmetic and the
-    // stores - a load -> use -> store chain per item would drain the store queue at every step (vmcnt counts stores too)
-    uint2 rv[MI][10];
+    const int m0 = tile0 + s2_row0;
+    // all residual loads of the lane first, then the arithmetic and the stores - a load -> use -> store chain per item
+    // would drain the store queue at every step (vmcnt counts stores too)
+    uint2 rv[SMI][SNJ];
 #pragma unroll
-    for (int j = 0; j < 10; ++j)
+    for (int j = 0; j < SNJ; ++j)
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
-        rv[i][j] = *reinterpret_cast<const uint2*>(res + (size_t)(m0 + 16 * i + lrow) * p.ldr + 160 * wn + 16 * j + 4 * lq);
+      for (int i = 0; i < SMI; ++i)
+        rv[i][j] = *reinterpret_cast<const uint2*>(res + (size_t)(m0 + 16 * i + lrow) * p.ldr + s2_col0 + 16 * j + 4 * lq);
 #pragma unroll
-    for (int j = 0; j < 10; ++j) {
-      const int col = 160 * wn + 16 * j + 4 * lq;
+    for (int j = 0; j < SNJ; ++j) {
+      const int col = s2_col0 + 16 * j + 4 * lq;
       const float4 b4 = *reinterpret_cast<const float4*>(tab + 4 * FF_H + col);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
+      for (int i = 0; i < SMI; ++i) {
         const size_t row = (size_t)(m0 + 16 * i + lrow);
         const uint2 r2 = rv[i][j];
         const float v0 = Y[i][j][0] + b4.x + __uint_as_float(r2.x << 16);
