@@ -106,9 +106,22 @@ __global__ __launch_bounds__(64 * (16 / MI), MI == 4 ? 1 : 2) void ff_fused_kern
   }
   __syncthreads();
 
+  // tile walk: XCD x (= block id % 8) owns the contiguous x-th eighth of the 128-row tiles, like the GEMM and attention
+  // kernels around this one (vx_gemm_ring.hip, VX_XCD_ROWS): the rows this kernel reads were written on the same XCD
   const int n_tiles = p.m / FF_BM;
   const int G = gridDim.x;
-  const int my_tiles = (n_tiles - (int)blockIdx.x + G - 1) / G;
+#if VX_XCD_ROWS
+  const int nxcd = G < 8 ? G : 8;
+  const int xcd = (int)blockIdx.x % nxcd, xidx = (int)blockIdx.x / nxcd;
+  const int tstride = (G - xcd + nxcd - 1) / nxcd;
+  const int t0 = (int)((long)n_tiles * xcd / nxcd), t1 = (int)((long)n_tiles * (xcd + 1) / nxcd);
+  const int tfirst = t0 + xidx;
+  const int my_tiles = tfirst < t1 ? (t1 - tfirst + tstride - 1) / tstride : 0;
+  if (my_tiles <= 0) return;
+#else
+  const int tstride = G, tfirst = (int)blockIdx.x;
+  const int my_tiles = (n_tiles - tfirst + G - 1) / G;
+#endif
   const char* __restrict__ w1t = (const char*)p.w1t;
   const char* __restrict__ w2t = (const char*)p.w2t;
 
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(64 * (16 / MI), MI == 4 ? 1 : 2) void ff_fused_kern
   uint4 xa[MI][FF_KS];
   float rs[MI], rm[MI];
   auto load_x = [&](int ti) {
-    const int r0 = ((int)blockIdx.x + ti * G) * FF_BM + 16 * MI * wm;
+    const int r0 = (tfirst + ti * tstride) * FF_BM + 16 * MI * wm;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const bf16_t* row = x + (size_t)(r0 + 16 * i + lrow) * p.ldx + 8 * lq;
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(64 * (16 / MI), MI == 4 ? 1 : 2) void ff_fused_kern
   constexpr bool XPF = (VX_FF_XPF != 0) && MI == 2;   // (the four-wave form has no registers to spare)
   if (XPF) load_x(0);
   for (int ti = 0; ti < my_tiles; ++ti) {
-    const int tile0 = ((int)blockIdx.x + ti * G) * FF_BM;    // first row of the tile
+    const int tile0 = (tfirst + ti * tstride) * FF_BM;    // first row of the tile
     if (!XPF) load_x(ti);
     f32x4_t Y[SMI][SNJ];
 #pragma unroll

@@ -36,6 +36,16 @@ __device__ __forceinline__ void glds16_v(const void* vaddr, uint32_t lds_wave_ad
                : "memory", "m0");
 }
 
+// VX_XCD_ROWS (round 4 experiment, default 0; 1 = A/B builds): every kernel that walks row tiles gives XCD x (= block id
+// % 8) the CONTIGUOUS x-th eighth of the rows, so that what one kernel leaves in an XCD's L2 would be read by the next
+// kernel on the same XCD (gemm_ring_kernel's tile walk, ff_fused_kernel's, the GroupNorm kernels' block order; the classic
+// tiles and the attention kernels always do through xcd_remap).  Measured: 12.51 vs 12.56 frames/s (-0.4 %,
+// profiles/r04i_xcd_row_ownership_negative_result.txt) - an XCD's 4 MB of L2 holds a twentieth of an 84 MB tensor, the
+// cross-launch reuse lives in the 256 MB Infinity Cache, which does not care about the XCD.  Off.
+#ifndef VX_XCD_ROWS
+#define VX_XCD_ROWS 0
+#endif
+
 // XCD-aware block remap (8 XCDs, blocks are dealt round-robin): logical ids that are adjacent run on the same
 // XCD, so the column tiles of one A row-tile share that XCD's L2.  Bijective for any block count.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -69,6 +69,7 @@ constexpr int R_LDS_TOTAL = R_LDS_BYTES + STATS_BYTES;   // 155,648 of the CU's 
 #ifndef VX_RING_MISSUE
 #define VX_RING_MISSUE 0
 #endif
+// (tile walk: VX_XCD_ROWS of vx_gemm_common.h)
 // VX_RING_PRIO (experiment): 1 = the M slot runs at s_setprio 1 (product), 0 = no priority changes, 2 = the L slot does
 #ifndef VX_RING_PRIO
 #define VX_RING_PRIO 1
@@ -80,6 +81,29 @@ constexpr int R_LDS_TOTAL = R_LDS_BYTES + STATS_BYTES;   // 155,648 of the CU's 
 #endif
 constexpr bool RING_MI_M = VX_RING_MISSUE == 1 || VX_RING_MISSUE == 2;
 constexpr bool RING_MI_LATE = VX_RING_MISSUE == 3;
+// Cache policy of the STORE epilogue's output stores (experiment, round 4: -DVX_RING_STORE_MOD='" sc1"' = write-through,
+// '" sc0 sc1"', '" nt"'; the product library is built without = plain stores).  The question: does leaving up to 32 MB of
+// dirty lines in the L2s for the end-of-kernel write-back cost the NEXT launch more than writing through while the
+// kernel still runs?
+#ifdef VX_RING_STORE_MOD
+typedef uint32_t ring_u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t ring_u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ring_store16(char* base, uint32_t off, const uint4& v) {
+  const ring_u32x4_t d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, %2" VX_RING_STORE_MOD ::"v"(off), "v"(d), "s"(base) : "memory");
+}
+__device__ __forceinline__ void ring_store8(char* base, uint32_t off, const uint2& v) {
+  const ring_u32x2_t d = {v.x, v.y};
+  asm volatile("global_store_dwordx2 %0, %1, %2" VX_RING_STORE_MOD ::"v"(off), "v"(d), "s"(base) : "memory");
+}
+#else
+__device__ __forceinline__ void ring_store16(char* base, uint32_t off, const uint4& v) {
+  *reinterpret_cast<uint4*>(base + off) = v;
+}
+__device__ __forceinline__ void ring_store8(char* base, uint32_t off, const uint2& v) {
+  *reinterpret_cast<uint2*>(base + off) = v;
+}
+#endif
 #ifdef VX_RING_TRACE
 // slot timing trace (tools/gemm_bench --trace): waves 0 and 4 of block 0 record s_memtime at every barrier
 __device__ unsigned long long* g_ring_trace = nullptr;
@@ -151,13 +175,29 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
     trace = g_ring_trace + (wave >> 2) * RING_TRACE_MAX;
 #endif
 
-  // ---- this block's output tiles: lb, lb + G, lb + 2G, ...   (column tile fastest, so co-running blocks of an XCD
-  // share activation row tiles through its L2)
+  // ---- this block's output tiles.  Blocks are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8, each with its
+  // own L2).  VX_XCD_ROWS (round 4 experiment, off - see vx_gemm_common.h): XCD x owns the CONTIGUOUS x-th eighth of the tile list in every launch -
+  // i.e. the same eighth of the rows (frames 4 x .. 4 x + 3 of a 32-frame batch) as in the attention kernels, the classic
+  // tiles and every other ring launch, whatever its column-tile count: what one kernel wrote into an XCD's L2 is read by
+  // the next kernel on the same XCD (output stores that bypass L2 cost 14 % of a clip, profiles/r04h_*).  Within its
+  // range a block takes tiles lb, lb + stride, ... (column tile fastest: co-running blocks share activation row tiles).
+  // Off: the round-1 walk lb = xcd_remap(b), stride G (first round contiguous per XCD, later rounds elsewhere).
   const int n_tiles = p.n / R_BN;
   const int total_tiles = (p.m / R_BM) * n_tiles;
   const int G = gridDim.x;
+#if VX_XCD_ROWS
+  const int nxcd = G < 8 ? G : 8;
+  const int xcd = (int)blockIdx.x % nxcd, xidx = (int)blockIdx.x / nxcd;
+  const int stride = (G - xcd + nxcd - 1) / nxcd;                      // blocks of this launch on this XCD
+  const int t0 = (int)((long)total_tiles * xcd / nxcd), t1 = (int)((long)total_tiles * (xcd + 1) / nxcd);
+  const int lb = t0 + xidx;
+  const int my_tiles = lb < t1 ? (t1 - lb + stride - 1) / stride : 0;
+  if (my_tiles <= 0) return;                                           // (uniform for the block, before any barrier)
+#else
+  const int stride = G;
   const int lb = xcd_remap(blockIdx.x, G);
   const int my_tiles = (total_tiles - lb + G - 1) / G;
+#endif
   const int nk = p.k / BKE;
   const int S = my_tiles * nk;   // K-tile sequence length of this block
 
@@ -273,7 +313,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
 #endif
     if (iss_kt == nk) {
       iss_kt = 0; s_ci = 0; s_kx = 0; s_ky = 0;
-      iss_lid += G;
+      iss_lid += stride;
       if (more) setup_issue_tile();
     }
     if (more) refresh_issue_bases();
@@ -586,7 +626,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
             continue;
           }
           const uint2 pk2 = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-          *reinterpret_cast<uint2*>(outb + out_off(k)) = pk2;
+          ring_store8(outb, out_off(k), pk2);
           if constexpr (GNS) {
             const float g0 = __uint_as_float(pk2.x << 16), g1 = __uint_as_float(pk2.x & 0xffff0000u);
             const float g2 = __uint_as_float(pk2.y << 16), g3 = __uint_as_float(pk2.y & 0xffff0000u);
@@ -638,7 +678,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
             continue;
           }
           const uint4 pk8 = pack_bf16x8(v);
-          *reinterpret_cast<uint4*>(outb + out_off(k)) = pk8;
+          ring_store16(outb, out_off(k), pk8);
           if constexpr (GNS) {
             float gg[8];
             unpack_bf16x8(pk8, gg);
@@ -774,7 +814,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
         }
       }
     }
-    cmp_lid += G;
+    cmp_lid += stride;
   }
 }
 

@@ -15,6 +15,7 @@
 // LayerNorm: one wave per row, the whole row lives in registers (C <= 64*8*MAXC), two-pass mean/variance via
 // wave shuffles, fused affine and the motion module's additive sinusoid table.
 #include "vx_common.h"
+#include "vx_gemm_common.h"
 #include "../../include/vexpress_hip.h"
 
 namespace {
@@ -72,7 +73,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16_t* __re
                                                               float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int C = c1 + c2;
-  const int frame = blockIdx.x / slices, slice = blockIdx.x % slices;
+  // (frames, slices) in XCD-contiguous order: XCD x reads / writes the x-th eighth of the frames, as the GEMM and attention
+  // kernels that produce and consume these tensors do (vx_gemm_ring.hip, VX_XCD_ROWS)
+  const int bid = VX_XCD_ROWS ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int frame = bid / slices, slice = bid % slices;
   const int tid = threadIdx.x;
   const GnPlan P = gn_plan(x1, c1, x2, c2, hw, frame);
   const int p_begin = slice * slice_pix;
@@ -247,7 +251,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
                                                               int out_pad, int stat_slices) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int C = c1 + c2;
-  const int frame = blockIdx.x / slices, slice = blockIdx.x % slices;
+  const int bid = VX_XCD_ROWS ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;      // XCD-contiguous (see gn_stats_kernel)
+  const int frame = bid / slices, slice = bid % slices;
   const int tid = threadIdx.x;
   float* scale = reinterpret_cast<float*>(smem);   // [C]
   float* shift = scale + C;                        // [C]
