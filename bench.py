@@ -359,6 +359,13 @@ def main():
                                     f"left-over units frame-sharded {mshards} ways" if mshards > 1 else ""))},
         "prologue_ms": 1e3 * prologue_s, "model_build_s": t_build, "lib_sha256": _lib_sha(),
     }
+    if args.fp8:
+        # VERDICT r03 item 7, closed in DESIGN 11.4: the e4m3 projections are a parity-complete OPTION, not a speed-up.
+        result["fp8_note"] = ("fp8 (e4m3) q/k/v/out projections: parity-complete (tests/test_gpu_kernels.py, "
+                              "test_gpu_models.py), not a speed-up - these are K = 320..1280 launches bound by HBM and "
+                              "launch latency, fp8 halves one operand's bytes and adds a quantisation pass; measured "
+                              "768x768: 4.01 (fp8) vs 4.50 (bf16) frames/s, profiles/r03f_bench_768_*.json.  Compare "
+                              "this line's value with the same command without --fp8.")
     if world > 1:
         # One more clip with every collective of the data path timed (events on the launch stream) and this rank's own
         # compute time between the collectives: what a first real 8-GPU run needs to be diagnosable from this one line.

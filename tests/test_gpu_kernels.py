@@ -713,12 +713,16 @@ def test_geglu_and_split_with_folded_layernorm(ops):
 # ------------------------------------------------------------------- round 3: producer-side statistics, GroupNorm fold
 @pytest.mark.parametrize("m,n,k,res,offset", [(256 * 384, 320, 320, True, 0.0), (256 * 200, 320, 1280, True, 2.5),
                                               (256 * 192, 320, 64, False, 0.5), (256 * 96, 640, 320, True, 0.5),
-                                              (300, 320, 640, True, 1.0)])
+                                              (300, 320, 640, True, 1.0), (256 * 192, 320, 320, True, 30.0)])
 def test_gemm_row_stats_out(ops, m, n, k, res, offset):
     """vx_gemm_params.row_stats_out: (mean, rstd) of every STORED bf16 output row, against float64 statistics of the
     tensor the launch wrote - from the ring epilogue's registers when one 256 x 320 tile holds whole rows (n = 320; sums
     of x and x^2 in float32, rows with a mean of up to 2.5 standard deviations), from vx_row_stats inside vx_gemm
-    otherwise (n = 640 on the ring kernel, the classic tiles).  The output itself must not change."""
+    otherwise (n = 640 on the ring kernel, the classic tiles).  The output itself must not change.
+
+    Last row: |mean| / std of about 30 - the precision statement of vexpress_hip.h for the one-pass form (E[x^2] - mean^2
+    from float32 sums of 320 values cancels ~10 bits there): rstd within 3e-3 instead of 1e-4.  The model's residual
+    stream has |mean| / std < 1 in every LayerNorm input (tests/test_gpu_fullsize.py would not hold otherwise)."""
     a, w = rnd(m, k), rnd(n, k, scale=k ** -0.5, seed=1)
     bias = rnd(n, seed=2, dtype=torch.float32) + offset
     r = rnd(m, n, seed=3) if res else None
@@ -733,7 +737,11 @@ def test_gemm_row_stats_out(ops, m, n, k, res, offset):
     mean, rstd = x.mean(dim=1), torch.rsqrt(x.var(dim=1, unbiased=False) + 1e-5)
     assert torch.isfinite(st).all()
     assert torch.allclose(st[:, 0].double(), mean, rtol=2e-5, atol=2e-6), (st[:, 0].double() - mean).abs().max()
-    assert torch.allclose(st[:, 1].double(), rstd, rtol=1e-4), ((st[:, 1].double() - rstd) / rstd).abs().max()
+    rtol = 1e-4 if abs(offset) < 10 else 3e-3
+    assert torch.allclose(st[:, 1].double(), rstd, rtol=rtol), ((st[:, 1].double() - rstd) / rstd).abs().max()
+    if abs(offset) >= 10:
+        sd = x.std(dim=1, unbiased=False)
+        assert float((mean.abs() / sd).median()) > 15, "the row is supposed to test a large mean-to-deviation ratio"
     # a launch over the first half of the rows gives the same bits (batch invariance of the fused statistics)
     if (m // 2) % 256 == 0 and (m // 2 // 256) * (n // 320) >= 192:
         st2 = torch.empty((m // 2, 2), device="cuda")
