@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 10
+#define VX_ABI_VERSION 11
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
@@ -153,7 +153,7 @@ const char* vx_gemm_config_name(const vx_gemm_params* p);
  * rows of a committed kernel trace one to one.  "" before the first launch. */
 const char* vx_gemm_last_kernel(void);
 
-/* ---- Fused GEGLU feed-forward of the 64x64 level (round 4 prototype) ---------------------------------------------
+/* ---- Fused GEGLU feed-forward of the 64x64 level (round 4) -------------------------------------------------------
  * out = residual + (value * gelu(gate)) W2^T + bias2,  [value | gate] = LN(x) W1^T + b1   in ONE launch: the [m, 4C]
  * intermediate of diffusers FeedForward(activation_fn="geglu") (modules/mutual_self_attention.py:247,
  * modules/motion_module.py:256) never leaves the CU.  C = 320, hidden = 1280 only (x fragments of a 128-row tile live in
@@ -177,6 +177,34 @@ typedef struct {
 } vx_ff_params;
 int vx_ff_pack_weights(const void* w1_interleaved, const void* w2, void* w1t, void* w2t, int c, int hidden, void* stream);
 int vx_ff_fused(const vx_ff_params* p, void* stream);
+
+/* ---- Fused temporal self-attention block of the 64x64 level (round 4) ----------------------------------------------
+ * x <- x + to_out(softmax_over_frames(q k^T * scale) v),  [q | k | v] = (LN(x) + pe[frame]) Wqkv^T + b   in ONE launch:
+ * VersatileAttention.forward inside TemporalTransformerBlock.forward (modules/motion_module.py:243-256, :351-388: the two
+ * rearranges, pos_encoder, to_q / to_k / to_v, attention over the frame axis per (pixel, head), to_out, residual) - the
+ * [m, 3C] projections and the [m, C] attention output never reach memory.  C = 320, 8 heads, f = 16 frames only (a tile =
+ * 8 pixels x their 16 frames; the x rows of a tile live in registers); rows are [(b f), hw] frame-major as everywhere
+ * (row = (item * f + frame) * hw + pixel), hw % 8 == 0.  The LayerNorm is folded in as in vx_gemm_params.ln_stats: wqkv =
+ * the folded weight, bias / colsum its bias and column sums, pe_rows = the positional table pushed through the weight
+ * (float32 [f][3C]: row `frame` is added to every row of that frame).  ln_stats = (mean, rstd) per row, or NULL: the
+ * kernel then takes them from the rows it holds (two-pass, float32).  vx_tblock_pack re-tiles the weights and tables once
+ * per layer:  wqkv_t 655360 B, wo_t 204800 B, tb / tbt 65536 B each, colsum_p 4096 B. */
+typedef struct {
+  void* x;                   /* bf16 [b f hw, ldx], updated in place */
+  int32_t ldx, b, f, hw, c, heads;
+  const void* wqkv_t;        /* vx_tblock_pack outputs */
+  const void* wo_t;
+  const float* tb;
+  const float* tbt;
+  const float* colsum_p;
+  const float* bias_o;       /* [c] or NULL */
+  const float* ln_stats;     /* [m][2] or NULL */
+  float ln_eps, scale;       /* LayerNorm eps (ln_stats == NULL); softmax scale (head_dim^-0.5) */
+} vx_tblock_params;
+int vx_tblock_pack(const void* wqkv, const float* bias, const float* colsum, const float* pe_rows, int pe_ld,
+                   const void* wo, void* wqkv_t, void* wo_t, float* tb, float* tbt, float* colsum_p, int c, int heads,
+                   int f, void* stream);
+int vx_tblock_fused(const vx_tblock_params* p, void* stream);
 
 /* ---- GroupNorm (+SiLU), per-frame statistics, NHWC, optional dual (concat) source --------------------------
  * Replaces F.group_norm via InflatedGroupNorm (modules/resnet.py:20-28; :220-221,:235,:241), Transformer3DModel.norm

@@ -233,6 +233,17 @@ def ff_fused(h, w1_folded, b1, colsum, stats, w2, b2):
     return gemm(g, w2, b2, residual=h, out=h)
 
 
+def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, heads, stats=None, eps=1e-5):
+    """vx_tblock_fused = the three launches it replaces, in place on h (statistics: the rows' own when none are given)."""
+    if stats is None:
+        stats = row_stats(h, eps)
+    m, c = h.shape
+    rb = pe_rows[:f].repeat(b, 1).contiguous() if pe_rows is not None else None
+    qkv = gemm(h, wqkv_folded, bqkv, rowbias=rb, rows_per_group=hw, ln=(stats, colsum))
+    a = temporal_attention(qkv, b=b, f=f, hw=hw, heads=heads, head_dim=c // heads)
+    return gemm(a, wo, bo, residual=h, out=h)
+
+
 def alloc_vt(seqs, heads, head_dim, n, device):
     return torch.zeros((seqs, heads, head_dim, (n + 7) // 8 * 8), device=device, dtype=BF16)
 
@@ -363,7 +374,7 @@ def vae_postprocess(x, n, c, h, w):
     return (x[:, :c].float().reshape(n, h, w, c).permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1).contiguous()
 
 
-ALL = ("wave_conv1d", "groupnorm", "groupnorm_stats", "groupnorm_fold_linear", "layernorm", "row_stats", "layernorm_fp8", "quantize_fp8", "gemm", "geglu", "ff_fused", "alloc_vt", "gemm_split", "key_norm_max", "attention",
+ALL = ("wave_conv1d", "groupnorm", "groupnorm_stats", "groupnorm_fold_linear", "layernorm", "row_stats", "layernorm_fp8", "quantize_fp8", "gemm", "geglu", "ff_fused", "tblock_fused", "alloc_vt", "gemm_split", "key_norm_max", "attention",
        "temporal_attention", "small_kv_attention", "add_row_bias", "gather_latents", "cfg_combine", "pack_rows", "combine_units", "overlap_ddim_step",
        "ncfhw_to_nhwc", "nhwc_to_ncfhw", "vae_postprocess")
 

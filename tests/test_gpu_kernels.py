@@ -5,6 +5,8 @@ Tolerance (written per test): outputs are bf16, so the only error vs an fp32 eva
 accumulation order + one final rounding:  max|err| <= 2^-7 * max|ref| (+ tiny abs) and relative L2 <= 6e-3.
 """
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -958,3 +960,79 @@ def test_ff_fused_prototype_matches_the_two_launches(ops, m):
     h = (p[:, :, 0] * F.gelu(p[:, :, 1])).reshape(m, hidden)
     ref = xf + h.to(BF).float() @ w2.float().t() + b2
     check(got, ref, f"ff_fused {m} rows vs float32", rel=8e-3)
+
+
+# ------------------------------------------------------------- round 4: the temporal attention block in one launch
+def _tblock_problem(b, hw, seed=0):
+    c, heads, f = 320, 8, 16
+    x = rnd(b * f * hw, c, seed=seed) * 1.5 + 0.3
+    wqkv = rnd(3 * c, c, scale=c ** -0.5, seed=seed + 1)
+    wo = rnd(c, c, scale=c ** -0.5, seed=seed + 2)
+    bq = rnd(3 * c, seed=seed + 3, dtype=torch.float32) * 0.2
+    bo = rnd(c, seed=seed + 4, dtype=torch.float32) * 0.2
+    pe = rnd(24, 3 * c, seed=seed + 5, dtype=torch.float32) * 0.5
+    colsum = wqkv.float().sum(dim=1).contiguous()
+    return x, wqkv, wo, bq, bo, pe, colsum
+
+
+def test_tblock_pack_matches_the_emulated_layout(ops):
+    """vx_tblock_pack against tools/tblock_emulate.pack - the numpy statement of the fragment-major layouts that the
+    lane-level emulation of the kernel (tests/test_host_logic.py) checks against plain float64 math."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import tblock_emulate as E
+    from v_express_amd import lib as L
+    _, wqkv, wo, bq, _, pe, colsum = _tblock_problem(1, 8)
+    dev = wqkv.device
+    wqkv_t = torch.empty(655360 // 2, device=dev, dtype=BF)
+    wo_t = torch.empty(204800 // 2, device=dev, dtype=BF)
+    tb, tbt = (torch.empty(16 * 1024, device=dev, dtype=torch.float32) for _ in range(2))
+    cs = torch.empty(1024, device=dev, dtype=torch.float32)
+    L.check(L.lib.vx_tblock_pack(wqkv.data_ptr(), bq.data_ptr(), colsum.data_ptr(), pe.data_ptr(), pe.stride(0),
+                                 wo.data_ptr(), wqkv_t.data_ptr(), wo_t.data_ptr(), tb.data_ptr(), tbt.data_ptr(),
+                                 cs.data_ptr(), 320, 8, 16, torch.cuda.current_stream().cuda_stream), "vx_tblock_pack")
+    e_w, e_wo, e_tb, e_tbt, e_cs = E.pack(wqkv.float().cpu().numpy(), bq.cpu().numpy(), colsum.cpu().numpy(),
+                                          pe[:16].cpu().numpy(), wo.float().cpu().numpy())
+    assert torch.equal(wqkv_t.float().cpu(), torch.from_numpy(e_w).reshape(-1))
+    assert torch.equal(wo_t.float().cpu(), torch.from_numpy(e_wo).reshape(-1))
+    assert torch.equal(tb.cpu(), torch.from_numpy(e_tb).reshape(-1))
+    assert torch.equal(tbt.cpu(), torch.from_numpy(e_tbt).reshape(-1))
+    assert torch.equal(cs.cpu(), torch.from_numpy(e_cs))
+
+
+@pytest.mark.parametrize("b,hw,given_stats", [(1, 8, True), (2, 64, False), (2, 4096, True), (2, 4096, False), (3, 1160, False)])
+def test_tblock_fused_matches_the_three_launches(ops, b, hw, given_stats):
+    """vx_tblock_fused (C = 320, 8 heads, 16 frames): LayerNorm-folded QKV projection + positional rows, attention over the
+    frame axis, out-projection and residual in ONE launch (VersatileAttention inside TemporalTransformerBlock,
+    modules/motion_module.py:243-256, :351-388) against the three launches it replaces - same rounding points, so the two
+    differ only by the summation order inside the 16 x 16 products: a few bf16 ulps on a few elements - and against
+    float32 math.  given_stats = False: the kernel takes the LayerNorm statistics from the rows it holds.
+    (3, 1160): a tile count that is no multiple of the grid, pixels per item no power of two."""
+    c, heads, f = 320, 8, 16
+    d = c // heads
+    x, wqkv, wo, bq, bo, pe, colsum = _tblock_problem(b, hw)
+    m = b * f * hw
+    stats = ops.row_stats(x)
+    with ops.frame_rows(hw, items=b):
+        qkv = ops.gemm(x, wqkv, bq, rowbias=pe[:f].repeat(b, 1).contiguous(), rows_per_group=hw, ln=(stats, colsum))
+        a = ops.temporal_attention(qkv, b=b, f=f, hw=hw, heads=heads, head_dim=d)
+        want = ops.gemm(a, wo, bo, residual=x)
+    got = ops.tblock_fused(x.clone(), wqkv, bq, colsum, pe, wo, bo, b=b, f=f, hw=hw, heads=heads,
+                           stats=stats if given_stats else None)
+    torch.cuda.synchronize()
+    diff = (got.float() - want.float()).abs()
+    frac = (got != want).float().mean().item()
+    scale = want.float().abs().max().item()
+    print(f"[tblock_fused b={b} hw={hw} stats={'given' if given_stats else 'own'}] max|diff| vs three launches "
+          f"{diff.max().item():.4g} (max |out| {scale:.3g}), differing elements {100 * frac:.3g} %, "
+          f"rel-L2 {(diff.norm() / want.float().norm()).item():.3g}")
+    assert diff.max().item() <= 2 ** -5 * scale and (diff.norm() / want.float().norm()).item() <= 2e-3
+    # float32 statement of the block
+    xf = x.float()
+    mean, var = xf.mean(dim=1, keepdim=True), xf.var(dim=1, unbiased=False, keepdim=True)
+    ln = (xf - mean) * torch.rsqrt(var + 1e-5)
+    q3 = ln @ wqkv.float().t() + bq + pe[:f].repeat(b, 1).repeat_interleave(hw, dim=0)
+    q, k, v = (t.reshape(b, f, hw, heads, d).permute(0, 2, 3, 1, 4) for t in q3.to(BF).float().chunk(3, dim=-1))
+    o = F.scaled_dot_product_attention(q, k, v).permute(0, 3, 1, 2, 4).reshape(m, c)
+    ref = xf + o.to(BF).float() @ wo.float().t() + bo
+    check(got, ref, f"tblock_fused b={b} hw={hw} vs float32", rel=8e-3)

@@ -103,10 +103,15 @@ def test_round3_fused_paths_host_composition_vs_reference_golden(emulated, monke
     def qk_everywhere(m, c):
         used["qk"] += 1
         return True
+    def tblock_everywhere(c, heads, f, hw):
+        used["tblock"] = used.get("tblock", 0) + 1
+        return True
     monkeypatch.setattr(ops, "gn_fold_applies", fold_everywhere)
     monkeypatch.setattr(ops, "qk_on_ring", qk_everywhere)
+    monkeypatch.setattr(ops, "tblock_fused_applies", tblock_everywhere)
     fused = unet(x, t, encoder_hidden_states=ehs, kps_features=inp["kps_features"], return_dict=False)[0]
     assert used["fold"] == 16 + 21 and used["qk"] == 16          # every spatial + motion proj_in, every spatial qkv
+    assert used["tblock"] == 2 * 21                              # both attention blocks of every motion module (round 4)
     print(f"[round-3 fused composition] vs golden {rel_l2(fused, gold):.4g} (default {rel_l2(base, gold):.4g}), "
           f"fused vs default {rel_l2(fused, base):.4g}")
     assert rel_l2(fused, gold) <= 3e-2 and rel_l2(base, gold) <= 3e-2

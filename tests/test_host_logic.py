@@ -20,7 +20,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for n in names:
         assert hasattr(so, n), n
-    assert lib.lib.vx_abi_version() == 10
+    assert lib.lib.vx_abi_version() == 11
     assert ctypes.sizeof(lib.GemmParams) % 8 == 0
     # argument validation happens before any launch, so it works without a GPU and never aborts the process
     p = lib.GemmParams()
@@ -500,3 +500,16 @@ def test_kernel_routing_decisions_do_not_depend_on_the_batch():
     assert not ops.gn_fold_applies(2 * f * 4096, 4096, 320, 320)              # outside a frame_rows context: never
     with ops.frame_rows(4096, items=2):                                       # a frame-sharded half window (f = 8)
         assert ops.gn_fold_applies(2 * 8 * 4096, 4096, 320, 320)
+
+
+def test_tblock_lane_level_emulation_matches_plain_math():
+    """tools/tblock_emulate.py: the fused temporal-attention kernel's pack layouts, fragment addresses, MFMA operand roles
+    and LDS hand-over restated lane by lane in numpy (same index formulas as csrc/vx_tblock.hip) against a float64
+    statement of the block with the same rounding points.  The GPU test compares vx_tblock_pack with this pack()."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import tblock_emulate as E
+    assert E.self_check(seed=1) < 2e-3
+    # every column of q | k | v appears exactly once in the packed order, 8 pad rows per head
+    cols = [E.src_col(h, blk, r) for h in range(8) for blk in range(8) for r in range(16)]
+    assert sorted(c for c in cols if c >= 0) == list(range(960)) and cols.count(-1) == 64

@@ -330,15 +330,27 @@ def _motion_module(P, x, *, b, f, H, W, heads, groups, shard=None, gn_next=False
     m = b * f_all * hw_t
     # row statistics of h for the folded LayerNorms: written by the GEMM that produces the rows (see the spatial block)
     folds = [_fold_on(A.get("ln_qkv")) for A in P.attn] + [_ff_fold_on(P)]
-    st = torch.empty((m, 2), device=x.device, dtype=torch.float32) if any(folds) else None
+    # attention blocks that run as ONE launch (ops.tblock_fused: the 64x64 level) take their LayerNorm statistics from
+    # the rows they hold: nobody has to produce statistics for them
+    fused = [folds[i] and ops.tblock_fused_applies(c, heads, f_all, hw_t) for i in range(len(P.attn))] + [False]
+    wants = [folds[i] and not fused[i] for i in range(len(folds))]          # consumers of row statistics
+    st = torch.empty((m, 2), device=x.device, dtype=torch.float32) if any(wants) else None
     if shard is not None:
         n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
         n = shard.to_pixel_shard(n, b, f)
-        h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b, stats_out=st if folds[0] else None)
+        h = ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b, stats_out=st if wants[0] else None)
     else:
-        h = _norm_proj_in(P, x, frames, hw, groups, stats_out=st if folds[0] else None)
+        h = _norm_proj_in(P, x, frames, hw, groups, stats_out=st if wants[0] else None)
+    have_st = wants[0]                  # st holds the statistics of the current h
     for i, A in enumerate(P.attn):
+        if fused[i]:
+            ops.tblock_fused(h, A.ln_qkv.w, A.ln_qkv.b, A.ln_qkv.s, A.pe_rows, A.attn.out.w, A.attn.out.b, b=b, f=f_all,
+                             hw=hw_t, heads=heads)
+            have_st = False
+            continue
         if folds[i]:
+            if not have_st:
+                st = ops.row_stats(h)
             key = ("pe_rows_tiled", b, f_all)
             if key not in A:                   # [b * f_all, 3C] float32: frame (m // hw_t) % f_all of the table
                 A[key] = A.pe_rows[:f_all].repeat(b, 1).contiguous()
@@ -348,8 +360,9 @@ def _motion_module(P, x, *, b, f, H, W, heads, groups, shard=None, gn_next=False
             qkv = ops.gemm(ln, ops.proj_weight(ln, A.attn.wqkv), A.attn.bqkv)
         a = ops.proj_input(ops.temporal_attention(qkv, b=b, f=f_all, hw=hw_t, heads=heads, head_dim=d))
         ops.gemm(a, ops.proj_weight(a, A.attn.out.w), A.attn.out.b, residual=h, out=h,
-                 stats_out=st if folds[i + 1] else None)
-    _feed_forward(P, h, st if folds[-1] else None)
+                 stats_out=st if wants[i + 1] else None)
+        have_st = wants[i + 1]
+    _feed_forward(P, h, st if folds[-1] and have_st else None)
     if shard is not None:
         h = shard.to_frame_shard(h.view(b * f_all, hw_t, c), b, f).view(frames * hw, c)
     out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x.view(frames * hw, c), gn=(groups, hw) if gn_next else None)

@@ -412,6 +412,7 @@ def clear_caches():
     _PADDED.clear()
     _FP8_W.clear()
     _FF_PACKED.clear()
+    _TB_PACKED.clear()
 
 
 _ITEMS = [None]
@@ -600,6 +601,49 @@ def ff_fused(h, w1_folded, b1, colsum, stats, w2, b2):
     p.bias2 = b2.data_ptr() if b2 is not None else None
     p.residual, p.ldr, p.out, p.ldo = h.data_ptr(), ldx, h.data_ptr(), ldx
     L.check(_lib.vx_ff_fused(C.byref(p), _stream()), "vx_ff_fused")
+    return h
+
+
+# Temporal self-attention block of the 64x64 level in ONE launch (csrc/vx_tblock.hip): LayerNorm-folded QKV projection,
+# attention over the 16 frames, out-projection and residual; VX_TB_FUSED=0 restores the three launches (A/B knob).
+TB_FUSED = [os.environ.get("VX_TB_FUSED", "1") != "0"]
+_TB_PACKED = {}
+
+
+def tblock_fused_applies(c, heads, f, hw):
+    return TB_FUSED[0] and LN_FOLD[0] and c == 320 and heads == 8 and f == 16 and hw % 8 == 0 and not FP8_PROJ[0]
+
+
+def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, heads, stats=None, eps=1e-5):
+    """h += to_out(attention over f of (LN(h) + pe) Wqkv^T + b), in place on h [(b f) hw, C] (a tile of the kernel is 8
+    pixels x their 16 frames: rows of other pixels are independent).  stats: (mean, rstd) per row, or None - the kernel
+    then takes them from the rows it holds.  Weights and tables are re-tiled once per layer (vx_tblock_pack)."""
+    _chk_bf16(h, "h")
+    ldx, m = _row_stride(h)
+    c = h.shape[-1]
+    if m != b * f * hw:
+        raise ValueError("h rows != b*f*hw")
+    key = (wqkv_folded.data_ptr(), wo.data_ptr(), pe_rows.data_ptr() if pe_rows is not None else 0)
+    hit = _TB_PACKED.get(key)
+    if hit is None:
+        dev = h.device
+        wqkv_t = torch.empty(655360 // 2, device=dev, dtype=BF16)
+        wo_t = torch.empty(204800 // 2, device=dev, dtype=BF16)
+        tb, tbt = (torch.empty(16 * 1024, device=dev, dtype=torch.float32) for _ in range(2))
+        cs = torch.empty(1024, device=dev, dtype=torch.float32)
+        L.check(_lib.vx_tblock_pack(_ptr(wqkv_folded), _ptr(bqkv) if bqkv is not None else None, _ptr(colsum),
+                                    _ptr(pe_rows) if pe_rows is not None else None,
+                                    pe_rows.stride(0) if pe_rows is not None else 0, _ptr(wo), _ptr(wqkv_t), _ptr(wo_t),
+                                    _ptr(tb), _ptr(tbt), _ptr(cs), c, heads, f, _stream()), "vx_tblock_pack")
+        hit = _TB_PACKED[key] = (wqkv_folded, wo, pe_rows, wqkv_t, wo_t, tb, tbt, cs)   # sources kept alive: the key is their address
+    p = L.TBlockParams()
+    p.x, p.ldx, p.b, p.f, p.hw, p.c, p.heads = h.data_ptr(), ldx, b, f, hw, c, heads
+    p.wqkv_t, p.wo_t, p.tb, p.tbt, p.colsum_p = (t.data_ptr() for t in hit[3:8])
+    p.bias_o = bo.data_ptr() if bo is not None else None
+    p.ln_stats = stats.data_ptr() if stats is not None else None
+    p.ln_eps, p.scale = eps, (c // heads) ** -0.5
+    with _hbm_op("tblock_fused", 2 * m * c * 2):                 # reads the rows once, writes them once (bf16)
+        L.check(_lib.vx_tblock_fused(C.byref(p), _stream()), "vx_tblock_fused")
     return h
 
 
