@@ -2,7 +2,12 @@
     python tools/tb_bench.py [iters]"""
 import sys
 
+import os
+import sys
+
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from v_express_amd import ops
 

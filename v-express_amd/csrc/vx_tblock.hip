@@ -356,12 +356,21 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
           o2 = Vp[i][2];
         } else {
           // S^T[key frame 4 lq + r][query frame lrow] = sum_d K[key][d] Q[query][d]
-          f32x4_t sc = mfma16(make_uint4(Kp[i][0].x, Kp[i][0].y, Kp[i][1].x, Kp[i][1].y),
-                              make_uint4(Qp[i][0].x, Qp[i][0].y, Qp[i][1].x, Qp[i][1].y), f32x4_t{0.f, 0.f, 0.f, 0.f});
+          const f32x4_t s_main = mfma16(make_uint4(Kp[i][0].x, Kp[i][0].y, Kp[i][1].x, Kp[i][1].y),
+                                        make_uint4(Qp[i][0].x, Qp[i][0].y, Qp[i][1].x, Qp[i][1].y),
+                                        f32x4_t{0.f, 0.f, 0.f, 0.f});
           // channels 32..39: the mixed block holds q in lanes 0-31 and k in lanes 32-63 -> (q | 0), (k | 0)
           auto m0 = __builtin_amdgcn_permlane32_swap(Mp[i].x, 0u, false, false);
           auto m1 = __builtin_amdgcn_permlane32_swap(Mp[i].y, 0u, false, false);
-          sc = mfma16k(make_uint2(m0[1], m1[1]), make_uint2(m0[0], m1[0]), sc);
+          // Its own accumulator, added on the VALU - NOT chained through the C operand: a v_mfma_f32_16x16x16_bf16 that
+          // takes the result of the v_mfma_f32_16x16x32_bf16 right in front of it as C read it too early on the hardware
+          // (hipcc 7.2 puts no wait states between that pair; measured: the 32-channel term of S went missing for whichever
+          // pixel had fewer than ~5 instructions between the two, run-to-run different for the late waves;
+          // profiles/r04m_tblock_probes.txt).  VALU reads of MFMA results are interlocked by the compiler as everywhere.
+          const f32x4_t s_mix = mfma16k(make_uint2(m0[1], m1[1]), make_uint2(m0[0], m1[0]), f32x4_t{0.f, 0.f, 0.f, 0.f});
+          f32x4_t sc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[r] = s_main[r] + s_mix[r];
           float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
           mx = wave_xor_max(mx, 16);
           mx = wave_xor_max(mx, 32);
