@@ -188,22 +188,20 @@ int vx_ff_fused(const vx_ff_params* p, void* stream);
  * the folded weight, bias / colsum its bias and column sums, pe_rows = the positional table pushed through the weight
  * (float32 [f][3C]: row `frame` is added to every row of that frame).  ln_stats = (mean, rstd) per row, or NULL: the
  * kernel then takes them from the rows it holds (two-pass, float32).  vx_tblock_pack re-tiles the weights and tables once
- * per layer:  wqkv_t 655360 B, wo_t 204800 B, tb / tbt 65536 B each, colsum_p 4096 B. */
+ * per layer:  wqkv_t 720896 B (weights and the bias / positional table of each 16-column block together), wo_t 204800 B,
+ * colsum_p 4096 B. */
 typedef struct {
   void* x;                   /* bf16 [b f hw, ldx], updated in place */
   int32_t ldx, b, f, hw, c, heads;
   const void* wqkv_t;        /* vx_tblock_pack outputs */
   const void* wo_t;
-  const float* tb;
-  const float* tbt;
   const float* colsum_p;
   const float* bias_o;       /* [c] or NULL */
   const float* ln_stats;     /* [m][2] or NULL */
   float ln_eps, scale;       /* LayerNorm eps (ln_stats == NULL); softmax scale (head_dim^-0.5) */
 } vx_tblock_params;
 int vx_tblock_pack(const void* wqkv, const float* bias, const float* colsum, const float* pe_rows, int pe_ld,
-                   const void* wo, void* wqkv_t, void* wo_t, float* tb, float* tbt, float* colsum_p, int c, int heads,
-                   int f, void* stream);
+                   const void* wo, void* wqkv_t, void* wo_t, float* colsum_p, int c, int heads, int f, void* stream);
 int vx_tblock_fused(const vx_tblock_params* p, void* stream);
 
 /* ---- GroupNorm (+SiLU), per-frame statistics, NHWC, optional dual (concat) source --------------------------

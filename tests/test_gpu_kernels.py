@@ -984,19 +984,18 @@ def test_tblock_pack_matches_the_emulated_layout(ops):
     from v_express_amd import lib as L
     _, wqkv, wo, bq, _, pe, colsum = _tblock_problem(1, 8)
     dev = wqkv.device
-    wqkv_t = torch.empty(655360 // 2, device=dev, dtype=BF)
+    wqkv_t = torch.empty(720896 // 2, device=dev, dtype=BF)
     wo_t = torch.empty(204800 // 2, device=dev, dtype=BF)
-    tb, tbt = (torch.empty(16 * 1024, device=dev, dtype=torch.float32) for _ in range(2))
     cs = torch.empty(1024, device=dev, dtype=torch.float32)
     L.check(L.lib.vx_tblock_pack(wqkv.data_ptr(), bq.data_ptr(), colsum.data_ptr(), pe.data_ptr(), pe.stride(0),
-                                 wo.data_ptr(), wqkv_t.data_ptr(), wo_t.data_ptr(), tb.data_ptr(), tbt.data_ptr(),
-                                 cs.data_ptr(), 320, 8, 16, torch.cuda.current_stream().cuda_stream), "vx_tblock_pack")
-    e_w, e_wo, e_tb, e_tbt, e_cs = E.pack(wqkv.float().cpu().numpy(), bq.cpu().numpy(), colsum.cpu().numpy(),
-                                          pe[:16].cpu().numpy(), wo.float().cpu().numpy())
-    assert torch.equal(wqkv_t.float().cpu(), torch.from_numpy(e_w).reshape(-1))
+                                 wo.data_ptr(), wqkv_t.data_ptr(), wo_t.data_ptr(), cs.data_ptr(), 320, 8, 16,
+                                 torch.cuda.current_stream().cuda_stream), "vx_tblock_pack")
+    e_w, e_tab, e_wo, e_cs = E.pack(wqkv.float().cpu().numpy(), bq.cpu().numpy(), colsum.cpu().numpy(),
+                                    pe[:16].cpu().numpy(), wo.float().cpu().numpy())
+    chunks = wqkv_t.view(torch.uint8).cpu().view(32, 22528)          # a chunk: 20480 B of bf16 weights, 2048 B of fp32 table
+    assert torch.equal(chunks[:, :20480].contiguous().view(torch.bfloat16).float(), torch.from_numpy(e_w).reshape(32, -1))
+    assert torch.equal(chunks[:, 20480:].contiguous().view(torch.float32), torch.from_numpy(e_tab).reshape(32, -1))
     assert torch.equal(wo_t.float().cpu(), torch.from_numpy(e_wo).reshape(-1))
-    assert torch.equal(tb.cpu(), torch.from_numpy(e_tb).reshape(-1))
-    assert torch.equal(tbt.cpu(), torch.from_numpy(e_tbt).reshape(-1))
     assert torch.equal(cs.cpu(), torch.from_numpy(e_cs))
 
 

@@ -53,9 +53,11 @@ def src_col(head, blk, r):
 
 
 def pack(wqkv, bias, colsum, pe, wo):
-    """tblock_pack_kernel: returns wqkv_t [32 chunks][10][2][64][8], wo_t as a flat bf16 array in units of elements,
-    tb [16][1024], tbt [1024][16], colsum_p [1024]"""
+    """tblock_pack_kernel: returns wqkv_t [32 chunks][10][2][64][8] (the weights of a chunk), tab [32 chunks][2][256] (the
+    fp32 table behind them: bias + positional row, [frame][column] for blocks 0..4, [column][frame] for the V blocks),
+    wo_t [4][25600] in elements, colsum_p [1024]"""
     wqkv_t = np.zeros((32, KS, 2, 64, 8), np.float32)
+    tab = np.zeros((32, 2, 256), np.float32)
     for ch in range(32):
         hp, blk = ch >> 3, ch & 7
         for wn in range(2):
@@ -66,6 +68,11 @@ def pack(wqkv, bias, colsum, pe, wo):
                     continue
                 for ks in range(KS):
                     wqkv_t[ch, ks, wn, lane] = wqkv[col, 32 * ks + 8 * (lane >> 4): 32 * ks + 8 * (lane >> 4) + 8]
+            for e in range(256):
+                fr, r = (e >> 4, e & 15) if blk < 5 else (e & 15, e >> 4)
+                col = src_col(head, blk, r)
+                if col >= 0:
+                    tab[ch, wn, e] = bias[col] + pe[fr, col]
     wo_t = np.zeros((4, 25600), np.float32)          # per head pair: part0 10240 | part1 10240 | part2 5120 elements
     for hp in range(4):
         for part in range(2):
@@ -84,19 +91,17 @@ def pack(wqkv, bias, colsum, pe, wo):
                 base = head * D + 32 + 4 * (lq & 1)
                 dst = 20480 + (j * 64 + lane) * 4
                 wo_t[hp, dst:dst + 4] = wo[16 * j + (lane & 15), base:base + 4]
-    tb = np.zeros((F, PCOLS), np.float32)
     colsum_p = np.zeros(PCOLS, np.float32)
     for pc in range(PCOLS):
         col = src_col(pc >> 7, (pc >> 4) & 7, pc & 15)
         if col >= 0:
-            tb[:, pc] = bias[col] + pe[:, col]
             colsum_p[pc] = colsum[col]
-    return wqkv_t, wo_t, tb, tb.T.copy(), colsum_p
+    return wqkv_t, tab, wo_t, colsum_p
 
 
 def run_tile(x_tile, packed, scale_log2e, eps):
     """x_tile: [8 pixels][16 frames][320] (bf16 values as float32) -> the tile's output rows, same shape"""
-    wqkv_t, wo_t, tb, tbt, colsum_p = packed
+    wqkv_t, tab, wo_t, colsum_p = packed
     o_lds = np.zeros((4, PIX, 1280), np.float32)       # per head pair, pixel: kb0 512 elements | kb1 512 | kb2 256
     st_lds = np.zeros((PIX, F, 2), np.float32)
     for wave in range(NW):
@@ -125,10 +130,7 @@ def run_tile(x_tile, packed, scale_log2e, eps):
                 c = 8 * hp + blk
                 pc = (head * 8 + blk) * 16
                 plain = blk >= 5
-                if blk < 5:
-                    tq = np.stack([tb[LROW, pc + 4 * LQ + r] for r in range(4)], axis=1)
-                else:
-                    tq = np.stack([tbt[pc + LROW, 4 * LQ + r] for r in range(4)], axis=1)
+                tq = np.stack([tab[c, wn, LROW * 16 + 4 * LQ + r] for r in range(4)], axis=1)   # slot + 20480 + wn * 1024
                 P = np.zeros((NPX, 64, 4), np.float32)
                 for ks in range(KS):
                     wf = wqkv_t[c, ks, wn]               # smem + slot + ks * 2048 + wn * 1024 + lane * 16

@@ -43,17 +43,18 @@ constexpr int TB_C = 320, TB_HEADS = 8, TB_D = 40, TB_F = 16, TB_PIX = 8;
 constexpr int TB_NW = VX_TB_WAVES, TB_NPX = 16 / TB_NW;   // waves per workgroup (8 or 4), pixels per wave in phase 1
 constexpr int TB_KS = TB_C / 32;                 // 10 k-steps of 32
 constexpr int TB_PCOLS = TB_HEADS * 8 * 16;      // 1024 packed columns: 8 blocks of 16 per head
-constexpr int TB_SLOT = 2 * 16 * TB_C * 2;       // 20480 B: a QKV chunk = [k-step 10][head of the pair 2][lane 64][16 B]
+constexpr int TB_WBYTES = 2 * 16 * TB_C * 2;     // 20480 B of weights per QKV chunk: [k-step 10][head of the pair 2][lane 64][16 B]
+constexpr int TB_SLOT = TB_WBYTES + 2 * 1024;    // + the chunk's bias / positional table, 16 x 16 fp32 per head: 22528 B
 constexpr int TB_QKV_CHUNKS = 32, TB_TILE_CHUNKS = 44;   // + 4 head pairs x 3 out-projection parts
 constexpr int WO_P01 = 20 * 1024, WO_P2 = 20 * 512;
 constexpr int WO_PAIR = 2 * WO_P01 + WO_P2;      // 51200 B per head pair
 constexpr int RING_OFF = 0;                      // 3 slots
-constexpr int O_OFF = 3 * TB_SLOT;               // 61440: O^T of the tile, [head pair][pixel][kb0 1024 | kb1 1024 | kb2 512]
+constexpr int O_OFF = 3 * TB_SLOT;               // 67584: O^T of the tile, [head pair][pixel][kb0 1024 | kb1 1024 | kb2 512]
 constexpr int O_PIX = 2560, O_PAIR = TB_PIX * O_PIX;     // 20480 per head pair
-constexpr int CS_OFF = O_OFF + 4 * O_PAIR;       // 143360: column sums of the folded weight, packed column order (fp32)
-constexpr int BO_OFF = CS_OFF + TB_PCOLS * 4;    // 147456: out-projection bias (fp32)
-constexpr int ST_OFF = BO_OFF + TB_C * 4;        // 148736: (rstd, -mean rstd) of the tile's rows, [pixel][frame]
-constexpr int TB_LDS = ST_OFF + TB_PIX * TB_F * 8;   // 149760 <= 163840
+constexpr int CS_OFF = O_OFF + 4 * O_PAIR;       // 149504: column sums of the folded weight, packed column order (fp32)
+constexpr int BO_OFF = CS_OFF + TB_PCOLS * 4;    // 153600: out-projection bias (fp32)
+constexpr int ST_OFF = BO_OFF + TB_C * 4;        // 154880: (rstd, -mean rstd) of the tile's rows, [pixel][frame]
+constexpr int TB_LDS = ST_OFF + TB_PIX * TB_F * 8;   // 155904 <= 163840
 
 // Compile-time ablation switches (tools/build_tb_variants.sh; never defined for the product library):
 //   1 no weight copies after the prologue   2 no attention (O = the V rows)   4 no LayerNorm fold / tables
@@ -90,18 +91,6 @@ __device__ __forceinline__ void tb_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
-// 16-byte global load the compiler does not track (it would put a vmcnt(0) - i.e. a wait for every LDS-DMA copy issued
-// since - in front of the first use): issued before a chunk's copies, completed by tb_tab_wait<copies issued since>
-__device__ __forceinline__ f32x4_t tb_gload(const float* addr) {
-  f32x4_t v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-template <int N>
-__device__ __forceinline__ void tb_tab_wait(f32x4_t& a) {
-  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory");
-}
-
 // packed column (head, block, row) -> column of the [3 C] q | k | v projection, or -1 (zero padding)
 //   block 0 / 1: q 0..15 / 16..31   2 / 3: k   4: q 32..39 | k 32..39   5 / 6: v 0..15 / 16..31   7: v 32..39 | zero
 __host__ __device__ inline int tb_src_col(int head, int blk, int r) {
@@ -121,7 +110,7 @@ __host__ __device__ inline int tb_src_col(int head, int blk, int r) {
 __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(const vx_tblock_params p,
                                                                                  const float scale_log2e) {
   constexpr int NW = TB_NW, NT = 64 * NW, NPX = TB_NPX;
-  constexpr int CPW = (20 + NW - 1) / NW;         // copies per wave and chunk (slots past the end repeat a block)
+  constexpr int CPW = (22 + NW - 1) / NW;         // copies per wave and chunk (slots past the end repeat a block)
   constexpr int SNJ = 20 / (NW / 2);              // out-projection column blocks per wave
   constexpr int NX = NPX * TB_KS;                 // loads of one wave's x rows
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -154,8 +143,6 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
 
   const char* __restrict__ wq = (const char*)p.wqkv_t;
   const char* __restrict__ wo = (const char*)p.wo_t;
-  const float* __restrict__ tb = p.tb;
-  const float* __restrict__ tbt = p.tbt;
   const bf16_t* __restrict__ x = (const bf16_t*)p.x;
   const float2* __restrict__ st_in = reinterpret_cast<const float2*>(p.ln_stats);
   const float* cs_tab = reinterpret_cast<const float*>(smem + CS_OFF);
@@ -183,16 +170,17 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
   auto issue = [&](int c, int slot, int q) {        // q-th copy of this wave for chunk c (0 .. 43) into ring slot `slot`
     if (TABL(1) && in_loop) return;
     const char* src;
-    int nblk = 20;
+    int nblk = 22;
     if (c < TB_QKV_CHUNKS) {
       src = wq + (size_t)c * TB_SLOT;
     } else {
+      nblk = 20;
       const int hp2 = (c - TB_QKV_CHUNKS) / 3, part = (c - TB_QKV_CHUNKS) - 3 * hp2;
       src = wo + (size_t)hp2 * WO_PAIR + part * WO_P01;
       if (part == 2) nblk = 10;
     }
     const int iq = wave + NW * q;                                   // constant divisors: no scalar division sequence
-    const int blk = nblk == 10 ? iq % 10 : iq % 20;
+    const int blk = nblk == 10 ? iq % 10 : (nblk == 20 ? iq % 20 : iq % 22);
     glds16_s(src + blk * 1024, lane16, lds0 + RING_OFF + slot * TB_SLOT + blk * 1024);
   };
   {
@@ -275,11 +263,13 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
           tb_wait_vm<CPW>();
           tb_barrier();
         }
-        // bias + positional row of the block's columns (V blocks: transposed table), issued BEFORE this iteration's copies
         const int pc = (head * 8 + blk) * 16;
-        f32x4_t tq = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (!TABL(4)) tq = blk < 5 ? tb_gload(tb + lrow * TB_PCOLS + pc + 4 * lq) : tb_gload(tbt + (pc + lrow) * TB_F + 4 * lq);
         const char* wb = smem + RING_OFF + slot * TB_SLOT + wn * 1024 + lane * 16;
+        // bias + positional row of the block's 16 columns, travelling with the chunk: [frame][column] for the transposed
+        // blocks, [column][frame] for the V blocks - either way this lane's four values sit at [lrow][4 lq .. + 3]
+        float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!TABL(4))
+          tq = *reinterpret_cast<const float4*>(smem + RING_OFF + slot * TB_SLOT + TB_WBYTES + wn * 1024 + (lrow * 16 + 4 * lq) * 4);
         const int cn = next2(c), sn = slot2();
         f32x4_t P[NPX];
 #pragma unroll
@@ -307,16 +297,18 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
           }
         }
         // bias / LayerNorm fold / rounding into the block's packed home
-        if (!TABL(4)) tb_tab_wait<CPW>(tq);      // CPW copies were issued since the table load
         if constexpr (blk < 5) {
           const float4 s4 = *reinterpret_cast<const float4*>(cs_tab + pc + 4 * lq);
 #pragma unroll
           for (int i = 0; i < NPX; ++i) {
-            const float v0 = fmaf(rs[i], P[i][0], fmaf(rm[i], s4.x, tq[0]));
-            const float v1 = fmaf(rs[i], P[i][1], fmaf(rm[i], s4.y, tq[1]));
-            const float v2 = fmaf(rs[i], P[i][2], fmaf(rm[i], s4.z, tq[2]));
-            const float v3 = fmaf(rs[i], P[i][3], fmaf(rm[i], s4.w, tq[3]));
-            const uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            const float v0 = fmaf(rs[i], P[i][0], fmaf(rm[i], s4.x, tq.x));
+            const float v1 = fmaf(rs[i], P[i][1], fmaf(rm[i], s4.y, tq.y));
+            const float v2 = fmaf(rs[i], P[i][2], fmaf(rm[i], s4.z, tq.z));
+            const float v3 = fmaf(rs[i], P[i][3], fmaf(rm[i], s4.w, tq.w));
+            uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            // pinned here: otherwise the compiler sinks the fold of one of the pixels down to the attention phase and keeps
+            // accumulators, table values and column sums of five blocks alive instead of two packed registers each
+            asm volatile("" : "+v"(pk.x), "+v"(pk.y));
             if constexpr (blk < 2) Qp[i][blk] = pk;
             else if constexpr (blk < 4) Kp[i][blk - 2] = pk;
             else Mp[i] = pk;
@@ -328,11 +320,13 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
             // (rstd, -mean rstd) of frames 4 lq .. 4 lq + 3 of pixel NPX wm + i
             const float4 a = *reinterpret_cast<const float4*>(smem + ST_OFF + ((NPX * wm + i) * TB_F + 4 * lq) * 8);
             const float4 b = *reinterpret_cast<const float4*>(smem + ST_OFF + ((NPX * wm + i) * TB_F + 4 * lq + 2) * 8);
-            const float v0 = fmaf(a.x, P[i][0], fmaf(a.y, s1, tq[0]));
-            const float v1 = fmaf(a.z, P[i][1], fmaf(a.w, s1, tq[1]));
-            const float v2 = fmaf(b.x, P[i][2], fmaf(b.y, s1, tq[2]));
-            const float v3 = fmaf(b.z, P[i][3], fmaf(b.w, s1, tq[3]));
-            Vp[i][blk - 5] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            const float v0 = fmaf(a.x, P[i][0], fmaf(a.y, s1, tq.x));
+            const float v1 = fmaf(a.z, P[i][1], fmaf(a.w, s1, tq.y));
+            const float v2 = fmaf(b.x, P[i][2], fmaf(b.y, s1, tq.z));
+            const float v3 = fmaf(b.z, P[i][3], fmaf(b.w, s1, tq.w));
+            uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            asm volatile("" : "+v"(pk.x), "+v"(pk.y));
+            Vp[i][blk - 5] = pk;
           }
         }
         advance();
@@ -507,25 +501,36 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
 // bias + positional rows -> tb [frame][packed column] and tbt [packed column][frame]; column sums -> packed order
 __global__ void tblock_pack_kernel(const bf16_t* __restrict__ wqkv, const float* __restrict__ bias,
                                    const float* __restrict__ colsum, const float* __restrict__ pe, int pe_ld,
-                                   const bf16_t* __restrict__ wo, bf16_t* __restrict__ wqkv_t, bf16_t* __restrict__ wo_t,
-                                   float* __restrict__ tb, float* __restrict__ tbt, float* __restrict__ colsum_p) {
-  const int n_w = TB_QKV_CHUNKS * (TB_SLOT / 16);                // 16-byte items of the QKV stream
+                                   const bf16_t* __restrict__ wo, char* __restrict__ wqkv_t, bf16_t* __restrict__ wo_t,
+                                   float* __restrict__ colsum_p) {
+  const int n_w = TB_QKV_CHUNKS * (TB_WBYTES / 16);              // 16-byte weight items of the QKV stream
+  const int n_t = TB_QKV_CHUNKS * 2 * 256;                       // table floats of the QKV stream
   const int n_o01 = 4 * 2 * 20 * 64, n_o2 = 4 * 20 * 64;         // 16-byte items of parts 0 / 1, 8-byte items of part 2
-  const int n_tab = TB_F * TB_PCOLS;
-  const int total = n_w + n_o01 + n_o2 + n_tab + TB_PCOLS;
+  const int total = n_w + n_t + n_o01 + n_o2 + TB_PCOLS;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     if (idx < n_w) {
-      // [chunk = 8 hp + blk][ks][head of the pair][lane][8]
+      // chunk = 8 hp + blk: [ks][head of the pair][lane][8]
       const int lane = idx & 63, wn = (idx >> 6) & 1, ks = (idx >> 7) % TB_KS, ch = idx / (128 * TB_KS);
       const int hp = ch >> 3, blk = ch & 7, head = 2 * hp + wn;
       const int col = tb_src_col(head, blk, lane & 15);
       uint4 v = make_uint4(0, 0, 0, 0);
       if (col >= 0) v = *reinterpret_cast<const uint4*>(wqkv + (size_t)col * TB_C + 32 * ks + 8 * (lane >> 4));
-      *reinterpret_cast<uint4*>(wqkv_t + (size_t)idx * 8) = v;
-    } else if (idx < n_w + n_o01) {
+      *reinterpret_cast<uint4*>(wqkv_t + (size_t)ch * TB_SLOT + (size_t)(idx - ch * (128 * TB_KS)) * 16) = v;
+    } else if (idx < n_w + n_t) {
+      // behind the chunk's weights: [head of the pair][16][16] fp32 = bias + positional row, [frame][column] for the
+      // transposed blocks (0..4), [column][frame] for the V blocks
+      const int k = idx - n_w;
+      const int e = k & 255, wn = (k >> 8) & 1, ch = k >> 9;
+      const int hp = ch >> 3, blk = ch & 7, head = 2 * hp + wn;
+      const int fr = blk < 5 ? e >> 4 : e & 15, r = blk < 5 ? e & 15 : e >> 4;
+      const int col = tb_src_col(head, blk, r);
+      float v = 0.f;
+      if (col >= 0) v = (bias != nullptr ? bias[col] : 0.f) + (pe != nullptr ? pe[(size_t)fr * pe_ld + col] : 0.f);
+      *reinterpret_cast<float*>(wqkv_t + (size_t)ch * TB_SLOT + TB_WBYTES + wn * 1024 + e * 4) = v;
+    } else if (idx < n_w + n_t + n_o01) {
       // [hp][part 0 / 1][column block j][lane][8]: out column 16 j + (lane & 15); k slots 8 lq .. + 7 =
       // channels 4 lq .. + 3 and 16 + 4 lq .. + 3 of head 2 hp + part
-      const int k = idx - n_w;
+      const int k = idx - n_w - n_t;
       const int lane = k & 63, j = (k >> 6) % 20, part = (k / (64 * 20)) & 1, hp = k / (64 * 20 * 2);
       const int lq = lane >> 4, head = 2 * hp + part;
       const bf16_t* src = wo + (size_t)(16 * j + (lane & 15)) * TB_C + head * TB_D;
@@ -535,26 +540,18 @@ __global__ void tblock_pack_kernel(const bf16_t* __restrict__ wqkv, const float*
         dst[e] = src[4 * lq + e];
         dst[4 + e] = src[16 + 4 * lq + e];
       }
-    } else if (idx < n_w + n_o01 + n_o2) {
+    } else if (idx < n_w + n_t + n_o01 + n_o2) {
       // [hp][part 2][column block j][lane][4]: k slots 4 lq .. + 3 = channels 32 + 4 lq .. of head 2 hp (lq < 2),
       // 32 + 4 (lq - 2) .. of head 2 hp + 1 (lq >= 2)
-      const int k = idx - n_w - n_o01;
+      const int k = idx - n_w - n_t - n_o01;
       const int lane = k & 63, j = (k >> 6) % 20, hp = k / (64 * 20);
       const int lq = lane >> 4, head = 2 * hp + (lq >> 1);
       const bf16_t* src = wo + (size_t)(16 * j + (lane & 15)) * TB_C + head * TB_D + 32 + 4 * (lq & 1);
       bf16_t* dst = wo_t + (size_t)hp * (WO_PAIR / 2) + (size_t)(2 * WO_P01 / 2) + (size_t)(j * 64 + lane) * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) dst[e] = src[e];
-    } else if (idx < n_w + n_o01 + n_o2 + n_tab) {
-      const int k = idx - n_w - n_o01 - n_o2;
-      const int pc = k % TB_PCOLS, fr = k / TB_PCOLS;
-      const int col = tb_src_col(pc >> 7, (pc >> 4) & 7, pc & 15);
-      float v = 0.f;
-      if (col >= 0) v = (bias != nullptr ? bias[col] : 0.f) + (pe != nullptr ? pe[(size_t)fr * pe_ld + col] : 0.f);
-      tb[(size_t)fr * TB_PCOLS + pc] = v;
-      tbt[(size_t)pc * TB_F + fr] = v;
     } else {
-      const int pc = idx - (n_w + n_o01 + n_o2 + n_tab);
+      const int pc = idx - (n_w + n_t + n_o01 + n_o2);
       const int col = tb_src_col(pc >> 7, (pc >> 4) & 7, pc & 15);
       colsum_p[pc] = col >= 0 ? colsum[col] : 0.f;
     }
@@ -564,22 +561,22 @@ __global__ void tblock_pack_kernel(const bf16_t* __restrict__ wqkv, const float*
 }  // namespace
 
 extern "C" int vx_tblock_pack(const void* wqkv, const float* bias, const float* colsum, const float* pe_rows, int pe_ld,
-                              const void* wo, void* wqkv_t, void* wo_t, float* tb, float* tbt, float* colsum_p, int c,
-                              int heads, int f, void* stream_) {
+                              const void* wo, void* wqkv_t, void* wo_t, float* colsum_p, int c, int heads, int f,
+                              void* stream_) {
   VX_REQUIRE(wqkv != nullptr && colsum != nullptr && wo != nullptr && wqkv_t != nullptr && wo_t != nullptr &&
-                 tb != nullptr && tbt != nullptr && colsum_p != nullptr, "vx_tblock_pack: null pointer");
+                 colsum_p != nullptr, "vx_tblock_pack: null pointer");
   VX_REQUIRE(c == TB_C && heads == TB_HEADS && f == TB_F,
              "vx_tblock_pack: only C = %d, %d heads, %d frames (the 64x64 level) is built", TB_C, TB_HEADS, TB_F);
   VX_REQUIRE(pe_rows == nullptr || pe_ld >= 3 * TB_C, "vx_tblock_pack: pe_ld=%d", pe_ld);
   hipLaunchKernelGGL(tblock_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)wqkv, bias, colsum,
-                     pe_rows, pe_ld, (const bf16_t*)wo, (bf16_t*)wqkv_t, (bf16_t*)wo_t, tb, tbt, colsum_p);
+                     pe_rows, pe_ld, (const bf16_t*)wo, (char*)wqkv_t, (bf16_t*)wo_t, colsum_p);
   return vx_check_launch("vx_tblock_pack");
 }
 
 extern "C" int vx_tblock_fused(const vx_tblock_params* pp, void* stream_) {
   const vx_tblock_params& p = *pp;
-  VX_REQUIRE(p.x != nullptr && p.wqkv_t != nullptr && p.wo_t != nullptr && p.tb != nullptr && p.tbt != nullptr &&
-                 p.colsum_p != nullptr, "vx_tblock_fused: null pointer");
+  VX_REQUIRE(p.x != nullptr && p.wqkv_t != nullptr && p.wo_t != nullptr && p.colsum_p != nullptr,
+             "vx_tblock_fused: null pointer");
   VX_REQUIRE(p.c == TB_C && p.heads == TB_HEADS && p.f == TB_F,
              "vx_tblock_fused: only C = %d, %d heads, %d frames (the 64x64 level) is built", TB_C, TB_HEADS, TB_F);
   VX_REQUIRE(p.b > 0 && p.hw > 0 && (p.hw % TB_PIX) == 0, "vx_tblock_fused: hw=%d must be a multiple of %d", p.hw, TB_PIX);

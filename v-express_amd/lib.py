@@ -34,8 +34,7 @@ class TBlockParams(C.Structure):
     """Mirror of `vx_tblock_params` (include/vexpress_hip.h)."""
     _fields_ = [
         ("x", C.c_void_p), ("ldx", C.c_int32), ("b", C.c_int32), ("f", C.c_int32), ("hw", C.c_int32), ("c", C.c_int32),
-        ("heads", C.c_int32), ("wqkv_t", C.c_void_p), ("wo_t", C.c_void_p), ("tb", C.c_void_p), ("tbt", C.c_void_p),
-        ("colsum_p", C.c_void_p), ("bias_o", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
+        ("heads", C.c_int32), ("wqkv_t", C.c_void_p), ("wo_t", C.c_void_p), ("colsum_p", C.c_void_p), ("bias_o", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
         ("scale", C.c_float),
     ]
 
@@ -116,7 +115,7 @@ def _load():
     lib.vx_ff_fused.argtypes = [C.POINTER(FfParams), vp]
     lib.vx_ff_pack_weights.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     lib.vx_tblock_fused.argtypes = [C.POINTER(TBlockParams), vp]
-    lib.vx_tblock_pack.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.vx_tblock_pack.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.vx_groupnorm_fold_linear.argtypes = [vp, i32, i32, i32, i32, f32, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.vx_layernorm.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp]
     lib.vx_row_stats.argtypes = [vp, i32, i32, i32, f32, vp, vp]

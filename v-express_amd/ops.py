@@ -627,18 +627,17 @@ def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, hea
     hit = _TB_PACKED.get(key)
     if hit is None:
         dev = h.device
-        wqkv_t = torch.empty(655360 // 2, device=dev, dtype=BF16)
+        wqkv_t = torch.empty(720896 // 2, device=dev, dtype=BF16)
         wo_t = torch.empty(204800 // 2, device=dev, dtype=BF16)
-        tb, tbt = (torch.empty(16 * 1024, device=dev, dtype=torch.float32) for _ in range(2))
         cs = torch.empty(1024, device=dev, dtype=torch.float32)
         L.check(_lib.vx_tblock_pack(_ptr(wqkv_folded), _ptr(bqkv) if bqkv is not None else None, _ptr(colsum),
                                     _ptr(pe_rows) if pe_rows is not None else None,
                                     pe_rows.stride(0) if pe_rows is not None else 0, _ptr(wo), _ptr(wqkv_t), _ptr(wo_t),
-                                    _ptr(tb), _ptr(tbt), _ptr(cs), c, heads, f, _stream()), "vx_tblock_pack")
-        hit = _TB_PACKED[key] = (wqkv_folded, wo, pe_rows, wqkv_t, wo_t, tb, tbt, cs)   # sources kept alive: the key is their address
+                                    _ptr(cs), c, heads, f, _stream()), "vx_tblock_pack")
+        hit = _TB_PACKED[key] = (wqkv_folded, wo, pe_rows, wqkv_t, wo_t, cs)   # sources kept alive: the key is their address
     p = L.TBlockParams()
     p.x, p.ldx, p.b, p.f, p.hw, p.c, p.heads = h.data_ptr(), ldx, b, f, hw, c, heads
-    p.wqkv_t, p.wo_t, p.tb, p.tbt, p.colsum_p = (t.data_ptr() for t in hit[3:8])
+    p.wqkv_t, p.wo_t, p.colsum_p = (t.data_ptr() for t in hit[3:6])
     p.bias_o = bo.data_ptr() if bo is not None else None
     p.ln_stats = stats.data_ptr() if stats is not None else None
     p.ln_eps, p.scale = eps, (c // heads) ** -0.5
