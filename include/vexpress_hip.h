@@ -198,7 +198,10 @@ typedef struct {
   const float* colsum_p;
   const float* bias_o;       /* [c] or NULL */
   const float* ln_stats;     /* [m][2] or NULL */
-  float ln_eps, scale;       /* LayerNorm eps (ln_stats == NULL); softmax scale (head_dim^-0.5) */
+  float* stats_out;          /* [m][2] or NULL: (mean, rstd) of the rows written, for the next LayerNorm fold (one-pass
+                                variance like vx_gemm_params.row_stats_out; may alias ln_stats: a tile reads its own rows'
+                                entries before it writes them) */
+  float ln_eps, scale;       /* LayerNorm eps (ln_stats == NULL, stats_out); softmax scale (head_dim^-0.5) */
 } vx_tblock_params;
 int vx_tblock_pack(const void* wqkv, const float* bias, const float* colsum, const float* pe_rows, int pe_ld,
                    const void* wo, void* wqkv_t, void* wo_t, float* colsum_p, int c, int heads, int f, void* stream);

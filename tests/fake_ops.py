@@ -233,7 +233,7 @@ def ff_fused(h, w1_folded, b1, colsum, stats, w2, b2):
     return gemm(g, w2, b2, residual=h, out=h)
 
 
-def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, heads, stats=None, eps=1e-5):
+def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, heads, stats=None, stats_out=None, eps=1e-5):
     """vx_tblock_fused = the three launches it replaces, in place on h (statistics: the rows' own when none are given)."""
     if stats is None:
         stats = row_stats(h, eps)
@@ -241,7 +241,7 @@ def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, hea
     rb = pe_rows[:f].repeat(b, 1).contiguous() if pe_rows is not None else None
     qkv = gemm(h, wqkv_folded, bqkv, rowbias=rb, rows_per_group=hw, ln=(stats, colsum))
     a = temporal_attention(qkv, b=b, f=f, hw=hw, heads=heads, head_dim=c // heads)
-    return gemm(a, wo, bo, residual=h, out=h)
+    return gemm(a, wo, bo, residual=h, out=h, stats_out=stats_out, stats_eps=eps)
 
 
 def alloc_vt(seqs, heads, head_dim, n, device):

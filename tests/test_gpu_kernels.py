@@ -1016,9 +1016,16 @@ def test_tblock_fused_matches_the_three_launches(ops, b, hw, given_stats):
         qkv = ops.gemm(x, wqkv, bq, rowbias=pe[:f].repeat(b, 1).contiguous(), rows_per_group=hw, ln=(stats, colsum))
         a = ops.temporal_attention(qkv, b=b, f=f, hw=hw, heads=heads, head_dim=d)
         want = ops.gemm(a, wo, bo, residual=x)
+    so = stats.clone() if given_stats else torch.full((m, 2), float("nan"), device="cuda")    # given: in place, as the model does
     got = ops.tblock_fused(x.clone(), wqkv, bq, colsum, pe, wo, bo, b=b, f=f, hw=hw, heads=heads,
-                           stats=stats if given_stats else None)
+                           stats=so if given_stats else None, stats_out=so)
     torch.cuda.synchronize()
+    # stats_out: (mean, rstd) of the rows as stored, for the next LayerNorm fold
+    g64 = got.double()
+    mean, rstd = g64.mean(dim=1), torch.rsqrt(g64.var(dim=1, unbiased=False) + 1e-5)
+    assert torch.isfinite(so).all()
+    assert torch.allclose(so[:, 0].double(), mean, rtol=2e-5, atol=2e-6), (so[:, 0].double() - mean).abs().max()
+    assert torch.allclose(so[:, 1].double(), rstd, rtol=1e-4), ((so[:, 1].double() - rstd) / rstd).abs().max()
     diff = (got.float() - want.float()).abs()
     frac = (got != want).float().mean().item()
     scale = want.float().abs().max().item()

@@ -330,10 +330,9 @@ def _motion_module(P, x, *, b, f, H, W, heads, groups, shard=None, gn_next=False
     m = b * f_all * hw_t
     # row statistics of h for the folded LayerNorms: written by the GEMM that produces the rows (see the spatial block)
     folds = [_fold_on(A.get("ln_qkv")) for A in P.attn] + [_ff_fold_on(P)]
-    # attention blocks that run as ONE launch (ops.tblock_fused: the 64x64 level) take their LayerNorm statistics from
-    # the rows they hold: nobody has to produce statistics for them
+    # attention blocks that run as ONE launch (ops.tblock_fused: the 64x64 level): statistics in and out like the GEMMs
     fused = [folds[i] and ops.tblock_fused_applies(c, heads, f_all, hw_t) for i in range(len(P.attn))] + [False]
-    wants = [folds[i] and not fused[i] for i in range(len(folds))]          # consumers of row statistics
+    wants = folds                                                            # consumers of row statistics
     st = torch.empty((m, 2), device=x.device, dtype=torch.float32) if any(wants) else None
     if shard is not None:
         n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
@@ -345,8 +344,8 @@ def _motion_module(P, x, *, b, f, H, W, heads, groups, shard=None, gn_next=False
     for i, A in enumerate(P.attn):
         if fused[i]:
             ops.tblock_fused(h, A.ln_qkv.w, A.ln_qkv.b, A.ln_qkv.s, A.pe_rows, A.attn.out.w, A.attn.out.b, b=b, f=f_all,
-                             hw=hw_t, heads=heads)
-            have_st = False
+                             hw=hw_t, heads=heads, stats=st if have_st else None, stats_out=st if wants[i + 1] else None)
+            have_st = wants[i + 1]
             continue
         if folds[i]:
             if not have_st:

@@ -465,20 +465,24 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
     }
 
     // ---- x <- x + Y + bias: lane = frame lrow of pixel s2_pix0 + i, columns s2_col0 + 16 j + 4 lq .. + 3; in batches of
-    // five column blocks: all residual loads of a batch first, then its arithmetic and stores (a load -> use -> store
+    // JB column blocks: all residual loads of a batch first, then its arithmetic and stores (a load -> use -> store
     // chain per item would drain the store queue at every step: vmcnt counts stores too)
     bf16_t* __restrict__ out = (bf16_t*)p.x;
+    float so_s[4] = {0.f, 0.f, 0.f, 0.f}, so_q[4] = {0.f, 0.f, 0.f, 0.f};   // stats_out: this lane's share of row (pixel i, lrow)
+    constexpr int JB = 3;       // column blocks per batch (rv = 4 JB uint2: the epilogue is the register peak of the kernel)
 #pragma unroll
-    for (int jb = 0; jb < SNJ; jb += 5) {
-      uint2 rv[4][5];
+    for (int jb = 0; jb < SNJ; jb += JB) {
+      uint2 rv[4][JB];
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
+      for (int j = 0; j < JB; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          rv[i][j] = *reinterpret_cast<const uint2*>(out + (row0 + s2_pix0 + i) * p.ldx + lrow * frame_stride + s2_col0 +
-                                                     16 * (jb + j) + 4 * lq);
+          if (jb + j < SNJ)
+            rv[i][j] = *reinterpret_cast<const uint2*>(out + (row0 + s2_pix0 + i) * p.ldx + lrow * frame_stride + s2_col0 +
+                                                       16 * (jb + j) + 4 * lq);
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
+      for (int j = 0; j < JB; ++j) {
+        if (jb + j >= SNJ) continue;
         const int col = s2_col0 + 16 * (jb + j) + 4 * lq;
         const float4 b4 = *reinterpret_cast<const float4*>(bo_tab + col);
 #pragma unroll
@@ -488,9 +492,45 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
           const float v1 = Y[i][jb + j][1] + b4.y + __uint_as_float(r2.x & 0xffff0000u);
           const float v2 = Y[i][jb + j][2] + b4.z + __uint_as_float(r2.y << 16);
           const float v3 = Y[i][jb + j][3] + b4.w + __uint_as_float(r2.y & 0xffff0000u);
-          *reinterpret_cast<uint2*>(out + (row0 + s2_pix0 + i) * p.ldx + lrow * frame_stride + col) =
-              make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+          const uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+          *reinterpret_cast<uint2*>(out + (row0 + s2_pix0 + i) * p.ldx + lrow * frame_stride + col) = pk;
+          if (p.stats_out != nullptr) {        // of the STORED values, as vx_row_stats would read them back
+            const float r0 = __uint_as_float(pk.x << 16), r1 = __uint_as_float(pk.x & 0xffff0000u);
+            const float r2_ = __uint_as_float(pk.y << 16), r3 = __uint_as_float(pk.y & 0xffff0000u);
+            so_s[i] += (r0 + r1) + (r2_ + r3);
+            so_q[i] = fmaf(r0, r0, so_q[i]); so_q[i] = fmaf(r1, r1, so_q[i]);
+            so_q[i] = fmaf(r2_, r2_, so_q[i]); so_q[i] = fmaf(r3, r3, so_q[i]);
+          }
         }
+      }
+    }
+    // ---- stats_out: (mean, rstd) of the rows just written, for the LayerNorm fold of the NEXT consumer (the second
+    // attention block, the feed-forward).  A row's 320 columns sit in 4 lanes x NW / 2 waves: lanes fold over lq, waves
+    // meet in LDS - in the O^T region of head pair 0, which nobody has read since the third iteration of phase 2 and nobody
+    // writes before the eighth barrier of the next tile - one barrier, then wave w finishes rows 16 w .. 16 w + 15.  One-pass
+    // variance (E[x^2] - mean^2 from float32 sums in a fixed order), as the GEMM epilogue's row_stats_out.
+    if (p.stats_out != nullptr) {
+      float2* scr = reinterpret_cast<float2*>(smem + O_OFF);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a = so_s[i], b = so_q[i];
+        a = wave_xor_sum(a, 16); a = wave_xor_sum(a, 32);
+        b = wave_xor_sum(b, 16); b = wave_xor_sum(b, 32);
+        if (lq == 0) scr[((s2_pix0 + i) * TB_F + lrow) * (NW / 2) + s2_cg] = make_float2(a, b);
+      }
+      tb_barrier();
+      if (lane < 16) {
+        const int rl = 16 * wave + lane;                 // row of the tile: pixel rl / 16, frame rl % 16 (NW == 8: 128 rows)
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int cgi = 0; cgi < NW / 2; ++cgi) {
+          const float2 t = scr[rl * (NW / 2) + cgi];
+          a += t.x;
+          b += t.y;
+        }
+        const float mean = a * (1.0f / TB_C);
+        const float var = fmaxf(b * (1.0f / TB_C) - mean * mean, 0.f);
+        reinterpret_cast<float2*>(p.stats_out)[row0 + (rl >> 4) + (size_t)(rl & 15) * p.hw] = make_float2(mean, rsqrtf(var + p.ln_eps));
       }
     }
   }
@@ -498,7 +538,7 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
 }
 
 // ---- pack: folded [3 C, C] QKV weight -> fragment-major chunks; [C, C] out-projection -> the three parts per head pair;
-// bias + positional rows -> tb [frame][packed column] and tbt [packed column][frame]; column sums -> packed order
+// bias + positional rows -> the 16 x 16 table behind each chunk's weights; column sums -> packed order
 __global__ void tblock_pack_kernel(const bf16_t* __restrict__ wqkv, const float* __restrict__ bias,
                                    const float* __restrict__ colsum, const float* __restrict__ pe, int pe_ld,
                                    const bf16_t* __restrict__ wo, char* __restrict__ wqkv_t, bf16_t* __restrict__ wo_t,

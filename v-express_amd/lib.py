@@ -34,7 +34,7 @@ class TBlockParams(C.Structure):
     """Mirror of `vx_tblock_params` (include/vexpress_hip.h)."""
     _fields_ = [
         ("x", C.c_void_p), ("ldx", C.c_int32), ("b", C.c_int32), ("f", C.c_int32), ("hw", C.c_int32), ("c", C.c_int32),
-        ("heads", C.c_int32), ("wqkv_t", C.c_void_p), ("wo_t", C.c_void_p), ("colsum_p", C.c_void_p), ("bias_o", C.c_void_p), ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
+        ("heads", C.c_int32), ("wqkv_t", C.c_void_p), ("wo_t", C.c_void_p), ("colsum_p", C.c_void_p), ("bias_o", C.c_void_p), ("ln_stats", C.c_void_p), ("stats_out", C.c_void_p), ("ln_eps", C.c_float),
         ("scale", C.c_float),
     ]
 

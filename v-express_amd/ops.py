@@ -614,10 +614,12 @@ def tblock_fused_applies(c, heads, f, hw):
     return TB_FUSED[0] and LN_FOLD[0] and c == 320 and heads == 8 and f == 16 and hw % 8 == 0 and not FP8_PROJ[0]
 
 
-def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, heads, stats=None, eps=1e-5):
+def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, heads, stats=None, stats_out=None, eps=1e-5):
     """h += to_out(attention over f of (LN(h) + pe) Wqkv^T + b), in place on h [(b f) hw, C] (a tile of the kernel is 8
     pixels x their 16 frames: rows of other pixels are independent).  stats: (mean, rstd) per row, or None - the kernel
-    then takes them from the rows it holds.  Weights and tables are re-tiled once per layer (vx_tblock_pack)."""
+    then takes them from the rows it holds.  stats_out: float32 [rows, 2] that receives (mean, rstd) of the rows written
+    (for the next LayerNorm fold; may be the same tensor as stats).  Weights and tables are re-tiled once per layer
+    (vx_tblock_pack)."""
     _chk_bf16(h, "h")
     ldx, m = _row_stride(h)
     c = h.shape[-1]
@@ -640,6 +642,7 @@ def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, hea
     p.wqkv_t, p.wo_t, p.colsum_p = (t.data_ptr() for t in hit[3:6])
     p.bias_o = bo.data_ptr() if bo is not None else None
     p.ln_stats = stats.data_ptr() if stats is not None else None
+    p.stats_out = stats_out.data_ptr() if stats_out is not None else None
     p.ln_eps, p.scale = eps, (c // heads) ** -0.5
     with _hbm_op("tblock_fused", 2 * m * c * 2):                 # reads the rows once, writes them once (bf16)
         L.check(_lib.vx_tblock_fused(C.byref(p), _stream()), "vx_tblock_fused")
