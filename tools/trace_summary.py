@@ -8,11 +8,13 @@ import sys
 from collections import defaultdict
 
 rows = defaultdict(lambda: [0, 0.0])
+spans = []
 with open(sys.argv[1]) as f:
     r = csv.DictReader(f)
     for row in r:
         name = row.get("Kernel_Name") or row.get("kernel_name")
         s, e = int(row["Start_Timestamp"]), int(row["End_Timestamp"])
+        spans.append((s, e))
         name = re.sub(r"\(anonymous namespace\)::", "", name)
         name = name[:110]
         rows[name][0] += 1
@@ -23,3 +25,14 @@ tot = sum(v[1] for v in rows.values())
 print(f"total kernel time {tot/1e3:.1f} ms over {sum(v[0] for v in rows.values())} launches")
 for k, v in sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]:
     print(f"{v[1]/1e3:10.2f} ms {100*v[1]/tot:5.1f}% n={v[0]:6d} avg={v[1]/v[0]:9.1f} us  {k}")
+
+# idle time between consecutive kernels (one stream, in order): the dispatch-to-dispatch latency of dependent launches.
+# Gaps above 50 us are host stalls (model build, synchronisation points), not launch latency: listed apart.
+spans.sort()
+gaps = [spans[i + 1][0] - spans[i][1] for i in range(len(spans) - 1)]
+small = sorted(g * 1e-3 for g in gaps if 0 <= g < 50_000)
+big = [g * 1e-3 for g in gaps if g >= 50_000]
+if small:
+    print(f"# inter-kernel gaps < 50 us: n={len(small)} total {sum(small) / 1e3:.1f} ms ({100 * sum(small) / 1e3 / (tot / 1e3):.1f} % of kernel time), "
+          f"median {small[len(small) // 2]:.2f} us, p90 {small[int(0.9 * len(small))]:.2f} us; gaps >= 50 us: n={len(big)} total {sum(big) / 1e3:.1f} ms; "
+          f"overlapping launches: {sum(1 for g in gaps if g < 0)}")
