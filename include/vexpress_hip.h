@@ -130,6 +130,16 @@ typedef struct {
    * summation order per slab). */
   float* gn_ws;
   int32_t gn_groups, gn_hw;
+  /* Row statistics in TWO parts (round 4, n == 640 / k == 640: the 32x32 level, where one 256 x 320 tile of the persistent
+   * kernel holds half a row).  row_stats_parts == 2 (requires n == 640): row_stats_out is [m][2][2] = (sum, sum of squares)
+   * of the stored bf16 values of columns [0, 320) and [320, 640) of every row - each half comes out of one tile's epilogue,
+   * no pass re-reads the tensor (launches that do not run on the persistent kernel fill the same format with
+   * vx_row_stats_parts).  ln_stats_parts == 2 (requires k == 640 and a launch on the persistent kernel - ask
+   * vx_gemm_config_name; else VX_ERR_UNSUPPORTED: convert with vx_row_stats_finalize): ln_stats holds that format; the
+   * epilogue adds the two halves and takes mean = s / k, rstd = 1 / sqrt(max(0, q / k - mean^2) + ln_eps) itself (one-pass
+   * variance, see row_stats_out).  0 / 1 = the (mean, rstd) format. */
+  int32_t row_stats_parts, ln_stats_parts;
+  float ln_eps;
 } vx_gemm_params;
 
 int vx_gemm(const vx_gemm_params* p, void* stream);
@@ -251,6 +261,11 @@ int vx_layernorm(const void* x, int ldx, int rows, int c, float eps, const float
 /* Row statistics of a LayerNorm that is folded into the consuming GEMM (vx_gemm_params.ln_stats): stats[r] = (mean,
  * 1 / sqrt(var + eps)) of x[r, 0:c], two-pass variance in registers exactly as vx_layernorm computes it. */
 int vx_row_stats(const void* x, int ldx, int rows, int c, float eps, float* stats, void* stream);
+/* the two-part format of vx_gemm_params.row_stats_parts: stats[r][p] = (sum, sum of squares) of x[r, p * c / 2 : (p + 1) * c / 2] */
+int vx_row_stats_parts(const void* x, int ldx, int rows, int c, float* stats, void* stream);
+/* two-part sums [rows][2][2] -> (mean, rstd) [rows][2] with the arithmetic of the ln_stats_parts == 2 epilogue: for a consumer
+ * launch that does not run on the persistent kernel (only that kernel finishes the two-part format itself) */
+int vx_row_stats_finalize(const float* parts, int rows, int c, float eps, float* stats, void* stream);
 
 /* LayerNorm (or, with gamma == NULL, no normalisation) whose result is quantised per row to OCP e4m3 for an fp8
  * projection GEMM: out8[r, 0:c] = e4m3(y[r, :] / scale[r]) with y as vx_layernorm computes it (incl. the additive

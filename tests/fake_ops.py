@@ -89,10 +89,15 @@ def layernorm(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_e
 
 
 def row_stats(x, eps=1e-5, out=None):
+    """vx_row_stats: (mean, rstd) per row; into a [rows, 4] buffer (vx_row_stats_parts): (sum, sum of squares) of each half."""
     x2 = (x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x).double()
-    mean = x2.mean(dim=1)
-    var = x2.var(dim=1, unbiased=False)
-    st = torch.stack([mean, torch.rsqrt(var + eps)], dim=1).float()
+    if out is not None and out.shape[1] == 4:
+        h = x2.shape[1] // 2
+        st = torch.stack([x2[:, :h].sum(1), (x2[:, :h] ** 2).sum(1), x2[:, h:].sum(1), (x2[:, h:] ** 2).sum(1)], dim=1).float()
+    else:
+        mean = x2.mean(dim=1)
+        var = x2.var(dim=1, unbiased=False)
+        st = torch.stack([mean, torch.rsqrt(var + eps)], dim=1).float()
     if out is not None:
         assert out.dtype == torch.float32 and out.is_contiguous() and out.shape == st.shape
         out.copy_(st)
@@ -100,12 +105,19 @@ def row_stats(x, eps=1e-5, out=None):
     return st
 
 
-def _apply_ln(y, ln):
-    """vx_gemm_params.ln_stats: acc <- rstd[m] * (acc - mean[m] * colsum[n])"""
+def _apply_ln(y, ln, eps=1e-5):
+    """vx_gemm_params.ln_stats: acc <- rstd[m] * (acc - mean[m] * colsum[n]); [m, 4] statistics = two-part sums over the k
+    columns of the rows (ln_stats_parts = 2), finished here like the epilogue does"""
     if ln is None:
         return y
-    stats, colsum = ln
-    return stats[:, 1:2].double() * (y - stats[:, 0:1].double() * colsum.double()[None, :])
+    stats, colsum, *k = ln
+    st = stats.double()
+    if stats.shape[1] == 4:
+        kk = k[0]
+        mean = (st[:, 0] + st[:, 2]) / kk
+        var = ((st[:, 1] + st[:, 3]) / kk - mean * mean).clamp_min(0)
+        st = torch.stack([mean, torch.rsqrt(var + eps)], dim=1)
+    return st[:, 1:2] * (y - st[:, 0:1] * colsum.double()[None, :])
 
 
 def layernorm_fp8(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_entries=1):
@@ -183,7 +195,7 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=0
     else:
         assert a.dtype == BF16 and w.dtype == BF16 and a.stride(-1) == 1 and w.is_contiguous()
         y = _conv_rows(a.reshape(-1, a.shape[-1]), None if a2 is None else a2.reshape(-1, a2.shape[-1]), w, geom)
-    y = _apply_ln(y, ln)
+    y = _apply_ln(y, None if ln is None else (*ln, a.shape[-1]))
     if bias is not None:
         assert bias.dtype == torch.float32
         y = y + bias
@@ -216,7 +228,7 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=0
 
 
 def geglu(a, w_interleaved, bias_interleaved, out=None, ln=None):
-    y = _apply_ln(a.double() @ w_interleaved.double().t(), ln)
+    y = _apply_ln(a.double() @ w_interleaved.double().t(), None if ln is None else (*ln, a.shape[-1]))
     if bias_interleaved is not None:
         y = y + bias_interleaved
     blk = y.view(y.shape[0], -1, 2, 8)                      # blocks of 8 value columns followed by their 8 gates
@@ -253,7 +265,7 @@ def gemm_split(a, w, bias, parts, *, part_cols, seq_len=0, head_dim=0, geom=None
         x, wt = _dequant(a, w)
         y = x @ wt.t()
     else:
-        y = _apply_ln(a.double() @ w.double().t(), ln)
+        y = _apply_ln(a.double() @ w.double().t(), None if ln is None else (*ln, a.shape[-1]))
     if bias is not None:
         y = y + bias
     for i, (kind, t) in enumerate(parts):

@@ -1042,3 +1042,73 @@ def test_tblock_fused_matches_the_three_launches(ops, b, hw, given_stats):
     o = F.scaled_dot_product_attention(q, k, v).permute(0, 3, 1, 2, 4).reshape(m, c)
     ref = xf + o.to(BF).float() @ wo.float().t() + bo
     check(got, ref, f"tblock_fused b={b} hw={hw} vs float32", rel=8e-3)
+
+
+# ------------------------------------------------------------- round 4: row statistics in two parts (n = k = 640)
+def _half_sums(x):
+    x64 = x.double()
+    h = x64.shape[1] // 2
+    return torch.stack([x64[:, :h].sum(1), (x64[:, :h] ** 2).sum(1), x64[:, h:].sum(1), (x64[:, h:] ** 2).sum(1)], dim=1)
+
+
+@pytest.mark.parametrize("m,k,res,ring", [(256 * 384, 640, True, True), (256 * 100, 2560, True, True), (256 * 128, 640, False, True),
+                                          (3000, 640, True, False)])
+def test_gemm_row_stats_two_parts(ops, m, k, res, ring):
+    """vx_gemm_params.row_stats_parts = 2 (n = 640): (sum, sum of squares) of each half of every STORED bf16 row, from the
+    epilogue of the persistent kernel's two column tiles (no pass re-reads the tensor) or - a launch off that kernel - from
+    vx_row_stats_parts; against float64 sums of the tensor the launch wrote.  The output must not change; a launch over
+    half the rows gives the same bits."""
+    n = 640
+    a, w = rnd(m, k), rnd(n, k, scale=k ** -0.5, seed=1)
+    bias = rnd(n, seed=2, dtype=torch.float32) + 0.5
+    r = rnd(m, n, seed=3) if res else None
+    st = torch.full((m, 4), float("nan"), device="cuda")
+    with ops.GemmProfile() as prof:
+        out = ops.gemm(a, w, bias, residual=r, stats_out=st)
+    assert _ring_used(prof) == ring, prof.records[0][3]
+    assert torch.equal(out, ops.gemm(a, w, bias, residual=r))
+    want = _half_sums(out)
+    assert torch.isfinite(st).all()
+    assert torch.allclose(st.double(), want, rtol=3e-6, atol=2e-3), (st.double() - want).abs().max()
+    if ring and (m // 2) % 256 == 0 and (m // 2 // 256) * 2 >= 192:          # (the half launch stays on the persistent kernel)
+        st2 = torch.empty((m // 2, 4), device="cuda")
+        ops.gemm(a[:m // 2], w, bias, residual=None if r is None else r[:m // 2], stats_out=st2)
+        assert torch.equal(st2, st[:m // 2])
+    st3 = ops.row_stats(out, out=torch.empty((m, 4), device="cuda"))          # vx_row_stats_parts itself
+    assert torch.allclose(st3.double(), want, rtol=3e-6, atol=2e-3)
+
+
+@pytest.mark.parametrize("m,n,kind", [(256 * 128, 640, "store"), (256 * 128, 1920, "store"), (256 * 64, 5120, "geglu"),
+                                      (256 * 128, 1920, "split"), (2000, 640, "store")])
+def test_layernorm_fold_from_two_part_statistics(ops, m, n, kind):
+    """vx_gemm_params.ln_stats_parts = 2 (k = 640): the folded-LayerNorm epilogue of the persistent kernel finishes the
+    two-part sums itself (STORE and GEGLU); launches off that kernel (the QKV split of the classic tile, small problems)
+    get them finished by vx_row_stats_finalize first.  Against the same launch fed (mean, rstd) of vx_row_stats: the two
+    differ only by the one-pass variance (rstd within 1e-4)."""
+    k = 640
+    x = rnd(m, k) * 1.3 + 0.4
+    w = rnd(n, k, scale=k ** -0.5, seed=1)
+    b = rnd(n, seed=2, dtype=torch.float32) * 0.2
+    colsum = w.float().sum(dim=1).contiguous()
+    st2 = ops.row_stats(x)
+    st4 = ops.row_stats(x, out=torch.empty((m, 4), device="cuda"))
+    if kind == "store":
+        got, want = ops.gemm(x, w, b, ln=(st4, colsum)), ops.gemm(x, w, b, ln=(st2, colsum))
+    elif kind == "geglu":
+        got, want = ops.geglu(x, w, b, ln=(st4, colsum)), ops.geglu(x, w, b, ln=(st2, colsum))
+    else:
+        heads, seq = 8, 64
+        d = (n // 3) // heads
+
+        def run(st):
+            q = torch.empty((m, n // 3), device="cuda", dtype=BF)
+            kk = torch.empty((m, n // 3), device="cuda", dtype=BF)
+            vt = ops.alloc_vt(m // seq, heads, d, seq, "cuda")
+            ops.gemm_split(x, w, b, [("rows", q), ("rows", kk), ("vt", vt)], part_cols=n // 3, seq_len=seq, head_dim=d,
+                           ln=(st, colsum))
+            return torch.cat([q.float(), kk.float(), vt[..., :seq].float().permute(0, 3, 1, 2).reshape(m, n // 3)], dim=1)
+        got, want = run(st4), run(st2)
+    diff = (got.float() - want.float()).abs()
+    frac = (got != want).float().mean().item()
+    print(f"[ln fold, two-part statistics {kind} m={m} n={n}] max|diff| {diff.max().item():.4g}, differing {100 * frac:.3g} %")
+    assert diff.max().item() <= 2 ** -6 * want.float().abs().max().item() and frac < 0.02

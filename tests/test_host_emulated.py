@@ -116,6 +116,20 @@ def test_round3_fused_paths_host_composition_vs_reference_golden(emulated, monke
           f"fused vs default {rel_l2(fused, base):.4g}")
     assert rel_l2(fused, gold) <= 3e-2 and rel_l2(base, gold) <= 3e-2
     assert not torch.equal(fused, base) and rel_l2(fused, base) <= 2e-2
+    # round 4: row statistics as two-part sums ([rows, 4] buffers; vx_gemm_params.row_stats_parts / ln_stats_parts), forced
+    # on at every width of this model - producers write the halves' sums, consumers finish them
+    made = []
+    real_buffer = ops.stats_buffer
+
+    def counting_buffer(rows, c, device):
+        made.append(real_buffer(rows, c, device).shape[1])
+        return real_buffer(rows, c, device)
+    monkeypatch.setattr(ops, "STATS_PARTS_WIDTHS", set(range(8, 4096, 8)))
+    monkeypatch.setattr(ops, "stats_buffer", counting_buffer)
+    parts = unet(x, t, encoder_hidden_states=ehs, kps_features=inp["kps_features"], return_dict=False)[0]
+    assert made and all(w_ == 4 for w_ in made)
+    print(f"[two-part row statistics] vs one-part {rel_l2(parts, fused):.4g}, vs golden {rel_l2(parts, gold):.4g}")
+    assert rel_l2(parts, fused) <= 2e-2 and rel_l2(parts, gold) <= 3e-2      # (bf16 rounding flips, like fused vs default)
 
 
 @pytest.mark.parametrize("name", ["aligned_F10_c4o2", "reflected_F11_c4o2", cases.NOCFG_CASE[0]])

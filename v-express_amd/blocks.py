@@ -188,7 +188,7 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
     # LayerNorm (at the 64x64 level straight from the epilogue's registers: ops.gemm(stats_out=...))
     f_qkv, f_q15, f_q2 = _fold_on(P.get("ln_qkv")), _fold_on(P.get("ln_q15")), _fold_on(P.get("ln_q2"))
     f_ff = _ff_fold_on(P)
-    st = torch.empty((m, 2), device=x.device, dtype=torch.float32) if (f_qkv or f_q15 or f_q2 or f_ff) else None
+    st = ops.stats_buffer(m, c, x.device) if (f_qkv or f_q15 or f_q2 or f_ff) else None
     h = _norm_proj_in(P, x, frames, hw, groups, stats_out=st if f_qkv else None)
     # A batch item without a bank (the unconditional CFG half) gets exactly w_ref * attn1_5.to_out.bias from block 1.5,
     # and - when its audio tokens are all zero as well - exactly w_aud * attn2.to_out.bias from block 2 (SURVEY.md App.
@@ -333,7 +333,7 @@ def _motion_module(P, x, *, b, f, H, W, heads, groups, shard=None, gn_next=False
     # attention blocks that run as ONE launch (ops.tblock_fused: the 64x64 level): statistics in and out like the GEMMs
     fused = [folds[i] and ops.tblock_fused_applies(c, heads, f_all, hw_t) for i in range(len(P.attn))] + [False]
     wants = folds                                                            # consumers of row statistics
-    st = torch.empty((m, 2), device=x.device, dtype=torch.float32) if any(wants) else None
+    st = ops.stats_buffer(m, c, x.device) if any(wants) else None
     if shard is not None:
         n = ops.groupnorm(x, P.norm.g, P.norm.b, frames=frames, hw=hw, groups=groups, eps=1e-6, silu=False)
         n = shard.to_pixel_shard(n, b, f)

@@ -893,6 +893,18 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
   if (p.row_stats_out != nullptr)
     VX_REQUIRE(p.epi == VX_EPI_STORE && !p.out_f32 && p.row_stats_eps > 0.f && p.out != nullptr,
                "vx_gemm: row_stats_out needs the STORE epilogue into bf16 and row_stats_eps > 0");
+  VX_REQUIRE(p.row_stats_parts == 0 || p.row_stats_parts == 1 || (p.row_stats_parts == 2 && p.n == 640),
+             "vx_gemm: row_stats_parts=%d (0 / 1, or 2 with n == 640; n=%d)", p.row_stats_parts, p.n);
+  if (p.ln_stats != nullptr && p.ln_stats_parts == 2) {
+    if (p.k != 640 || !(p.ln_eps > 0.f) || !vx_gemm_ring_eligible(p)) {
+      vx_set_error("vx_gemm: ln_stats_parts = 2 needs k == 640, ln_eps > 0 and a launch on the persistent kernel (k=%d m=%d "
+                   "n=%d): convert with vx_row_stats_finalize", p.k, p.m, p.n);
+      return VX_ERR_UNSUPPORTED;
+    }
+  } else {
+    VX_REQUIRE(p.ln_stats_parts == 0 || p.ln_stats_parts == 1 || p.ln_stats == nullptr,
+               "vx_gemm: ln_stats_parts=%d (0 / 1 / 2)", p.ln_stats_parts);
+  }
   if (p.w_group_rows != 0)
     VX_REQUIRE(p.w_group_rows > 0 && (p.m % p.w_group_rows) == 0 && p.epi == VX_EPI_STORE && !p.a_fp8 && p.splitk <= 1,
                "vx_gemm: w_group_rows=%d must divide m=%d (STORE epilogue, no fp8 / split-K)", p.w_group_rows, p.m);
@@ -904,6 +916,7 @@ extern "C" int vx_gemm(const vx_gemm_params* pp, void* stream_) {
   const int rc = vx_gemm_dispatch(p, stream);
   if (rc != VX_OK || p.row_stats_out == nullptr) return rc;
   if (vx_gemm_ring_eligible(p) && vx_gemm_ring_writes_row_stats(p)) return rc;   // the epilogue wrote them
+  if (p.row_stats_parts == 2) return vx_row_stats_parts(p.out, p.ldc, p.m, p.n, p.row_stats_out, stream_);
   return vx_row_stats(p.out, p.ldc, p.m, p.n, p.row_stats_eps, p.row_stats_out, stream_);
 }
 

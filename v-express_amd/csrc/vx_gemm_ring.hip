@@ -529,11 +529,25 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
       float rs[8], rm[8];
       if constexpr (LNF) {
         const float2* __restrict__ st = reinterpret_cast<const float2*>(p.ln_stats);
+        if (p.ln_stats_parts == 2) {
+          // two-part format (k == 640): (sum, sum of squares) of each half of the row, finished here
+          const float inv_k = 1.0f / (float)p.k;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float2 t = st[row_base + 16 * i];
-          rs[i] = t.y;
-          rm[i] = -t.x * t.y;
+          for (int i = 0; i < 8; ++i) {
+            const float4 t = reinterpret_cast<const float4*>(st)[row_base + 16 * i];
+            const float mean = (t.x + t.z) * inv_k;
+            float var = (t.y + t.w) * inv_k - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            rs[i] = 1.0f / sqrtf(var + p.ln_eps);
+            rm[i] = -mean * rs[i];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float2 t = st[row_base + 16 * i];
+            rs[i] = t.y;
+            rm[i] = -t.x * t.y;
+          }
         }
       }
 #pragma unroll
@@ -705,12 +719,18 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
         if (tid < R_BM) {
           const float4 p01 = *reinterpret_cast<const float4*>(smem + STATS_OFF + tid * 32);
           const float4 p23 = *reinterpret_cast<const float4*>(smem + STATS_OFF + tid * 32 + 16);
-          const float inv_n = 1.0f / (float)R_BN;
-          const float mean = ((p01.x + p01.z) + (p23.x + p23.z)) * inv_n;
-          float var = ((p01.y + p01.w) + (p23.y + p23.w)) * inv_n - mean * mean;
-          var = var > 0.f ? var : 0.f;
-          reinterpret_cast<float2*>(p.row_stats_out)[tile_m * R_BM + tid] =
-              make_float2(mean, 1.0f / sqrtf(var + p.row_stats_eps));
+          const float s_t = (p01.x + p01.z) + (p23.x + p23.z), q_t = (p01.y + p01.w) + (p23.y + p23.w);
+          if (p.row_stats_parts == 2) {
+            // n == 640: this tile holds one half of every row - its (sum, sum of squares) is part tile_n of the row
+            reinterpret_cast<float2*>(p.row_stats_out)[(size_t)(tile_m * R_BM + tid) * 2 + tile_n] = make_float2(s_t, q_t);
+          } else {
+            const float inv_n = 1.0f / (float)R_BN;
+            const float mean = s_t * inv_n;
+            float var = q_t * inv_n - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            reinterpret_cast<float2*>(p.row_stats_out)[tile_m * R_BM + tid] =
+                make_float2(mean, 1.0f / sqrtf(var + p.row_stats_eps));
+          }
         }
       }
       if constexpr (GNS) {
@@ -957,7 +977,8 @@ int vx_gemm_ring_launch(const vx_gemm_params& p, hipStream_t stream) {
 
 // whether the ring launch of p fills p.row_stats_out itself (otherwise vx_gemm runs vx_row_stats on the output)
 bool vx_gemm_ring_writes_row_stats(const vx_gemm_params& p) {
-  return p.row_stats_out != nullptr && !p.a_fp8 && p.epi == VX_EPI_STORE && p.n == R_BN;
+  return p.row_stats_out != nullptr && !p.a_fp8 && p.epi == VX_EPI_STORE &&
+         (p.row_stats_parts == 2 ? p.n == 2 * R_BN : p.n == R_BN);
 }
 
 // GroupNorm partial sums from the STORE epilogue (vx_gemm_params.gn_ws): slabs per frame this launch writes, 0 = cannot

@@ -767,6 +767,63 @@ extern "C" int vx_layernorm_fp8(const void* x, int ldx, int rows, int c, float e
   return vx_check_launch("vx_layernorm_fp8");
 }
 
+// Two-part row statistics (vx_gemm_params.row_stats_parts): one wave per row, lanes 0-31 the first half of the row, lanes
+// 32-63 the second; (sum, sum of squares) per half, float32, fixed order
+__global__ __launch_bounds__(256) void row_stats_parts_kernel(const bf16_t* __restrict__ x, int ldx, int rows, int c,
+                                                              float4* __restrict__ stats) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+  const int hc = c >> 1;                                 // columns per half (a multiple of 8)
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    const bf16_t* src = x + (size_t)row * ldx + half * hc;
+    float sm = 0.f, sq = 0.f;
+    for (int ch = l32 * 8; ch < hc; ch += 32 * 8) {
+      float v[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(src + ch), v);
+      sm += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sq = fmaf(v[e], v[e], sq);
+    }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+      sm = wave_xor_sum(sm, m);
+      sq = wave_xor_sum(sq, m);
+    }
+    const float s1 = __shfl(sm, 32, 64), q1 = __shfl(sq, 32, 64);
+    if (lane == 0) stats[row] = make_float4(sm, sq, s1, q1);
+  }
+}
+
+extern "C" int vx_row_stats_parts(const void* x, int ldx, int rows, int c, float* stats, void* stream_) {
+  VX_REQUIRE(x != nullptr && stats != nullptr, "vx_row_stats_parts: null pointer");
+  VX_REQUIRE(rows > 0 && c > 0 && (c % 16) == 0 && (ldx % 8) == 0, "vx_row_stats_parts: bad shape");
+  int nblk = ceil_div(rows, 4);
+  if (nblk > 8192) nblk = 8192;
+  hipLaunchKernelGGL(row_stats_parts_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)x, ldx, rows, c,
+                     reinterpret_cast<float4*>(stats));
+  return vx_check_launch("vx_row_stats_parts");
+}
+
+// two-part sums -> (mean, rstd): for a consumer that only takes the finished format (a launch off the persistent kernel)
+__global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float4* __restrict__ parts, int rows, float inv_c,
+                                                                 float eps, float2* __restrict__ stats) {
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
+    const float4 t = parts[r];
+    const float mean = (t.x + t.z) * inv_c;
+    float var = (t.y + t.w) * inv_c - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    stats[r] = make_float2(mean, 1.0f / sqrtf(var + eps));
+  }
+}
+
+extern "C" int vx_row_stats_finalize(const float* parts, int rows, int c, float eps, float* stats, void* stream_) {
+  VX_REQUIRE(parts != nullptr && stats != nullptr && rows > 0 && c > 0 && eps > 0.f, "vx_row_stats_finalize: bad arguments");
+  int nblk = ceil_div(rows, 256);
+  if (nblk > 2048) nblk = 2048;
+  hipLaunchKernelGGL(row_stats_finalize_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream_,
+                     reinterpret_cast<const float4*>(parts), rows, 1.0f / (float)c, eps, reinterpret_cast<float2*>(stats));
+  return vx_check_launch("vx_row_stats_finalize");
+}
+
 extern "C" int vx_row_stats(const void* x, int ldx, int rows, int c, float eps, float* stats, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   VX_REQUIRE(x != nullptr && stats != nullptr, "vx_row_stats: null pointer");

@@ -67,6 +67,7 @@ class GemmParams(C.Structure):
         ("row_stats_out", C.c_void_p), ("row_stats_eps", C.c_float),
         ("w_group_rows", C.c_int32),
         ("gn_ws", C.c_void_p), ("gn_groups", C.c_int32), ("gn_hw", C.c_int32),
+        ("row_stats_parts", C.c_int32), ("ln_stats_parts", C.c_int32), ("ln_eps", C.c_float),
     ]
 
 
@@ -119,6 +120,8 @@ def _load():
     lib.vx_groupnorm_fold_linear.argtypes = [vp, i32, i32, i32, i32, f32, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.vx_layernorm.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp]
     lib.vx_row_stats.argtypes = [vp, i32, i32, i32, f32, vp, vp]
+    lib.vx_row_stats_parts.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.vx_row_stats_finalize.argtypes = [vp, i32, i32, f32, vp, vp]
     lib.vx_layernorm_fp8.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp, vp]
     lib.vx_attention.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp]
     lib.vx_attention_bounded.argtypes = [vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]

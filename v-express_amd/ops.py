@@ -308,21 +308,47 @@ def row_stats(x, eps=1e-5, out=None):
     ldx, rows = _row_stride(x)
     if out is None:
         out = torch.empty((rows, 2), device=x.device, dtype=torch.float32)
-    elif out.dtype != torch.float32 or not out.is_contiguous() or tuple(out.shape) != (rows, 2):
-        raise ValueError("row_stats: out must be a contiguous float32 [rows, 2] tensor")
+    elif out.dtype != torch.float32 or not out.is_contiguous() or tuple(out.shape) not in ((rows, 2), (rows, 4)):
+        raise ValueError("row_stats: out must be a contiguous float32 [rows, 2] (mean, rstd) or [rows, 4] (two-part sums) tensor")
     with _hbm_op("row_stats", rows * (2 * x.shape[-1] + 8)):
-        L.check(_lib.vx_row_stats(_ptr(x), ldx, rows, x.shape[-1], float(eps), _ptr(out), _stream()), "vx_row_stats")
+        if out.shape[1] == 4:
+            L.check(_lib.vx_row_stats_parts(_ptr(x), ldx, rows, x.shape[-1], _ptr(out), _stream()), "vx_row_stats_parts")
+        else:
+            L.check(_lib.vx_row_stats(_ptr(x), ldx, rows, x.shape[-1], float(eps), _ptr(out), _stream()), "vx_row_stats")
     return out
 
 
-def _set_ln(p, ln):
+# Row statistics in TWO parts (vx_gemm_params.row_stats_parts / ln_stats_parts): at the widths listed here a statistics
+# buffer is float32 [rows, 4] = (sum, sum of squares) of each half row instead of [rows, 2] = (mean, rstd) - the format is
+# the buffer's own width, so slices carry it.  At 640 channels (the 32x32 level) one tile of the persistent kernel holds
+# half a row: each half comes out of a tile's epilogue and the vx_row_stats pass behind the GEMM disappears.
+# VX_STATS_PARTS=0 restores the (mean, rstd) format everywhere (A/B knob).
+STATS_PARTS_WIDTHS = {640} if os.environ.get("VX_STATS_PARTS", "1") != "0" else set()
+
+
+def stats_buffer(rows, c, device):
+    """The row-statistics buffer of a residual stream of width c: [rows, 4] (two-part sums) or [rows, 2] (mean, rstd)."""
+    two = c in STATS_PARTS_WIDTHS and FUSED_STATS[0] and LN_FOLD[0] and not FP8_PROJ[0]
+    return torch.empty((rows, 4 if two else 2), device=device, dtype=torch.float32)
+
+
+def _set_ln(p, ln, eps=1e-5):
     if ln is None:
         return
     stats, colsum = ln
     if stats.dtype != torch.float32 or colsum.dtype != torch.float32 or not stats.is_contiguous() or \
-            stats.shape != (p.m, 2) or colsum.numel() != p.n:
-        raise ValueError("ln=(stats [m, 2] float32, colsum [n] float32) expected")
+            tuple(stats.shape) not in ((p.m, 2), (p.m, 4)) or colsum.numel() != p.n:
+        raise ValueError("ln=(stats [m, 2] or [m, 4] float32, colsum [n] float32) expected")
     p.ln_stats, p.ln_colsum = stats.data_ptr(), colsum.data_ptr()
+    if stats.shape[1] == 4:
+        # two-part sums: the persistent kernel finishes them in its epilogue; any other launch gets them finished first
+        p.ln_stats_parts, p.ln_eps = 2, float(eps)
+        if p.k != 640 or not _lib.vx_gemm_config_name(C.byref(p)).decode().startswith("gemm_ring"):
+            fin = torch.empty((p.m, 2), device=stats.device, dtype=torch.float32)
+            L.check(_lib.vx_row_stats_finalize(_ptr(stats), p.m, p.k, float(eps), _ptr(fin), _stream()),
+                    "vx_row_stats_finalize")
+            p.ln_stats, p.ln_stats_parts = fin.data_ptr(), 0
+            p._keep_ln = fin            # alive until the launch is enqueued (same stream: the allocator orders the reuse)
 
 
 def layernorm_fp8(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_entries=1):
@@ -532,11 +558,12 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
         p.ring_hint = _ring_hint(p)
     _set_ln(p, ln)
     if stats_out is not None:
-        if stats_out.dtype != torch.float32 or not stats_out.is_contiguous() or tuple(stats_out.shape) != (p.m, 2) \
-                or out_f32:
-            raise ValueError("stats_out must be a contiguous float32 [m, 2] tensor (bf16 output only)")
+        if stats_out.dtype != torch.float32 or not stats_out.is_contiguous() or out_f32 or \
+                tuple(stats_out.shape) not in ((p.m, 2), (p.m, 4)):
+            raise ValueError("stats_out must be a contiguous float32 [m, 2] / [m, 4] tensor (bf16 output only)")
         if FUSED_STATS[0]:
             p.row_stats_out, p.row_stats_eps = stats_out.data_ptr(), float(stats_eps)
+            p.row_stats_parts = 2 if stats_out.shape[1] == 4 else 0
     gst = None
     if gn is not None and GN_FUSED[0] and not p.a_fp8:
         groups, hw = gn
@@ -657,8 +684,8 @@ def gemm_split(a, w, bias, parts, *, part_cols, seq_len=0, head_dim=0, geom=None
     """One GEMM whose column ranges go to different destinations (ln: as in gemm).
     parts: list of ("rows", tensor[m, part_cols]) or ("vt", tensor[seqs, heads, head_dim, pitch])."""
     p, geom = _base_params(a, w, geom)
-    _set_ln(p, ln)
     p.epi = L.VX_EPI_SPLIT
+    _set_ln(p, ln)                      # (after the epilogue is known: two-part statistics ask which kernel will run)
     p.bias = bias.data_ptr() if bias is not None else None
     p.part_cols, p.n_parts = part_cols, len(parts)
     p.seq_len, p.head_dim = seq_len, head_dim
