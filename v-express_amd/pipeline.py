@@ -19,6 +19,8 @@ transformers module.  The benchmark and the loop parity tests pass the prologue 
 """
 from typing import Callable, List, Optional, Union
 
+import os
+
 import torch
 
 from . import ops
@@ -56,7 +58,7 @@ class VExpressPipeline:
         # merged calls measure 4-5 % faster (profiles/r02e_host_overhead.json: b = 3 74.0 ms vs 49.2 + 28.2 ms,
         # b = 4 94.1 vs 2 x 49.2 ms at 512x512, f = 16), which is what the 3-unit ranks of the 8-GPU config-4 run and
         # the multi-window single-GPU clips execute
-        self.units_per_call = 4
+        self.units_per_call = int(os.environ.get("VX_UNITS_PER_CALL", "4"))
         self.last_timing = {}
 
     # ------------------------------------------------------------------ plumbing
