@@ -27,6 +27,16 @@ def emulate_kernels():
     fake_ops.install(_Patch(), ops)
     unet_3d._UNetBase._need_gpu = lambda self: None
     vae.AutoencoderKLDecoder._need_gpu = lambda self: None
+    if os.environ.get("VX_TEST_FORCE_ROUND4") == "1":
+        force_round4_paths(ops)
+
+
+def force_round4_paths(ops, patch=setattr):
+    """The round-4 host paths at the small widths of the CPU models, where the routing rules would not pick them: every
+    temporal attention block as ONE `ops.tblock_fused` call (also in the pixel-shard layout of a frame-sharded unit), row
+    statistics as two-part sums ([rows, 4] buffers) at every width."""
+    patch(ops, "tblock_fused_applies", lambda c, heads, f, hw: True)
+    patch(ops, "STATS_PARTS_WIDTHS", set(range(8, 4096, 8)))
 
 
 def build_pipeline(device):

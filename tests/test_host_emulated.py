@@ -236,6 +236,34 @@ def test_sharded_loop_with_the_real_host_code_matches_single_process(emulated, w
         assert torch.isfinite(lat).all() and torch.equal(lat, ref), (rank, rel_l2(lat, ref))
 
 
+@pytest.mark.parametrize("world,S,F,cf,co", [(2, 2, 8, 8, 2), (2, 1, 14, 8, 2)])
+def test_sharded_loop_with_the_round4_paths_forced_on(emulated, monkeypatch, world, S, F, cf, co):
+    """The same comparison with the round-4 host paths forced on in every process (`dist_gpu_worker.force_round4_paths`):
+    the temporal attention blocks as single `ops.tblock_fused` calls - in the frame-sharded case on the pixel-shard layout
+    between the two all-to-alls - and two-part row statistics.  Sharding stays pure data movement: BIT-identical clips, and
+    the forced paths really ran (the clip differs from the default composition's by rounding only)."""
+    from v_express_amd import ops
+    default = W.run(F, cf, co, 2, 0, device="cpu")
+    W.force_round4_paths(ops, monkeypatch.setattr)
+    monkeypatch.setenv("VX_TEST_FORCE_ROUND4", "1")
+    ref = W.run(F, cf, co, 2, 0, device="cpu")
+    assert not torch.equal(ref, default) and rel_l2(ref, default) <= 3e-2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, F, cf, co, S, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, lat in results:
+        assert torch.isfinite(lat).all() and torch.equal(lat, ref), (rank, rel_l2(lat, ref))
+
+
 def build_end_to_end(device):
     """Every model of VExpressPipeline.__call__ at its small test configuration with seeded synthetic weights:
     (pipeline, state dicts, configs)."""
