@@ -613,6 +613,8 @@ def ff_fused(h, w1_folded, b1, colsum, stats, w2, b2):
     _chk_bf16(h, "h")
     ldx, m = _row_stride(h)
     c, hidden = h.shape[-1], w2.shape[1]
+    if stats.dtype != torch.float32 or not stats.is_contiguous() or tuple(stats.shape) != (m, 2):
+        raise ValueError("ff_fused: statistics must be a contiguous float32 [rows, 2] (mean, rstd) tensor")
     key = (w1_folded.data_ptr(), w2.data_ptr())
     hit = _FF_PACKED.get(key)
     if hit is None:
@@ -652,6 +654,9 @@ def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, hea
     c = h.shape[-1]
     if m != b * f * hw:
         raise ValueError("h rows != b*f*hw")
+    for t_ in (stats, stats_out):
+        if t_ is not None and (t_.dtype != torch.float32 or not t_.is_contiguous() or tuple(t_.shape) != (m, 2)):
+            raise ValueError("tblock_fused: statistics must be contiguous float32 [rows, 2] (mean, rstd) tensors")
     key = (wqkv_folded.data_ptr(), wo.data_ptr(), pe_rows.data_ptr() if pe_rows is not None else 0)
     hit = _TB_PACKED.get(key)
     if hit is None:
