@@ -513,3 +513,28 @@ def test_tblock_lane_level_emulation_matches_plain_math():
     # every column of q | k | v appears exactly once in the packed order, 8 pad rows per head
     cols = [E.src_col(h, blk, r) for h in range(8) for blk in range(8) for r in range(16)]
     assert sorted(c for c in cols if c >= 0) == list(range(960)) and cols.count(-1) == 64
+
+
+def test_tblock_weight_stream_protocol_happens_before():
+    """tools/tblock_schedule_check.py: the counted vmcnt waits, the per-chunk barrier and the three-slot ring of
+    csrc/vx_tblock.hip restated as a per-wave sequence of vector-memory operations (constants read from the kernel source):
+    every chunk read sits behind a wait that guarantees the reader's own copies of it (loads retire in order: a load is
+    complete iff at least N loads are younger at a vmcnt(N)), no slot is refilled before the barrier that ends the reads of
+    its previous content, the O^T / statistics parking areas are never written under a possible reader."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import tblock_schedule_check as S
+    K, reads, reuses = S.main()
+    assert K["NW"] == 8 and reads == 3 * 44 and reuses == 3 * 44
+    # the check is sharp: a wait that leaves the x loads of the next tile out of the count one iteration too long is caught
+    bad = dict(K)
+    ev = S.wave_program(K, 2)
+    k = [i for i, e in enumerate(ev) if e == ("B", (0, 35))][0] - 1
+    assert ev[k] == ("W", K["CPW"])
+    orig = S.wave_program
+    try:
+        S.wave_program = lambda KK, tiles: [("W", K["CPW"] + K["NX"]) if i == k else e for i, e in enumerate(orig(KK, tiles))]
+        with pytest.raises(AssertionError):
+            S.check_waits(bad, 2)
+    finally:
+        S.wave_program = orig
