@@ -19,15 +19,20 @@ F = 12*N + 4 (one window per GPU per step).  value = F*K / max-over-ranks time.
 (one per GPU, RCCL); a world size that differs from --gpus is an error.
 
 Extra objects in the JSON line:
-  roofline      dominant kernel = the MFMA GEMM / implicit-conv kernel (bound "mfma"): algorithmic FLOPs of every
-                vx_gemm launch (2*M*N*K) / its HIP-event duration, measured on ONE extra instrumented DDIM step after
-                the timed region (events on the launch stream); `whole_path` = fps * algorithmic FLOP per frame
-                (66.4 TFLOP/frame at F=16) / peak.
+  roofline      dominant kernel = the ONE kernel instantiation with the most time in a whole clip, chosen over ALL profiled
+                kernels - every vx_gemm launch (2*M*N*K FLOP), the attention kernels (4*B*H*Nq*Nkv*d at the true head dim),
+                the one-launch feed-forward / temporal blocks and the HBM-bound kernels (algorithmic bytes) - from HIP-event
+                durations of ONE extra instrumented DDIM step + the decode of 4 frames after the timed region (events on
+                the launch stream, each launch weighted by how often it runs per clip); `ranking` lists the top kernels
+                the same way; `whole_path` = fps * algorithmic FLOP per frame (66.4 TFLOP/frame at F=16) /
+                peak.
   cpu_baseline  the fp32 oracle (port of the reference path) on the host cores (thread count picked by probing the three
-                op classes of the UNet itself: conv, linear, SDPA): one CFG UNet3D forward at 512^2 with a 4-frame
-                window + one frame of VAE decode (a bounded sample), extrapolated linearly (x4 frames - the
-                reference's own modules scale 18.1 s -> 78.1 s from f=4 to f=16, SURVEY.md E6 - x25 steps, x16 frames
-                of decode).  The reference-module figure of SURVEY.md E6 is printed beside it.
+                op classes of the UNet itself - conv, linear, SDPA - over powers of two up to the physical core count):
+                a CFG UNet3D forward at 512^2 with a 2-frame window, one untimed warm-up + two timed runs (mean), + one
+                warmed frame of VAE decode (a bounded sample), extrapolated linearly (x8 frames - the reference's own
+                modules scale 18.1 s -> 78.1 s from f=4 to f=16, SURVEY.md E6 - x25 steps, x16 frames of decode); the
+                all-physical-cores figure and the reference-module figure of SURVEY.md E6 are printed beside it, with
+                core-seconds per frame for both.
 """
 import argparse
 import json
@@ -35,7 +40,12 @@ import os
 import sys
 import time
 
-import torch
+# CPU leg (cpu_baseline): OpenMP threads spread over the cores of the affinity mask, one per core, unless the caller chose
+# otherwise - must be in the environment before torch loads its OpenMP runtime.  The GPU legs run one host thread.
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+os.environ.setdefault("OMP_PLACES", "cores")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -51,12 +61,12 @@ UNET_SDPA_TFLOP_PER_FRAME_FWD = 0.245   # attn1 + attn1_5 SDPA (2 x 3.92 TFLOP /
 VAE_SDPA_TFLOP_PER_FRAME = 0.0344       # single-head mid attention over 4096 tokens, d = 512
 
 
-def flop_per_frame(num_frames, windows, steps, scale):
+def flop_per_frame(num_frames, windows, steps, scale, ctx=16):
     """Algorithmic TFLOP per decoded frame.  `scale` = pixel count relative to 512x512: the SDPA terms
     grow with scale^2, everything else with scale (768x768: 113.97 TFLOP per CFG forward, 5.754 per decoded frame)."""
     fwd = (UNET_TFLOP_PER_FRAME_FWD - UNET_SDPA_TFLOP_PER_FRAME_FWD) * scale + UNET_SDPA_TFLOP_PER_FRAME_FWD * scale ** 2
     vae = (VAE_TFLOP_PER_FRAME - VAE_SDPA_TFLOP_PER_FRAME) * scale + VAE_SDPA_TFLOP_PER_FRAME * scale ** 2
-    return steps * 2 * fwd * (16 * windows / num_frames) + vae
+    return steps * 2 * fwd * (ctx * windows / num_frames) + vae
 
 
 def _lib_sha():
@@ -100,7 +110,7 @@ def _rocprof_launch_avg(symbol):
         if not lines or f"lib_sha256={sha}" not in lines[0]:
             continue
         for ln in lines:
-            m = re.search(r"n=\s*(\d+)\s+avg=\s*([0-9.]+) us\s+void (.*)$", ln)
+            m = re.search(r"n=\s*(\d+)\s+avg=\s*([0-9.]+) us\s+(?:void )?(.*)$", ln)     # (non-template kernels: no "void")
             if m and m.group(3).startswith(symbol + "("):
                 return dict(avg_launch_us=float(m.group(2)), launches=int(m.group(1)), file=os.path.relpath(path, ROOT))
     return None
@@ -109,13 +119,33 @@ def _rocprof_launch_avg(symbol):
 HBM_PEAK_GBS = 8000.0              # HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy reaches
 
 
+def _physical_cores(avail):
+    """Physical cores inside the affinity mask (one per (package, core id) pair of /proc/cpuinfo); `avail` if unknown."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        cores, cpu, pkg = set(), None, 0
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("processor"):
+                    cpu = int(ln.split(":")[1])
+                elif ln.startswith("physical id"):
+                    pkg = int(ln.split(":")[1])
+                elif ln.startswith("core id") and cpu in allowed:
+                    cores.add((pkg, int(ln.split(":")[1])))
+        return min(len(cores), avail) if cores else avail
+    except (OSError, ValueError, AttributeError):
+        return avail
+
+
 def _pick_threads():
-    """Thread count for the CPU leg: the fastest of a few candidates on a probe made of the UNet's own three op classes
-    at the 64x64 level (3x3 conv, short-K linear, 4096-token SDPA with d = 40) - a 256-thread box runs the fp32 oracle
-    several times SLOWER with all hardware threads than with one thread per few cores, and a conv-only probe picked
-    counts that were wrong for the attention half of the forward."""
+    """Thread count for the CPU leg: the fastest of a few candidates - powers of two up to the PHYSICAL core count inside
+    the affinity mask, and that count itself - on a probe made of the UNet's own three op classes at the 64x64 level (3x3
+    conv, short-K linear, 4096-token SDPA with d = 40), two frames like the measured sample: a 256-thread box runs the
+    fp32 oracle several times SLOWER with all hardware threads than with one thread per few cores, and a conv-only probe
+    picked counts that were wrong for the attention half of the forward.  Returns (chosen, physical cores, {threads: s})."""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cands = sorted({c for c in (8, 16, 32, 64, 128, avail) if c <= avail} or {avail})
+    phys = _physical_cores(avail)
+    cands = sorted({c for c in (8, 16, 32, 64, 128, 256, phys) if c <= phys} or {phys})
     F = torch.nn.functional
     x = torch.randn(4, 320, 64, 64)
     wt = torch.randn(320, 320, 3, 3)
@@ -127,30 +157,37 @@ def _pick_threads():
         F.conv2d(x, wt, padding=1)
         F.linear(tok, wl)
         F.scaled_dot_product_attention(q, q, q)
-    best, best_t = cands[0], float("inf")
+    best, best_t, seen = cands[0], float("inf"), {}
     for c in cands:
         torch.set_num_threads(c)
-        probe()
+        probe()                                  # warm: thread team, primitive caches
         t0 = time.time()
         probe()
-        dt = time.time() - t0
+        probe()
+        dt = (time.time() - t0) / 2
+        seen[c] = dt
         if dt < best_t:
             best, best_t = c, dt
-    return best
+    return best, phys, seen
 
 
 def cpu_baseline(size, seconds_budget):
-    """Port (`oracle/`) of the reference path timed on the host cores, bounded sample."""
+    """Port (`oracle/`) of the reference path timed on the host cores, bounded sample: one CFG UNet3D
+    forward at 512x512 with a 2-frame window, run ONCE untimed (page-in of the weights, allocator and primitive caches,
+    thread team) and then TWICE timed - the mean of the two is the figure - plus, when the chosen thread count is not the
+    physical core count and the budget allows, one more timed forward on all physical cores (`all_cores`), plus one frame
+    of VAE decode (warmed the same way).  Threads: see _pick_threads; OMP_PROC_BIND / OMP_PLACES default to spread / cores
+    (set at the top of this file before torch loads OpenMP, never overriding the caller's), inside the affinity mask."""
     import oracle
     from oracle import unet as OU
     from oracle import vae as OV
     from v_express_amd import synth
-    threads = _pick_threads()
+    t_all = time.time()
+    threads, phys, probe = _pick_threads()
     torch.set_num_threads(threads)
     cfg, ocfg = synth.UNetConfig(), oracle.UNetConfig()
     h = w = size // 8
-    f = 4
-    t0 = time.time()
+    f = 2
     sd3 = synth.unet3d_state_dict(cfg)
     inp = synth.synthetic_inputs(cfg, f, h, w)
     banks = {}
@@ -174,28 +211,80 @@ def cpu_baseline(size, seconds_budget):
     rb = OU.reader_banks(banks)
     x = inp["latents"].repeat(2, 1, 1, 1, 1)
     ehs = inp["audio_embeddings"].reshape(-1, 5, 768)
-    gen_s = time.time() - t0
-    with torch.no_grad():
+
+    def fwd():
         t0 = time.time()
         OU.unet3d_forward(sd3, ocfg, x, 519, ehs, inp["kps_features"], rb, 0.95, 3.0)
-        unet_s = time.time() - t0
+        return time.time() - t0
+    with torch.no_grad():
+        warm_s = fwd()
+        timed = [fwd(), fwd()]
+        unet_s = sum(timed) / len(timed)
+        all_cores = None
+        if phys != threads and (time.time() - t_all) + 2.5 * unet_s < 2 * seconds_budget:
+            torch.set_num_threads(phys)
+            fwd()                                   # a new thread team: warm it
+            all_cores = dict(threads=phys, unet_forward_s=fwd())
+            torch.set_num_threads(threads)
+        elif phys != threads:
+            all_cores = dict(threads=phys, unet_forward_s=None, note="skipped: outside the time budget of the CPU leg")
         del sd3
         vcfg = synth.VaeConfig()
         sdv = synth.vae_decoder_state_dict(vcfg)
         z = inp["latents"][0, :, :1].permute(1, 0, 2, 3).contiguous()
+        OV.vae_decode(sdv, oracle.VaeConfig(), z)       # warm
         t0 = time.time()
         OV.vae_decode(sdv, oracle.VaeConfig(), z)
         vae_s = time.time() - t0
     clip_s = unet_s * (16 / f) * 25 + vae_s * 16
-    return dict(value=16.0 / clip_s, unit="frames/s", cores=threads, host_cpus=os.cpu_count(), kind="port",
-                sample=(f"oracle fp32: 1 CFG UNet3D forward {size}x{size} f={f} ({unet_s:.1f} s) + 1 frame VAE decode "
-                        f"({vae_s:.1f} s) on {torch.get_num_threads()} threads; extrapolated x(16/{f}) frames x25 "
-                        f"steps + x16 frames = {clip_s:.0f} s per 16-frame clip"),
-                unet_forward_s=unet_s, vae_frame_s=vae_s,
+    # the same sample per core-second next to the dev-container figure of the reference's own modules (SURVEY.md E6:
+    # 78.1 s for the f = 16 CFG forward on 8 cores = 39.1 core-seconds per frame of the window)
+    core_s_per_frame = unet_s * threads / f
+    return dict(value=16.0 / clip_s, unit="frames/s", cores=threads, physical_cores=phys, host_cpus=os.cpu_count(),
+                kind="port",
+                sample=(f"oracle fp32: CFG UNet3D forward {size}x{size} f={f}, 1 untimed warm-up ({warm_s:.1f} s) + 2 timed "
+                        f"({timed[0]:.1f} s, {timed[1]:.1f} s; mean used) + 1 frame VAE decode, warmed ({vae_s:.1f} s) on "
+                        f"{threads} threads; extrapolated x(16/{f}) frames x25 steps + x16 frames = {clip_s:.0f} s per "
+                        "16-frame clip"),
+                unet_forward_s=unet_s, unet_forward_timed_s=timed, unet_forward_warmup_s=warm_s, vae_frame_s=vae_s,
+                thread_probe_s={str(k): v for k, v in probe.items()}, all_cores=all_cores,
+                omp=dict(OMP_PROC_BIND=os.environ.get("OMP_PROC_BIND"), OMP_PLACES=os.environ.get("OMP_PLACES")),
+                unet_core_seconds_per_frame=core_s_per_frame, cpu_leg_s=time.time() - t_all,
                 reference_modules_dev_container=dict(
-                    value=16.0 / (25 * 78.1 + 16 * 5.5), cores=8, unet_forward_s=78.1,
+                    value=16.0 / (25 * 78.1 + 16 * 5.5), cores=8, unet_forward_s=78.1, unet_core_seconds_per_frame=78.1 * 8 / 16,
                     note="SURVEY.md E6: the reference's own modules (fp32, f=16 CFG forward) on the 8 cores of the dev "
                          "container, measured once during the survey; not re-measured on the GPU box"))
+
+
+def kernel_rate(v):
+    """(achieved, peak, unit, bound) of one kernel's launches: algorithmic FLOP/s against the dense bf16 MFMA peak for the
+    MFMA kernels (flops > 0), algorithmic bytes/s against HBM3E otherwise."""
+    if v["flops"] > 0:
+        return v["flops"] / v["seconds"] / 1e12, PEAK_BF16_TFLOPS, "TFLOP/s", "mfma"
+    return v["bytes"] / v["seconds"] / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+
+
+def rank_kernels(launches, top=12):
+    """launches: dicts (symbol, seconds, weight, flops, bytes) - one per profiled launch of the instrumented leg, `weight` =
+    how many times the launch runs per clip.  Returns (ranking, per-symbol totals, clip seconds per symbol, clip total):
+    `ranking` = the `top` kernels by clip-weighted time over ALL kernels, MFMA or not (the line named an 8 %
+    GEMM instantiation while a 12 % attention kernel existed); ranking[0] is the dominant kernel of the roofline."""
+    allk, clip_s = {}, {}
+    for ln in launches:
+        d = allk.setdefault(ln["symbol"], dict(launches=0, seconds=0.0, flops=0.0, bytes=0.0))
+        d["launches"] += 1
+        d["seconds"] += ln["seconds"]
+        d["flops"] += ln["flops"]
+        d["bytes"] += ln["bytes"]
+        clip_s[ln["symbol"]] = clip_s.get(ln["symbol"], 0.0) + ln["weight"] * ln["seconds"]
+    clip_total = sum(clip_s.values())
+    ranking = []
+    for sym, sec in sorted(clip_s.items(), key=lambda kv: -kv[1])[:top]:
+        a, p, u, b = kernel_rate(allk[sym])
+        ranking.append({"kernel": sym, "share_of_clip_kernel_time": sec / clip_total, "bound": b, "achieved": a, "unit": u,
+                        "frac": a / p, "launches": allk[sym]["launches"],
+                        "avg_launch_us": 1e6 * allk[sym]["seconds"] / allk[sym]["launches"]})
+    return ranking, allk, clip_s, clip_total
 
 
 def main():
@@ -206,6 +295,9 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=25)
     ap.add_argument("--frames", type=int, default=0, help="override the clip length")
+    ap.add_argument("--context-frames", type=int, default=16,
+                    help="window length (BASELINE configs use 16; the reference's own default is 24: inference.py:67)")
+    ap.add_argument("--context-overlap", type=int, default=4)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N>1: strong = the F=124 clip of BASELINE configs[3] for every N; weak = F = 12*N+4")
     ap.add_argument("--no-same-clip-1gpu", action="store_true",
@@ -255,7 +347,7 @@ def main():
     from v_express_amd.context import uniform
 
     cfg, vcfg = synth.UNetConfig(), synth.VaeConfig()
-    ctx, ovl = 16, 4
+    ctx, ovl = args.context_frames, args.context_overlap
     if args.frames:
         F = args.frames
     elif world == 1:
@@ -337,7 +429,7 @@ def main():
     assert video.shape == (1, 3, F, args.size, args.size) and torch.isfinite(video).all()
     fps = F * args.steps / elapsed
     scale = (args.size / 512.0) ** 2
-    fpf = flop_per_frame(F, len(windows), args.ddim_steps, scale)
+    fpf = flop_per_frame(F, len(windows), args.ddim_steps, scale, ctx)
     from v_express_amd.distributed import choose_frame_shards, choose_mixed_shards
     fshards = pipe.frame_shards or choose_frame_shards(len(windows), world, ctx, (args.size // 64) ** 2)
     mshards = 1
@@ -358,9 +450,12 @@ def main():
                                    (f", {2 * len(windows) // world} whole units per GPU + the {2 * len(windows) % world} "
                                     f"left-over units frame-sharded {mshards} ways" if mshards > 1 else ""))},
         "prologue_ms": 1e3 * prologue_s, "model_build_s": t_build, "lib_sha256": _lib_sha(),
+        # which implementation each block of each UNet level took in this run (ops.BLOCK_PATHS: one-launch kernels vs the
+        # multi-launch forms, GroupNorm folds) - a geometry that falls off a fused path shows here and as a log warning
+        "block_paths": ops.block_paths(),
     }
     if args.fp8:
-        # VERDICT r03 item 7, closed in DESIGN 11.4: the e4m3 projections are a parity-complete OPTION, not a speed-up.
+        # VERDICT r03 item 7, closed in LABNOTES 11.4: the e4m3 projections are a parity-complete OPTION, not a speed-up.
         result["fp8_note"] = ("fp8 (e4m3) q/k/v/out projections: parity-complete (tests/test_gpu_kernels.py, "
                               "test_gpu_models.py), not a speed-up - these are K = 320..1280 launches bound by HBM and "
                               "launch latency, fp8 halves one operand's bytes and adds a quantisation pass; measured "
@@ -412,10 +507,14 @@ def main():
         with (prof if prof is not None else contextlib.nullcontext()), \
                 (opprof if opprof is not None else contextlib.nullcontext()):
             lat = inp["latents"].clone()
+            # the instrumented leg runs 1 of the clip's DDIM steps and decodes n_dec of its F frames: every launch carries
+            # the number of times it runs per clip (ops.PROFILE_WEIGHT), the choice of the dominant kernel is over clip time
+            ops.PROFILE_WEIGHT[0] = float(args.ddim_steps)
             pipe.denoise(lat, kps_tokens, audio, timesteps[:1], windows, 3.5)
-            n_unet_records = len(prof.records) if prof is not None else 0
+            ops.PROFILE_WEIGHT[0] = F / float(n_dec)
             if rank == 0:
                 pipe.vae.decode_video(lat[:, :, :n_dec].contiguous(), chunk=4)
+            ops.PROFILE_WEIGHT[0] = 1.0
         torch.cuda.synchronize()
     if rank == 0 and not args.no_roofline:
         summ = prof.summary()
@@ -427,34 +526,41 @@ def main():
                               f"{fl / sec / 1e12:7.1f} TF/s  {kern}\n")
         tot_s = sum(v["seconds"] for v in summ.values())
         tot_f = sum(v["flops"] for v in summ.values())
-        # dominant kernel = the ONE instantiation with the most time over a whole clip (pairs with one row of a rocprofv3
-        # trace): the instrumented leg ran 1 of the clip's DDIM steps and decoded n_dec of its F frames - weight accordingly
-        clip_s = {}
-        for i, rec in enumerate(prof.records):
-            wgt = float(args.ddim_steps) if i < n_unet_records else F / float(n_dec)
-            clip_s[rec[5]] = clip_s.get(rec[5], 0.0) + wgt * rec[0].elapsed_time(rec[1]) * 1e-3
-        dom_sym = max(clip_s.items(), key=lambda kv: kv[1])[0]
-        dom = (dom_sym, syms[dom_sym])
-        clip_total = sum(clip_s.values())
-        ach = dom[1]["flops"] / dom[1]["seconds"] / 1e12
+        # ---- every profiled launch, GEMM or not, keyed by the kernel instantiation as rocprofv3 prints it (MFMA kernels) or
+        # by the wrapper name (HBM-bound kernels); clip-weighted HIP-event time decides which ONE is the dominant kernel
+        osyms = opprof.by_symbol()
+        launches = [dict(symbol=r[5], seconds=r[0].elapsed_time(r[1]) * 1e-3, weight=r[6], flops=r[2],
+                         bytes=prof.bytes_of.get(id(r[0]), 0.0)) for r in prof.records]
+        launches += [dict(symbol=r[5], seconds=r[2].elapsed_time(r[3]) * 1e-3, weight=r[6], flops=r[4], bytes=r[1])
+                     for r in opprof.records]
+        ranking, allk, clip_s, clip_total = rank_kernels(launches)
+        dom_sym = ranking[0]["kernel"]
+        dom = (dom_sym, allk[dom_sym])
+        ach, peak, unit, bound = kernel_rate(dom[1])
         traffic, traffic_src = _pmc_traffic(dom[0])
         rp = _rocprof_launch_avg(dom[0])
         if rp is not None:
             # this run's algorithmic work per launch of the instantiation / the profiler's duration of the same launches
-            rp["achieved"] = dom[1]["flops"] / dom[1]["launches"] / (rp["avg_launch_us"] * 1e-6) / 1e12
-            rp["frac"] = rp["achieved"] / PEAK_BF16_TFLOPS
+            work = dom[1]["flops"] / 1e12 if bound == "mfma" else dom[1]["bytes"] / 1e9
+            rp["achieved"] = work / dom[1]["launches"] / (rp["avg_launch_us"] * 1e-6)
+            rp["frac"] = rp["achieved"] / peak
             rp["note"] = ("committed rocprofv3 --kernel-trace --stats summary of this command with this library build "
                           "(another box); durations without the HIP-event overhead")
-        # the family the instantiation belongs to (all instantiations of the same kernel template and epilogue kind)
-        fam_key = dom[0].split(",")[0]                         # e.g. "gemm_ring_kernel<0"
-        fam = [v for k, v in syms.items() if k.startswith(fam_key + ",")]
+        # the family the instantiation belongs to (all instantiations of the same kernel template; GEMM: and epilogue kind)
+        fam_key = dom[0].split(",")[0] if dom[0].startswith("gemm") else dom[0].split("<")[0]
+        fam = [v for k, v in allk.items() if k == dom[0] or k.startswith(fam_key + ",") or k.startswith(fam_key + "<")]
         fam_fl, fam_s, fam_n = sum(v["flops"] for v in fam), sum(v["seconds"] for v in fam), sum(v["launches"] for v in fam)
+        # the dominant GEMM instantiation (what `roofline.kernel` was before round 5, kept for continuity)
+        gsym = max((k for k in clip_s if k in syms), key=lambda k: clip_s[k])
+        gv = syms[gsym]
         # HBM-bound kernels: achieved GB/s = algorithmic bytes / HIP-event time against 8 TB/s
         hbm = {}
         for name, v in opprof.summary().items():
             hbm[name] = {"launches": v["launches"], "avg_us": 1e6 * v["seconds"] / v["launches"],
                          "algorithmic_mb_per_launch": v["bytes"] / v["launches"] / 1e6,
                          "gbs": v["bytes"] / v["seconds"] / 1e9, "frac": v["bytes"] / v["seconds"] / 1e9 / HBM_PEAK_GBS}
+            if v["flops"] > 0:
+                hbm[name]["tflops"] = v["flops"] / v["seconds"] / 1e12
         short = [(shape, t) for shape, t in prof.by_shape().items() if shape[2] <= 640 and shape[0] >= 16384]
         if short:
             sb = sum(prof.shape_bytes.get(shape, 0.0) for shape, _ in short)
@@ -463,23 +569,41 @@ def main():
             hbm["gemm K<=640 (M>=16384)"] = {"launches": sl, "avg_us": 1e6 * ss / sl, "algorithmic_mb_per_launch": sb / sl / 1e6,
                                             "gbs": sb / ss / 1e9, "frac": sb / ss / 1e9 / HBM_PEAK_GBS,
                                             "tflops": sum(t[2] for _, t in short) / ss / 1e12}
+        per_kernel = {k: {"launches": v["launches"], "avg_us": 1e6 * v["seconds"] / v["launches"],
+                          "tflops": v["flops"] / v["seconds"] / 1e12,
+                          # fp8 launches are priced against the dense fp8 MFMA peak (K incl. the zero padding)
+                          "frac_of_peak": v["flops"] / v["seconds"] / 1e12 /
+                          (PEAK_FP8_TFLOPS if "fp8" in k else PEAK_BF16_TFLOPS)} for k, v in summ.items()}
+        for k, v in osyms.items():            # the non-GEMM MFMA kernels: attention, the one-launch blocks
+            if v["flops"] > 0:
+                per_kernel[k] = {"launches": v["launches"], "avg_us": 1e6 * v["seconds"] / v["launches"],
+                                 "tflops": v["flops"] / v["seconds"] / 1e12,
+                                 "frac_of_peak": v["flops"] / v["seconds"] / 1e12 / PEAK_BF16_TFLOPS, "wrapper": v["name"]}
+        mf = [v for v in allk.values() if v["flops"] > 0]
         result["roofline"] = {
-            "bound": "mfma", "kernel": dom[0], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_BF16_TFLOPS, "frac_source": "HIP events of this run (launch stream)", "rocprof": rp,
+            "bound": bound, "kernel": dom[0], "achieved": ach, "peak": peak, "unit": unit,
+            "frac": ach / peak, "frac_source": "HIP events of this run (launch stream)", "rocprof": rp,
             "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_flop_per_launch": dom[1]["flops"] / max(dom[1]["launches"], 1),
             "algorithmic_bytes_per_launch": dom[1].get("bytes", 0.0) / max(dom[1]["launches"], 1),
             "avg_launch_us": 1e6 * dom[1]["seconds"] / dom[1]["launches"], "launches": dom[1]["launches"],
-            "share_of_clip_gemm_time": clip_s[dom_sym] / clip_total,
-            "family": {"kernels": fam_key + ", ...>", "launches": fam_n, "avg_launch_us": 1e6 * fam_s / fam_n,
-                       "achieved": fam_fl / fam_s / 1e12, "frac": fam_fl / fam_s / 1e12 / PEAK_BF16_TFLOPS},
+            "share_of_clip_kernel_time": clip_s[dom_sym] / clip_total,
+            "selection": "most clip-weighted HIP-event time over ALL profiled kernels (vx_gemm, attention, fused blocks, "
+                         "HBM-bound kernels); see `ranking`",
+            "ranking": ranking,
+            "family": {"kernels": fam_key + ("<...>" if "<" not in fam_key else ", ...>"), "launches": fam_n,
+                       "avg_launch_us": 1e6 * fam_s / fam_n, "achieved": (fam_fl / fam_s / 1e12) if fam_fl else None,
+                       "frac": (fam_fl / fam_s / 1e12 / PEAK_BF16_TFLOPS) if fam_fl else None},
+            "dominant_gemm": {"kernel": gsym, "achieved": gv["flops"] / gv["seconds"] / 1e12,
+                              "frac": gv["flops"] / gv["seconds"] / 1e12 / PEAK_BF16_TFLOPS,
+                              "avg_launch_us": 1e6 * gv["seconds"] / gv["launches"], "launches": gv["launches"],
+                              "share_of_clip_kernel_time": clip_s[gsym] / clip_total},
             "all_gemm_tflops": tot_f / tot_s / 1e12,
-            "per_kernel": {k: {"launches": v["launches"], "avg_us": 1e6 * v["seconds"] / v["launches"],
-                               "tflops": v["flops"] / v["seconds"] / 1e12,
-                               # fp8 launches are priced against the dense fp8 MFMA peak (K incl. the zero padding)
-                               "frac_of_peak": v["flops"] / v["seconds"] / 1e12 /
-                               (PEAK_FP8_TFLOPS if "fp8" in k else PEAK_BF16_TFLOPS)} for k, v in summ.items()},
+            "all_mfma_tflops": sum(v["flops"] for v in mf) / sum(v["seconds"] for v in mf) / 1e12,
+            "per_kernel": per_kernel,
             "per_instantiation": {k: {"launches": v["launches"], "avg_us": 1e6 * v["seconds"] / v["launches"],
-                                      "tflops": v["flops"] / v["seconds"] / 1e12} for k, v in syms.items()},
+                                      "tflops": v["flops"] / v["seconds"] / 1e12} for k, v in allk.items()
+                                  if v["flops"] > 0},
             "hbm_kernels": {"peak_gbs": HBM_PEAK_GBS, "note": "algorithmic bytes / HIP-event time of this run; "
                             "~6300 GB/s is what a streaming copy reaches on this part", "kernels": hbm},
             "whole_path": {"tflop_per_frame": fpf, "achieved": fps * fpf / world, "frac": fps * fpf / world / PEAK_BF16_TFLOPS,

@@ -19,10 +19,14 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 11
+#define VX_ABI_VERSION 12
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
+/* Identity of this BINARY: "<hash of the kernel sources it was compiled from>|<extra -D flags of the build>" as stamped by
+ * csrc/Makefile ("unstamped|" for a library built any other way).  The Python binding compares the hash with the sources
+ * on disk (v_express_amd.lib.source_id): measurements under profiles/ are keyed by it. */
+const char* vx_build_id(void);
 /* device properties snapshot: out[0]=CU count, out[1]=LDS bytes per block, out[2]=wavefront size, out[3]=clock kHz */
 int vx_device_info(int device, int* out4);
 
@@ -134,7 +138,11 @@ typedef struct {
    * kernel holds half a row).  row_stats_parts == 2 (requires n == 640): row_stats_out is [m][2][2] = (sum, sum of squares)
    * of the stored bf16 values of columns [0, 320) and [320, 640) of every row - each half comes out of one tile's epilogue,
    * no pass re-reads the tensor (launches that do not run on the persistent kernel fill the same format with
-   * vx_row_stats_parts).  ln_stats_parts == 2 (requires k == 640 and a launch on the persistent kernel - ask
+   * vx_row_stats_parts).  The two producers sum in different fp32 orders (epilogue: 20 columns per lane, then the 4 wave
+   * columns; vx_row_stats_parts: 32 lanes, stride 8), so the low bits of a row's sums depend on WHICH one ran: they are a
+   * function of per-item facts (batch-invariant) only when the caller pins the kernel choice with ring_hint != 0, as the
+   * Python layer does under ops.frame_rows(items=...); with ring_hint == 0 the choice follows the launch size.
+   * ln_stats_parts == 2 (requires k == 640 and a launch on the persistent kernel - ask
    * vx_gemm_config_name; else VX_ERR_UNSUPPORTED: convert with vx_row_stats_finalize): ln_stats holds that format; the
    * epilogue adds the two halves and takes mean = s / k, rstd = 1 / sqrt(max(0, q / k - mean^2) + ln_eps) itself (one-pass
    * variance, see row_stats_out).  0 / 1 = the (mean, rstd) format. */
@@ -162,6 +170,10 @@ const char* vx_gemm_config_name(const vx_gemm_params* p);
  * namespace ("gemm_ring_kernel<0, true, false, false, false, true>"): lets bench.py pair its HIP-event figures with the
  * rows of a committed kernel trace one to one.  "" before the first launch. */
 const char* vx_gemm_last_kernel(void);
+/* the same for EVERY MFMA entry point of the library (vx_gemm, vx_attention, vx_attention_bounded, vx_temporal_attention,
+ * vx_ff_fused, vx_tblock_fused): the instantiation the last such call of this thread launched
+ * ("attn3_kernel<2, false, true, false>", "ff_fused_kernel<2>", "tblock_kernel", ...). */
+const char* vx_last_kernel(void);
 
 /* ---- Fused GEGLU feed-forward of the 64x64 level (round 4) -------------------------------------------------------
  * out = residual + (value * gelu(gate)) W2^T + bias2,  [value | gate] = LN(x) W1^T + b1   in ONE launch: the [m, 4C]

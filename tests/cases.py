@@ -32,6 +32,9 @@ FULLSIZE_CASE = (16, 16, 4, 25)
 FULLSIZE_FRAMES = (0, 15)                             # decoded 512x512 frames kept in the golden file
 # the sliding-window path at the benchmarked geometry (make_golden.py fullsize_F28): two overlapping 16-frame windows
 FULLSIZE_F28_CASE = (28, 16, 4, 2)
+# the reference's DEFAULT window (inference.py:67-68: context_frames 24, context_overlap 4) at the benchmarked geometry
+# (make_golden.py fullsize_ctx24): F = 44 = windows [0..23] and [20..43] sharing four frames, 2 DDIM steps
+FULLSIZE_CTX24_CASE = (44, 24, 4, 2)
 # BASELINE configs[4]'s geometry (768x768 = 96x96 latents) through the reference (make_golden.py fullsize_768)
 FULLSIZE_768_CASE = (4, 4, 2, 2)
 

@@ -141,7 +141,7 @@ def fullsize(out):
     print("fullsize", {k: (tuple(v.shape) if hasattr(v, "shape") else v) for k, v in g.items()})
 
 
-def fullsize_F28(out):
+def fullsize_F28(out, case=None, fname="fullsize_F28_512.pt"):
     """The sliding-window / merged-call path at the BENCHMARKED geometry (BASELINE.json configs[2] shape, shortened):
     the reference's own `VExpressPipeline.__call__` (pipelines/v_express_pipeline.py:526-589) at SD-1.5 widths, 64x64
     latents (512x512), F = 28 with context 16 / overlap 4 -> two windows [0..15], [12..27] sharing four frames, CFG 3.5,
@@ -152,7 +152,7 @@ def fullsize_F28(out):
     cfg = cases.unet_cfg(cases.FULL)
     unet, refnet = H.build_reference_unets(cfg)
     vae = H.build_reference_vae(synth.VaeConfig(**cases.SMALL_VAE))     # only its scale factor (8) is used: no decode
-    F, cf, co, steps = cases.FULLSIZE_F28_CASE
+    F, cf, co, steps = case or cases.FULLSIZE_F28_CASE
     inp = synth.synthetic_inputs(cfg, F, 64, 64)
     orig = unet.forward
     preds = []
@@ -175,8 +175,16 @@ def fullsize_F28(out):
              pred_shapes=[tuple(p.shape) for p in preds[:per_step]],
              latents_step0=trace[0].clone(), latents=trace[-1].clone(), loop_seconds=time.time() - t0,
              threads=torch.get_num_threads())
-    torch.save(g, os.path.join(out, "fullsize_F28_512.pt"))
-    print("fullsize_F28", {k: (tuple(v.shape) if hasattr(v, "shape") else v) for k, v in g.items()})
+    torch.save(g, os.path.join(out, fname))
+    print(fname, {k: (tuple(v.shape) if hasattr(v, "shape") else v) for k, v in g.items()})
+
+
+def fullsize_ctx24(out):
+    """The reference's DEFAULT window geometry (inference.py:67-68: --context_frames 24 --context_overlap 4; the
+    positional table of the motion modules holds 32 entries, inference_v2.yaml:21) at SD-1.5 widths and 64x64 latents:
+    F = 44 -> windows [0..23] and [20..43] sharing four frames, CFG 3.5, 2 DDIM steps of the reference's own
+    `VExpressPipeline.__call__` (4 CFG forwards of 24 frames, ~10 min on 8 cores).  Same contents as fullsize_F28."""
+    return fullsize_F28(out, cases.FULLSIZE_CTX24_CASE, "fullsize_ctx24_F44_512.pt")
 
 
 def fullsize_768(out):
@@ -221,6 +229,8 @@ def main():
         return fullsize(out)
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize_F28":  # ~6 min; not part of the default regeneration
         return fullsize_F28(out)
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize_ctx24":  # ~10 min; not part of the default regeneration
+        return fullsize_ctx24(out)
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize_768":  # ~6 min; not part of the default regeneration
         return fullsize_768(out)
     prologue(out)

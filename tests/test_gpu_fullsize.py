@@ -195,8 +195,8 @@ GOLD_F28 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f
 F28_BOUNDS = (1.5e-2, 3e-2)        # relative L2 of the latents after step 1 / step 2 (two LARGE steps: t = 999, 499)
 
 
-def _run_f28(pipe, inp, units_per_call, spy=None):
-    F, cf, co, steps = cases.FULLSIZE_F28_CASE
+def _run_f28(pipe, inp, units_per_call, spy=None, case=None):
+    F, cf, co, steps = case or cases.FULLSIZE_F28_CASE
     unet = pipe.denoising_unet
     saved_upc, saved_fwd = pipe.units_per_call, unet.forward_tokens
     trace = {}
@@ -257,6 +257,45 @@ def test_fullsize_two_overlapping_windows_one_merged_call_vs_reference_golden(fu
               f" (max |diff| {(sep - merged[2 * wi:2 * wi + 2]).abs().max().item():.3g})")
         assert same, f"window {wi}: the merged b = 4 call is not bit-identical to the b = 2 call"
     assert torch.equal(lat2, lat4) and torch.equal(trace2[0], trace4[0])
+
+
+GOLD_CTX24 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_ctx24_F44_512.pt")
+
+
+def test_fullsize_reference_default_window_24_overlap_4_vs_reference_golden(full):
+    """The reference's DEFAULT window geometry (inference.py:67-68: --context_frames 24 --context_overlap 4; the motion
+    modules' positional table holds 32 entries, inference_v2.yaml:21) at SD-1.5 widths and 64x64 latents: F = 44 = windows
+    [0..23] and [20..43] sharing four frames, CFG 3.5, 2 DDIM steps, against the reference's own
+    `VExpressPipeline.__call__` (tests/golden/fullsize_ctx24_F44_512.pt, make_golden.py fullsize_ctx24).  Every model-level
+    test before round 5 used windows of 4, 8 or 16 frames; f = 24 exercises the temporal attention
+    past 16 frames (modules/motion_module.py:236-259,351-388) in every motion module of the UNet.  Also prints which
+    implementation the temporal blocks took at this window length (ops.block_paths)."""
+    if not os.path.exists(GOLD_CTX24):
+        pytest.fail("tests/golden/fullsize_ctx24_F44_512.pt is missing (python tests/make_golden.py fullsize_ctx24)")
+    from v_express_amd import ops, synth
+    pipe, cfg = full["pipe"], full["cfg"]
+    g = torch.load(GOLD_CTX24, weights_only=False)
+    F, cf, co, steps = cases.FULLSIZE_CTX24_CASE
+    assert [list(w) for w in g["windows"]] == [list(range(0, 24)), list(range(20, 44))]
+    inp = synth.synthetic_inputs(cfg, F, 64, 64)
+    calls = []
+    lat, trace = _run_f28(pipe, inp, 2, spy=calls, case=cases.FULLSIZE_CTX24_CASE)      # one b = 2 call per window
+    assert [b for b, _ in calls] == [2] * (2 * steps), [b for b, _ in calls]
+    want = g["pred_step0_f16"].float()
+    assert tuple(want.shape) == (4, 4, cf, 64, 64)
+    for wi in range(2):                      # rows: (window wi: uncond, cond) - the reference's order
+        first = calls[wi][1].view(2, cf, 64 * 64, -1)[..., :4].permute(0, 3, 1, 2).reshape(2, 4, cf, 64, 64)
+        r, c = rel_l2(first, want[2 * wi:2 * wi + 2]), cosine(first, want[2 * wi:2 * wi + 2])
+        print(f"[ctx 24 / overlap 4] window {wi} first prediction: relL2={r:.4g} cosine={c:.6f}")
+        assert r <= 3e-2 and c >= 0.999, (wi, r, c)
+    for i, key in ((0, "latents_step0"), (1, "latents")):
+        r, rn = rel_l2(trace[i], g[key]), rel_l2(inp["latents"], g[key])
+        print(f"[ctx 24 / overlap 4] latents after step {i + 1}: relL2={r:.4g} (bound {F28_BOUNDS[i]:.1e}; untouched noise {rn:.3g})")
+        assert r <= F28_BOUNDS[i], (i, r)
+        assert rn > 3 * F28_BOUNDS[i], (i, rn)                                    # the bound rejects a loop that does nothing
+    paths = {k: v for k, v in ops.block_paths().items() if k.startswith("temporal_attention") and " f=24 " in k}
+    print("[ctx 24 / overlap 4] temporal blocks:", paths)
+    assert paths, "no temporal-attention path was recorded for f = 24"
 
 
 GOLD_768 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_768_F4.pt")

@@ -20,7 +20,12 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for n in names:
         assert hasattr(so, n), n
-    assert lib.lib.vx_abi_version() == 11
+    assert lib.lib.vx_abi_version() == 12
+    # the binary says which sources it was compiled from (stamped by csrc/Makefile) and lib.py has compared that with the
+    # sources on disk at import: a stale .so does not get this far
+    src, _, defs = lib.lib.vx_build_id().decode().partition("|")
+    assert src == lib.source_id() and defs == "" and lib.LIB_SHA256 == src
+    assert lib.lib.vx_last_kernel() == b"" or lib.lib.vx_last_kernel().startswith((b"gemm", b"attn", b"ff_", b"tblock", b"temporal"))
     assert ctypes.sizeof(lib.GemmParams) % 8 == 0
     # argument validation happens before any launch, so it works without a GPU and never aborts the process
     p = lib.GemmParams()
@@ -282,6 +287,34 @@ def test_bench_algorithmic_flops_match_the_survey_figures():
     assert abs(bench.flop_per_frame(16, 1, 25, 2.25) - 183.8) < 0.1
 
 
+def test_bench_picks_the_dominant_kernel_over_all_kernels_by_clip_weighted_time():
+    """`roofline.kernel` was chosen among vx_gemm launches only, so the line named an 8 % GEMM instantiation
+    while the 12 % attention kernel had no roofline anywhere.  bench.rank_kernels sees every profiled launch - GEMM,
+    attention, the one-launch blocks, HBM-bound kernels - and weights each by how often it runs per clip."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("vx_bench3", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    gemm, attn, gn, vae = "gemm_kernel<128, 160, 2, 2, 2, 0, true, false, false, false>", \
+        "attn3_kernel<2, false, true, false>", "groupnorm_apply", "gemm_kernel<256, 256, 4, 2, 2, 0, true, false, false, false>"
+    launches = [dict(symbol=gemm, seconds=60e-6, weight=25.0, flops=44.2e9, bytes=60e6) for _ in range(77)]       # 115 ms per clip
+    launches += [dict(symbol=attn, seconds=600e-6, weight=25.0, flops=0.515e12, bytes=200e6) for _ in range(10)]  # 150 ms per clip
+    launches += [dict(symbol=gn, seconds=23e-6, weight=25.0, flops=0.0, bytes=92e6) for _ in range(77)]           # 44 ms per clip
+    launches += [dict(symbol=vae, seconds=9000e-6, weight=4.0, flops=9.0e12, bytes=1e9)]                           # 36 ms per clip,
+    #                                                                       the most raw time of the instrumented leg
+    ranking, allk, clip_s, total = bench.rank_kernels(launches)
+    assert [r["kernel"] for r in ranking] == [attn, gemm, gn, vae]
+    top = ranking[0]
+    assert top["bound"] == "mfma" and abs(top["achieved"] - 0.515e12 / 600e-6 / 1e12) < 1e-6
+    assert abs(top["frac"] - top["achieved"] / bench.PEAK_BF16_TFLOPS) < 1e-12 and top["launches"] == 10
+    assert abs(top["share_of_clip_kernel_time"] - 0.150 / total) < 1e-9 and abs(sum(clip_s.values()) - total) < 1e-12
+    hb = ranking[2]
+    assert hb["bound"] == "hbm" and hb["unit"] == "GB/s" and abs(hb["achieved"] - 92e6 / 23e-6 / 1e9) < 1e-6
+    assert abs(hb["frac"] - hb["achieved"] / bench.HBM_PEAK_GBS) < 1e-12
+    assert allk[gemm]["launches"] == 77 and abs(allk[gemm]["flops"] - 77 * 44.2e9) < 1.0
+
+
 def test_bench_quotes_committed_profiles_only_for_the_loaded_kernel_build(tmp_path, monkeypatch):
     """bench.py's `roofline.traffic` / `roofline.rocprof` come from files under profiles/ - but only from files that carry
     the identity of the kernel sources the loaded library was built from (`lib_sha256`); anything else is refused with a
@@ -318,6 +351,41 @@ def test_bench_quotes_committed_profiles_only_for_the_loaded_kernel_build(tmp_pa
     import sys
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "lib_id.py")], capture_output=True, text=True)
     assert out.stdout.strip() == lib.LIB_SHA256          # the scripts stamp profiles with the value bench.py checks
+    # non-template kernels are printed without "void" by rocprofv3; the fused blocks must be found as well
+    (prof / "r99_trace_summary.txt").write_text(f"# lib_sha256={lib.LIB_SHA256} command=x\n"
+                                                "    93.97 ms   3.6% n=   510 avg=    184.3 us  tblock_kernel(vx_tblock_params, float)\n"
+                                                "   312.23 ms  12.0% n=   520 avg=    600.4 us  void attn3_kernel<2, false, true, false>(Attn3Params)\n")
+    assert bench._rocprof_launch_avg("tblock_kernel")["avg_launch_us"] == 184.3
+    assert bench._rocprof_launch_avg("attn3_kernel<2, false, true, false>")["launches"] == 520
+
+
+def test_a_stale_or_variant_library_is_never_paired_with_committed_profiles(monkeypatch):
+    """the identity bench.py keys profiles by is the identity of the loaded BINARY (vx_build_id), not of the
+    sources on disk: an unstamped variant build, a build with extra -D flags and a stale build all get an identity that
+    no committed file carries; a stale build is an ImportError unless VX_ALLOW_STALE_LIB=1."""
+    import types
+    import warnings
+    from v_express_amd import lib
+    real = lib.lib
+
+    def with_id(s):
+        monkeypatch.setattr(lib, "lib", types.SimpleNamespace(vx_build_id=lambda: s.encode()))
+        try:
+            return lib._build_identity()
+        finally:
+            monkeypatch.setattr(lib, "lib", real)
+    sid = lib.source_id()
+    assert with_id(f"{sid}|") == sid
+    assert with_id(f"{sid}|-DVX_GELU_PK") == f"{sid}+-DVX_GELU_PK"
+    assert with_id("unstamped|").startswith("unstamped:")
+    monkeypatch.delenv("VX_ALLOW_STALE_LIB", raising=False)
+    with pytest.raises(ImportError, match="rebuild"):
+        with_id("0123456789abcdef|")
+    monkeypatch.setenv("VX_ALLOW_STALE_LIB", "1")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert with_id("0123456789abcdef|") == "stale:0123456789abcdef"
+    assert w and "rebuild" in str(w[0].message)
 
 
 def test_audio_encoder_directory_loader(tmp_path, monkeypatch):

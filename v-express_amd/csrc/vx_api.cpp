@@ -26,6 +26,18 @@ int vx_check_launch(const char* what) {
 extern "C" const char* vx_last_error_string(void) { return g_err; }
 extern "C" int vx_abi_version(void) { return VX_ABI_VERSION; }
 
+// Identity of THIS binary: the Makefile stamps the hash of the kernel sources it compiled (tools/lib_id.py =
+// v_express_amd.lib.source_id) and the extra -D flags of the build into this translation unit, which depends on every
+// source; a library built any other way (tools/build_*_variants.sh) says "unstamped".  lib.py compares it with the
+// sources on disk, so a stale or variant .so can never be paired with rocprofv3 / PMC files of another build.
+#ifndef VX_BUILD_SRC_ID
+#define VX_BUILD_SRC_ID "unstamped"
+#endif
+#ifndef VX_BUILD_DEFS
+#define VX_BUILD_DEFS ""
+#endif
+extern "C" const char* vx_build_id(void) { return VX_BUILD_SRC_ID "|" VX_BUILD_DEFS; }
+
 extern "C" int vx_device_info(int device, int* out4) {
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);

@@ -16,6 +16,7 @@
 // 16-B row copies and read conflict-free: K as [d/32 slabs][64 keys][64 B] with chunk ^= (-(key>>2))&3, V^T as
 // [dim rows][128 B] with chunk ^= (row>>1)&7.
 #include "vx_common.h"
+#include <stdio.h>
 #include "../../include/vexpress_hip.h"
 
 #include <stdlib.h>
@@ -260,6 +261,9 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid(ceil_div(p.n_q, 64 * QT), p.batch * p.heads);
+  static char sym[64] = "";
+  if (!sym[0]) snprintf(sym, sizeof(sym), "attn_kernel<%d, %d, %d, %s, %d>", KK, DT, QT, PREFETCH ? "true" : "false", MINW);
+  g_vx_last_kernel = sym;
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
   return vx_check_launch("vx_attention");
 }
@@ -630,6 +634,10 @@ int launch_attn2(const AttnParams& p, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid((unsigned)((long)ceil_div(p.n_q, 64 * QT) * p.batch * p.heads));
+  static char sym[64] = "";
+  if (!sym[0])
+    snprintf(sym, sizeof(sym), "attn2_kernel<%d, %d, %d, %s, %s>", KK, DT, QT, ONES ? "true" : "false", BOUND ? "true" : "false");
+  g_vx_last_kernel = sym;
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
   return vx_check_launch("vx_attention");
 }
@@ -777,13 +785,20 @@ int launch_temporal(const TemporalParams& p, hipStream_t stream) {
     wpb_env = e ? atoi(e) : 0;
   }
   const bool wide = wpb_env ? wpb_env == 8 : (p.heads % 8) == 0;
+  static char sym[4][56];
+  auto name = [&](int slot, int ft, int wpb) {
+    if (!sym[slot][0]) snprintf(sym[slot], sizeof(sym[slot]), "temporal_attn_kernel<%d, %d, %d, %d>", KK, DT, ft, wpb);
+    g_vx_last_kernel = sym[slot];
+  };
   if (wide && (p.heads % 8) == 0 && KK * (p.f <= 16 ? 1 : 2) <= 6) {   // LDS: 8 x 16 FT x (32 KK + 8) x 2 B <= 64 KiB
     dim3 grid((unsigned)((waves + 7) / 8));
+    name(p.f <= 16 ? 0 : 1, p.f <= 16 ? 1 : 2, 8);
     if (p.f <= 16) hipLaunchKernelGGL((temporal_attn_kernel<KK, DT, 1, 8>), grid, dim3(512), 0, stream, p);
     else hipLaunchKernelGGL((temporal_attn_kernel<KK, DT, 2, 8>), grid, dim3(512), 0, stream, p);
     return vx_check_launch("vx_temporal_attention");
   }
   dim3 grid((unsigned)((waves + 3) / 4));
+  name(p.f <= 16 ? 2 : 3, p.f <= 16 ? 1 : 2, 4);
   if (p.f <= 16) hipLaunchKernelGGL((temporal_attn_kernel<KK, DT, 1, 4>), grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((temporal_attn_kernel<KK, DT, 2, 4>), grid, dim3(256), 0, stream, p);
   return vx_check_launch("vx_temporal_attention");

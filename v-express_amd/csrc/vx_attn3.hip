@@ -523,6 +523,12 @@ int launch_attn3(const Attn3Params& p, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid((unsigned)((long)ceil_div(p.n_q, 64 * A3_QT) * p.batch * p.heads));
+  static char sym[64] = "";
+  if (!sym[0]) {
+    auto bs = [](bool v) { return v ? "true" : "false"; };
+    snprintf(sym, sizeof(sym), "attn3_kernel<%d, %s, %s, %s>", NBUF, bs(PIPE), bs(UNIT), bs(QK32));
+  }
+  g_vx_last_kernel = sym;
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
   return vx_check_launch("vx_attention");
 }

@@ -16,6 +16,10 @@ typedef uint16_t bf16_t;   // raw bfloat16 bits
 
 extern "C" void vx_set_error(const char* fmt, ...);
 int vx_check_launch(const char* what);
+// name of the kernel instantiation the last launch of this thread's MFMA entry points (vx_gemm, vx_attention*,
+// vx_temporal_attention, vx_ff_fused, vx_tblock_fused) made, spelled as rocprofv3 prints it (vx_last_kernel): set by the
+// launch templates themselves, so it is exact by construction
+extern thread_local const char* g_vx_last_kernel;
 
 #define VX_REQUIRE(cond, ...)                   \
   do {                                          \

@@ -418,6 +418,7 @@ extern "C" int vx_ff_fused(const vx_ff_params* pp, void* stream_) {
     attr_set = true;
   }
   const int tiles = p.m / FF_BM;
+  g_vx_last_kernel = four_waves ? "ff_fused_kernel<4>" : "ff_fused_kernel<2>";
   if (four_waves)
     hipLaunchKernelGGL(ff_fused_kernel<4>, dim3(tiles < cus ? tiles : cus), dim3(256), FF_LDS, (hipStream_t)stream_, p);
   else

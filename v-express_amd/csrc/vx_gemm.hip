@@ -851,6 +851,7 @@ extern "C" int vx_gemm_gn_slabs(const vx_gemm_params* pp) {
 
 thread_local const char* g_vx_last_kernel = "";
 extern "C" const char* vx_gemm_last_kernel(void) { return g_vx_last_kernel; }
+extern "C" const char* vx_last_kernel(void) { return g_vx_last_kernel; }
 
 extern "C" int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk) {
   return splitk > 1 ? (int64_t)splitk * m * n * (int64_t)sizeof(float) : 0;

@@ -19,7 +19,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* shared_ptr) {
   return (uint32_t)(size_t)(__attribute__((address_space(3))) const char*)shared_ptr;
 }
 // Cache-policy experiment for the copies (build with -DVX_GLDS_MOD='" nt"', '" sc1"', '" sc0 sc1"'; the product library
-// is built without, i.e. default policy): the long-K GEMMs are bound by the CU's L1 miss path
+// is built without, i.e. default policy): the long-K GEMMs are bound by the CU's L1 miss path (LABNOTES.md section 7)
 #ifndef VX_GLDS_MOD
 #define VX_GLDS_MOD ""
 #endif
@@ -53,9 +53,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// name of the kernel instantiation the last vx_gemm of this thread launched, as rocprofv3 prints it (vx_gemm_last_kernel):
-// set by the launch templates themselves, so it is exact by construction
-extern thread_local const char* g_vx_last_kernel;
+// (g_vx_last_kernel: vx_common.h)
 
 // FAST addressing eligibility (see gemm_kernel in vx_gemm.hip)
 bool vx_gemm_fast_ok(const vx_gemm_params& p);

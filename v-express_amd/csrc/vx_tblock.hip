@@ -636,6 +636,7 @@ extern "C" int vx_tblock_fused(const vx_tblock_params* pp, void* stream_) {
     attr_set = true;
   }
   const int tiles = p.b * (p.hw / TB_PIX);
+  g_vx_last_kernel = "tblock_kernel";
   hipLaunchKernelGGL(tblock_kernel, dim3(tiles < cus ? tiles : cus), dim3(64 * TB_NW), TB_LDS, (hipStream_t)stream_, p,
                      p.scale * 1.4426950408889634f);
   return vx_check_launch("vx_tblock_fused");

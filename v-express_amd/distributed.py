@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 class CommTimer:
     """Optional timing of every collective of the data path (bench.py --gpus N: the all-gather of a timestep's
-    predictions, the decode's frame gather, the frame-shard all-to-alls): `with CommTimer() as t:` records a pair of
+    predictions, the decode's frame gather, the frame-shard all-to-alls, the broadcast of rank 0's noise draw): `with CommTimer() as t:` records a pair of
     events on the current stream around each call; `t.summary()` -> {kind: dict(calls, ms, bytes)}.  Off (no events, no
     overhead) outside the context."""
     active = None
@@ -263,12 +263,13 @@ class DistContext:
         """In-place broadcast from `src` (rank 0's noise draw becomes every rank's initial latents)."""
         if not self.enabled:
             return t
-        if t.is_cuda and dist.get_backend(self.group) != "nccl":
-            host = t.detach().cpu().contiguous()          # single-GPU control-flow testing over gloo
-            dist.broadcast(host, src=src, group=self.group)
-            t.copy_(host)
-            return t
-        dist.broadcast(t, src=src, group=self.group)
+        with _timed_collective("broadcast", t):           # (timed like every other collective of the data path)
+            if t.is_cuda and dist.get_backend(self.group) != "nccl":
+                host = t.detach().cpu().contiguous()          # single-GPU control-flow testing over gloo
+                dist.broadcast(host, src=src, group=self.group)
+                t.copy_(host)
+            else:
+                dist.broadcast(t, src=src, group=self.group)
         return t
 
     def all_gather_units(self, local: torch.Tensor, max_units: int) -> torch.Tensor:

@@ -105,6 +105,8 @@ def _load():
     lib.vx_gemm_config_name.argtypes = [C.POINTER(GemmParams)]
     lib.vx_gemm_config_name.restype = C.c_char_p
     lib.vx_gemm_last_kernel.restype = C.c_char_p
+    lib.vx_last_kernel.restype = C.c_char_p
+    lib.vx_build_id.restype = C.c_char_p
     lib.vx_gemm_splitk_ws_bytes.argtypes = [i32, i32, i32]
     lib.vx_gemm_splitk_ws_bytes.restype = i64
     lib.vx_groupnorm_ws_floats.restype = i64
@@ -144,9 +146,9 @@ def _load():
     for name in declared_symbols():
         fn = getattr(lib, name)
         if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name",
-                        "vx_gemm_splitk_ws_bytes", "vx_gemm_last_kernel"):
+                        "vx_gemm_splitk_ws_bytes", "vx_gemm_last_kernel", "vx_last_kernel", "vx_build_id"):
             fn.restype = i32
-    if lib.vx_abi_version() != 11:
+    if lib.vx_abi_version() != 12:
         raise ImportError("libvexpress_hip.so ABI version mismatch")
     return lib
 
@@ -163,16 +165,41 @@ def source_id():
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) +
                    glob.glob(os.path.join(CSRC, "*.cpp")) + [os.path.join(CSRC, "Makefile"), HEADER])
-    for path in files:
-        h.update(os.path.basename(path).encode())
-        with open(path, "rb") as f:
-            h.update(f.read())
+    try:
+        for path in files:
+            h.update(os.path.basename(path).encode())
+            with open(path, "rb") as f:
+                h.update(f.read())
+    except OSError:
+        return None                      # a binary-only install: nothing to compare the library with
     return h.hexdigest()[:16]
 
 
+def _build_identity():
+    """Identity of the LOADED binary: `vx_build_id()` = "<source hash the Makefile stamped>|<extra -D flags>".
+    * stamped, no extra flags, hash == the sources on disk: that hash (what committed profiles are keyed by);
+    * stamped with extra -D flags (make EXTRA_DEFS=...): "<hash>+<flags>" - never equal to a plain hash;
+    * unstamped (tools/build_*_variants.sh, VX_LIBRARY A/B builds): "unstamped:<file name>";
+    * stamped with ANOTHER hash than the sources on disk: the .so is stale -> ImportError (VX_ALLOW_STALE_LIB=1: a warning
+      and the identity "stale:<hash>", so that no committed measurement is paired with it)."""
+    src, _, defs = lib.vx_build_id().decode().partition("|")
+    if src == "unstamped":
+        return "unstamped:" + os.path.basename(LIB_PATH)
+    disk = source_id()
+    if disk is not None and disk != src:
+        msg = (f"{LIB_PATH} was built from kernel sources {src}, the sources on disk are {disk}: rebuild it "
+               "(make -C v-express_amd/csrc, or __graft_entry__.build())")
+        if os.environ.get("VX_ALLOW_STALE_LIB") != "1":
+            raise ImportError(msg)
+        import warnings
+        warnings.warn(msg)
+        return "stale:" + src
+    return src + ("+" + defs if defs else "")
+
+
 # identity of the kernel build: measurements committed under profiles/ carry it, and bench.py quotes a committed trace /
-# counter file next to a live number only when it was taken with the SAME kernel sources
-LIB_SHA256 = source_id()
+# counter file next to a live number only when it was taken with the SAME binary (`vx_build_id`, stamped by the Makefile)
+LIB_SHA256 = _build_identity()
 
 
 class VxError(RuntimeError):

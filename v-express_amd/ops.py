@@ -5,6 +5,7 @@ shapes/strides and `torch.cuda.current_stream()` to libvexpress_hip.so.  Activat
 channels-last tokens `[frames, H*W, C]`; weights are pre-laid-out by `weights.py`.
 """
 import ctypes as C
+import logging
 import os
 
 import torch
@@ -19,13 +20,18 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Weight of the launches that follow in a whole clip (bench.py's instrumented leg runs 1 of the clip's DDIM steps and
+# decodes a few of its frames: it sets the factor before each part); stored with every profile record
+PROFILE_WEIGHT = [1.0]
+
+
 class GemmProfile:
     """Optional per-launch HIP-event timing of vx_gemm (bench.py's roofline leg).  Events are recorded on the
     same stream the kernels are launched on (torch's current stream)."""
     active = None
 
     def __init__(self):
-        self.records = []          # (start_event, end_event, flops, tile_key, shape)
+        self.records = []          # (start_event, end_event, flops, tile_key, shape, kernel symbol, clip weight)
         self.bytes_of = {}         # id(start_event) -> algorithmic bytes of that launch (operands read once + output)
         self.shape_bytes = {}      # (m, n, k, tile key) -> algorithmic bytes summed over its launches
 
@@ -39,7 +45,7 @@ class GemmProfile:
     def summary(self):
         torch.cuda.synchronize()
         by = {}
-        for s, e, fl, key, _, _ in self.records:
+        for s, e, fl, key, *_ in self.records:
             d = by.setdefault(key, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += s.elapsed_time(e) * 1e-3
@@ -65,7 +71,7 @@ class GemmProfile:
         """{(m, n, k, kernel): [launches, seconds, flops]} sorted by time (tools / tuning)."""
         torch.cuda.synchronize()
         by = {}
-        for s, e, fl, key, shape, _ in self.records:
+        for s, e, fl, key, shape, *_ in self.records:
             d = by.setdefault(shape + (key,), [0, 0.0, 0.0])
             d[0] += 1
             d[1] += s.elapsed_time(e) * 1e-3
@@ -74,12 +80,14 @@ class GemmProfile:
 
 
 class OpProfile:
-    """Optional per-call HIP-event timing of the HBM-bound (non-GEMM) wrappers with their algorithmic bytes - bench.py's
-    `roofline.hbm_kernels` table (achieved GB/s against the 8 TB/s of HBM3E).  Same stream as the launches."""
+    """Optional per-call HIP-event timing of every non-GEMM wrapper with its algorithmic bytes and - for the MFMA kernels
+    (attention, the fused feed-forward / temporal blocks) - its algorithmic FLOPs and the kernel instantiation it launched
+    (vx_last_kernel): bench.py's `roofline.hbm_kernels` table (achieved GB/s against the 8 TB/s of HBM3E) and,
+    together with GemmProfile, the choice of the dominant kernel over ALL kernels.  Same stream as the launches."""
     active = None
 
     def __init__(self):
-        self.records = []          # (name, algorithmic bytes, start_event, end_event)
+        self.records = []          # (name, algorithmic bytes, start_event, end_event, flops, kernel symbol or name, clip weight)
 
     def __enter__(self):
         OpProfile.active = self
@@ -91,19 +99,34 @@ class OpProfile:
     def summary(self):
         torch.cuda.synchronize()
         by = {}
-        for name, nbytes, s, e in self.records:
-            d = by.setdefault(name, dict(launches=0, seconds=0.0, bytes=0.0))
+        for name, nbytes, s, e, fl, *_ in self.records:
+            d = by.setdefault(name, dict(launches=0, seconds=0.0, bytes=0.0, flops=0.0))
             d["launches"] += 1
             d["seconds"] += s.elapsed_time(e) * 1e-3
+            d["bytes"] += nbytes
+            d["flops"] += fl
+        return by
+
+    def by_symbol(self):
+        """{kernel instantiation as rocprofv3 names it (MFMA kernels) or wrapper name: dict(launches, seconds, flops, bytes,
+        name)} - same shape as GemmProfile.by_symbol()."""
+        torch.cuda.synchronize()
+        by = {}
+        for name, nbytes, s, e, fl, sym, _ in self.records:
+            d = by.setdefault(sym, dict(launches=0, seconds=0.0, flops=0.0, bytes=0.0, name=name))
+            d["launches"] += 1
+            d["seconds"] += s.elapsed_time(e) * 1e-3
+            d["flops"] += fl
             d["bytes"] += nbytes
         return by
 
 
 class _hbm_op:
-    """`with _hbm_op(name, bytes):` around ONE library call (no-op unless an OpProfile is active)."""
+    """`with _hbm_op(name, bytes):` around ONE library call (no-op unless an OpProfile is active).  flops > 0: an MFMA
+    kernel - its algorithmic FLOPs and the instantiation the call launched (vx_last_kernel) are recorded too."""
 
-    def __init__(self, name, nbytes):
-        self.prof, self.name, self.nbytes = OpProfile.active, name, nbytes
+    def __init__(self, name, nbytes, flops=0.0):
+        self.prof, self.name, self.nbytes, self.flops = OpProfile.active, name, nbytes, flops
 
     def __enter__(self):
         if self.prof is not None:
@@ -113,7 +136,41 @@ class _hbm_op:
     def __exit__(self, *a):
         if self.prof is not None:
             self.e.record()
-            self.prof.records.append((self.name, float(self.nbytes), self.s, self.e))
+            sym = _lib.vx_last_kernel().decode() if self.flops else self.name
+            self.prof.records.append((self.name, float(self.nbytes), self.s, self.e, float(self.flops), sym,
+                                      PROFILE_WEIGHT[0]))
+
+
+_log = logging.getLogger("v_express_amd")
+# Which implementation each block of each UNet level took, recorded the first time the decision is made for a geometry
+# (a refused one-launch block used to fall back silently): {(block, geometry...): "path (reason)"}.
+# A block that HAS a one-launch form at its width but was refused by the geometry (f = 24, hw % 8 != 0, ...) is a
+# performance cliff and is logged as a WARNING once; everything else at INFO (logger "v_express_amd").
+BLOCK_PATHS = {}
+
+
+def _note_path(block, geom, fused, path, reason="", cliff=False):
+    key = (block,) + tuple(geom)
+    text = path + (f" ({reason})" if reason else "")
+    if BLOCK_PATHS.get(key) != text:
+        BLOCK_PATHS[key] = text
+        (_log.warning if cliff and not fused else _log.info)("%s %s: %s", block, dict(geom), text)
+    return fused
+
+
+def block_paths():
+    """{"block geometry": "path"} of every decision taken so far (bench.py prints it; tests read it)."""
+    return {f"{k[0]} " + " ".join(f"{a}={b}" for a, b in k[1:]): v for k, v in BLOCK_PATHS.items()}
+
+
+_WARNED = set()
+
+
+def _warn_once(msg):
+    if msg not in _WARNED:
+        _WARNED.add(msg)
+        import warnings
+        warnings.warn(msg, stacklevel=3)
 
 
 def _tile_key(p):
@@ -130,7 +187,7 @@ def _launch_gemm(p, what):
     L.check(_lib.vx_gemm(C.byref(p), _stream()), what)
     e.record()
     prof.records.append((s, e, 2.0 * p.m * p.n * p.k, _tile_key(p), (p.m, p.n, p.k),     # fp8: k incl. the zero padding
-                         _lib.vx_gemm_last_kernel().decode()))
+                         _lib.vx_gemm_last_kernel().decode(), PROFILE_WEIGHT[0]))
     # algorithmic bytes: every input row once (c1 + c2 channels), the weights once, the output once, residual once
     rows_in = p.nb * p.h_in * p.w_in
     n_out = p.n // 2 if p.epi == L.VX_EPI_GEGLU else p.n
@@ -293,6 +350,16 @@ def gn_of(x):
     return getattr(x, "_vx_gn", None) if GN_FUSED[0] else None
 
 
+def _set_gn(t, gst=None):
+    """`t` was just (re)written by a launch: attach the GroupNorm partial sums that launch produced, or - when it produced
+    none - drop whatever an earlier producer left on the same tensor object (a reused `out=` buffer must never carry
+    statistics of its previous contents into `groupnorm()`)."""
+    if gst is not None:
+        t._vx_gn = gst
+    elif getattr(t, "_vx_gn", None) is not None:
+        del t._vx_gn
+
+
 def keep_gn(view, src):
     """`view` is a reshape of `src`: carry the producer's GroupNorm statistics over to the new tensor object."""
     st = getattr(src, "_vx_gn", None)
@@ -344,6 +411,9 @@ def _set_ln(p, ln, eps=1e-5):
         # two-part sums: the persistent kernel finishes them in its epilogue; any other launch gets them finished first
         p.ln_stats_parts, p.ln_eps = 2, float(eps)
         if p.k != 640 or not _lib.vx_gemm_config_name(C.byref(p)).decode().startswith("gemm_ring"):
+            # (5 such launches of ~5 us per DDIM step at 512x512 - profiles/r04y_trace_summary.txt: the V^T halves of the
+            # 32x32-level QKV projections; every other consumer at that level runs on the persistent kernel - so the
+            # finished statistics are not cached across consumers: each statistics version has ONE consumer of this kind)
             fin = torch.empty((p.m, 2), device=stats.device, dtype=torch.float32)
             L.check(_lib.vx_row_stats_finalize(_ptr(stats), p.m, p.k, float(eps), _ptr(fin), _stream()),
                     "vx_row_stats_finalize")
@@ -564,6 +634,12 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
         if FUSED_STATS[0]:
             p.row_stats_out, p.row_stats_eps = stats_out.data_ptr(), float(stats_eps)
             p.row_stats_parts = 2 if stats_out.shape[1] == 4 else 0
+            if p.row_stats_parts and p.ring_hint == 0:
+                # which kernel sums the half rows (the persistent kernel's epilogue or vx_row_stats_parts - different
+                # fp32 summation orders) then depends on the launch size: batch invariance of the two-part statistics
+                # holds only under `with ops.frame_rows(hw, items=...)`, as every call site in blocks.py has it
+                _warn_once("two-part row statistics requested outside ops.frame_rows(items=...): the kernel that sums "
+                           "them is chosen by the launch size, so the low bits depend on the batch")
     gst = None
     if gn is not None and GN_FUSED[0] and not p.a_fp8:
         groups, hw = gn
@@ -575,8 +651,7 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
                           frames, hw, n)
             p.gn_ws = gst.ws.data_ptr()
     _launch_gemm(p, "vx_gemm")
-    if gst is not None:
-        out._vx_gn = gst
+    _set_gn(out, gst)
     if stats_out is not None and not FUSED_STATS[0]:
         row_stats(out, stats_eps, out=stats_out)       # A/B arm: the separate read pass of round 2
     return out
@@ -593,6 +668,7 @@ def geglu(a, w_interleaved, bias_interleaved, out=None, ln=None):
     p.ring_hint = _ring_hint(p)
     _set_ln(p, ln)
     _launch_gemm(p, "vx_gemm(geglu)")
+    _set_gn(out)
     return out
 
 
@@ -604,7 +680,12 @@ _FF_PACKED = {}
 
 
 def ff_fused_applies(m, c, hidden):
-    return FF_FUSED[0] and c == 320 and hidden == 1280 and m % 128 == 0 and not FP8_PROJ[0]
+    why = ("VX_FF_FUSED=0" if not FF_FUSED[0] else "fp8 projection mode" if FP8_PROJ[0] else
+           "the one-launch kernel holds a tile's rows in registers: C = 320 only" if (c != 320 or hidden != 1280) else
+           f"rows {m} not a multiple of 128" if m % 128 else "")
+    return _note_path("feed_forward", (("c", c), ("hidden", hidden), ("rows%128", m % 128)), not why,
+                      "one launch (vx_ff_fused)" if not why else "two launches (GEGLU GEMM + output GEMM)", why,
+                      cliff=(c == 320 and hidden == 1280))
 
 
 def ff_fused(h, w1_folded, b1, colsum, stats, w2, b2):
@@ -629,18 +710,31 @@ def ff_fused(h, w1_folded, b1, colsum, stats, w2, b2):
     p.ln_colsum, p.ln_stats = colsum.data_ptr(), stats.data_ptr()
     p.bias2 = b2.data_ptr() if b2 is not None else None
     p.residual, p.ldr, p.out, p.ldo = h.data_ptr(), ldx, h.data_ptr(), ldx
-    L.check(_lib.vx_ff_fused(C.byref(p), _stream()), "vx_ff_fused")
+    # reads the rows once, writes them once (bf16) + both weights; 2 m c (2 hidden) + 2 m hidden c FLOP
+    with _hbm_op("ff_fused", 2 * (2 * m * c + 3 * hidden * c), flops=6.0 * m * c * hidden):
+        L.check(_lib.vx_ff_fused(C.byref(p), _stream()), "vx_ff_fused")
+    _set_gn(h)
     return h
 
 
 # Temporal self-attention block of the 64x64 level in ONE launch (csrc/vx_tblock.hip): LayerNorm-folded QKV projection,
 # attention over the 16 frames, out-projection and residual; VX_TB_FUSED=0 restores the three launches (A/B knob).
 TB_FUSED = [os.environ.get("VX_TB_FUSED", "1") != "0"]
+# window lengths the one-launch kernel is built for -> pixels per tile (a tile = TB_PIX[f] pixels x their f frames)
+TB_FRAMES = (16,)
+TB_PIX = {16: 8}
 _TB_PACKED = {}
 
 
 def tblock_fused_applies(c, heads, f, hw):
-    return TB_FUSED[0] and LN_FOLD[0] and c == 320 and heads == 8 and f == 16 and hw % 8 == 0 and not FP8_PROJ[0]
+    why = ("VX_TB_FUSED=0" if not TB_FUSED[0] else "LayerNorm fold off" if not LN_FOLD[0] else
+           "fp8 projection mode" if FP8_PROJ[0] else
+           "the one-launch kernel holds a tile's rows in registers: C = 320, 8 heads only" if (c != 320 or heads != 8) else
+           f"window of {f} frames: the one-launch kernel is built for f in {TB_FRAMES}" if f not in TB_FRAMES else
+           f"{hw} pixels per frame not a multiple of the tile's {TB_PIX[f]}" if hw % TB_PIX[f] else "")
+    return _note_path("temporal_attention", (("c", c), ("heads", heads), ("f", f), ("hw%tile", hw % TB_PIX.get(f, 8))),
+                      not why, "one launch (vx_tblock_fused)" if not why else
+                      "three launches (QKV GEMM + temporal attention + output GEMM)", why, cliff=(c == 320 and heads == 8))
 
 
 def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, heads, stats=None, stats_out=None, eps=1e-5):
@@ -676,8 +770,10 @@ def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, hea
     p.ln_stats = stats.data_ptr() if stats is not None else None
     p.stats_out = stats_out.data_ptr() if stats_out is not None else None
     p.ln_eps, p.scale = eps, (c // heads) ** -0.5
-    with _hbm_op("tblock_fused", 2 * m * c * 2):                 # reads the rows once, writes them once (bf16)
+    # reads the rows once, writes them once (bf16); QKV + out projections 2 m c (3c + c), attention over f 4 m f c FLOP
+    with _hbm_op("tblock_fused", 2 * m * c * 2, flops=8.0 * m * c * c + 4.0 * m * f * c):
         L.check(_lib.vx_tblock_fused(C.byref(p), _stream()), "vx_tblock_fused")
+    _set_gn(h)
     return h
 
 
@@ -785,12 +881,17 @@ def gn_fold_applies(m, hw, c, n):
     `_ring_hint`), a 256-row tile never straddles a frame, and the per-frame weight copies (frames x n x c) are cheaper
     to write than the normalised tensor (2 x m x c): c = 320 in practice (the 64x64 and 96x96 levels)."""
     items = _ITEMS[0]
+    geom = (("c", c), ("n", n), ("hw", hw))
+    folded, applied = "GroupNorm folded into per-frame weights (no normalised tensor)", "GroupNorm apply pass + GEMM"
     if not GN_FOLD[0] or items is None or items <= 0 or m % items or hw % 256 or n % 320 or c % 64:
-        return False
+        return _note_path("groupnorm_proj_in", geom, False, applied, "fold off or geometry not whole 256 x 320 tiles per frame")
     if _lib.vx_gemm_get_ring_mode() == 0 or (c > 1280 and _lib.vx_gemm_get_ring_mode() == 1):
-        return False                   # the persistent kernel is switched off (A/B knob vx_gemm_set_ring_mode)
+        # the persistent kernel is switched off (A/B knob vx_gemm_set_ring_mode)
+        return _note_path("groupnorm_proj_in", geom, False, applied, "persistent kernel switched off")
     rows_item = m // items
-    return rows_item % 256 == 0 and (2 * rows_item // 256) * (n // 320) >= 192 and n * 2 <= hw
+    ok = rows_item % 256 == 0 and (2 * rows_item // 256) * (n // 320) >= 192 and n * 2 <= hw
+    return _note_path("groupnorm_proj_in", geom, ok, folded if ok else applied,
+                      "" if ok else "per-frame weight copies would cost more than the normalised tensor")
 
 
 def groupnorm_stats(x1, *, frames, hw, groups, x2=None):
@@ -865,16 +966,23 @@ def attention(q, k, vt, *, batch, heads, n_q, n_kv, head_dim, q_per_kv=1, out=No
     if out is None:
         out = torch.empty((batch * n_q, heads * head_dim), device=q.device, dtype=BF16)
     scale = 0.0 if k_prescaled else head_dim ** -0.5
+    # algorithmic work: QK^T + PV = 4 n_q n_kv d FLOP per (batch, head) at the TRUE head dim (zero padding is not counted);
+    # q and the output once, K and V^T once per kv batch
+    c = heads * head_dim
+    flops = 4.0 * batch * heads * n_q * n_kv * head_dim
+    nbytes = 2 * (2 * batch * n_q * c + 2 * (batch // q_per_kv) * n_kv * c)
     if _BOUNDED_SOFTMAX[0] and 32 < head_dim <= 48 and head_dim % 16:
         if kmax is None:
             kmax = key_norm_max(k, kv_batches=batch // q_per_kv, heads=heads, n_kv=n_kv, head_dim=head_dim)
-        L.check(_lib.vx_attention_bounded(_ptr(q), ldq, _ptr(k), ldk, _ptr(vt), vt.shape[-1], _ptr(out),
-                                          _row_stride(out)[0], batch, heads, n_q, n_kv, head_dim, q_per_kv,
-                                          scale, _ptr(kmax), _stream()), "vx_attention_bounded")
+        with _hbm_op("attention", nbytes, flops=flops):
+            L.check(_lib.vx_attention_bounded(_ptr(q), ldq, _ptr(k), ldk, _ptr(vt), vt.shape[-1], _ptr(out),
+                                              _row_stride(out)[0], batch, heads, n_q, n_kv, head_dim, q_per_kv,
+                                              scale, _ptr(kmax), _stream()), "vx_attention_bounded")
         return out
-    L.check(_lib.vx_attention(_ptr(q), ldq, _ptr(k), ldk, _ptr(vt), vt.shape[-1], _ptr(out), _row_stride(out)[0],
-                              batch, heads, n_q, n_kv, head_dim, q_per_kv, scale, _stream()),
-            "vx_attention")
+    with _hbm_op("attention", nbytes, flops=flops):
+        L.check(_lib.vx_attention(_ptr(q), ldq, _ptr(k), ldk, _ptr(vt), vt.shape[-1], _ptr(out), _row_stride(out)[0],
+                                  batch, heads, n_q, n_kv, head_dim, q_per_kv, scale, _stream()),
+                "vx_attention")
     return out
 
 
@@ -886,7 +994,8 @@ def temporal_attention(qkv, *, b, f, hw, heads, head_dim, out=None):
         raise ValueError("qkv rows != b*f*hw")
     if out is None:
         out = torch.empty((rows, heads * head_dim), device=qkv.device, dtype=BF16)
-    with _hbm_op("temporal_attention", 2 * rows * 4 * heads * head_dim):     # reads q | k | v, writes out (bf16)
+    # reads q | k | v, writes out (bf16); 4 f f d FLOP per (batch, pixel, head)
+    with _hbm_op("temporal_attention", 2 * rows * 4 * heads * head_dim, flops=4.0 * rows * f * heads * head_dim):
         L.check(_lib.vx_temporal_attention(_ptr(qkv), ld, _ptr(out), _row_stride(out)[0], b, f, hw, heads, head_dim,
                                            head_dim ** -0.5, _stream()), "vx_temporal_attention")
     return out
