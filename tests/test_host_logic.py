@@ -606,3 +606,67 @@ def test_tblock_weight_stream_protocol_happens_before():
             S.check_waits(bad, 2)
     finally:
         S.wave_program = orig
+
+
+def test_conv3_emulation_and_schedule():
+    """csrc/vx_conv3.hip before any GPU run: the lane-level emulation of its address arithmetic (plane copies and their slot
+    swizzle, in-place normalisation, tap offsets, weight permutation, K order over the two plane buffers, accumulator ->
+    output mapping) reproduces a float64 convolution of the normalised zero-padded input exactly, and the happens-before
+    replay of its copy / wait / barrier protocol finds no violation with the immediates written in the kernel - and does
+    find one when any of them is raised by one."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "tools", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    emu = load("conv3_emulate")
+    for W, H, frames, c1, c2, n in ((32, 8, 2, 64, 0, 320), (32, 16, 1, 32, 96, 640), (64, 8, 1, 64, 0, 320)):
+        assert emu.check(W, H, frames, c1, c2, n) < 1e-9, (W, H, frames, c1, c2, n)
+    sch = load("conv3_schedule_check")
+    pw, imm = sch.kernel_immediates()
+    assert sch.run(pw, imm) == []
+    for key in imm:
+        assert sch.run(pw, dict(imm, **{key: imm[key] + 1})), key
+    assert sch.run([pw[0] + 1, pw[1]], imm) and sch.run([pw[0], pw[1] + 1], imm)
+    # the weight permutation the host applies (ops.conv3_weight) is the emulation's
+    from v_express_amd import ops
+    w = torch.randn(320, 9 * 64).to(torch.bfloat16)
+    assert torch.equal(ops.conv3_weight(w).float(), torch.from_numpy(emu.permute_weight(w.float().numpy())))
+
+
+def test_resnet_block_conv3_path_composes_like_the_two_launch_path(monkeypatch):
+    """blocks._resnet_block at a geometry the fused GroupNorm + SiLU + conv kernel takes (W = 32, whole tiles): the host
+    composition around ops.conv3_gn (statistics from the producer, time-embedding rows, skip concat, shortcut, residual,
+    the next GroupNorm's partial sums) gives the same result as the GroupNorm-apply + implicit-GEMM composition, on the
+    emulated ops (tests/fake_ops.py)."""
+    import fake_ops
+    from v_express_amd import blocks, ops
+    from v_express_amd.weights import Prepared
+    fake_ops.install(monkeypatch, ops)
+    g = torch.Generator().manual_seed(5)
+    frames, H, W, c1, c2, cout, groups = 2, 8, 32, 64, 64, 320, 32
+    hw = H * W
+
+    def r(*shape, scale=1.0, dtype=torch.bfloat16):
+        return (torch.randn(*shape, generator=g) * scale).to(dtype)
+    cin = c1 + c2
+    P = Prepared(norm1=Prepared(g=1 + 0.1 * r(cin, dtype=torch.float32), b=0.1 * r(cin, dtype=torch.float32)),
+                 conv1=Prepared(w=r(cout, 9 * cin, scale=(9 * cin) ** -0.5), b=r(cout, dtype=torch.float32)),
+                 norm2=Prepared(g=1 + 0.1 * r(cout, dtype=torch.float32), b=0.1 * r(cout, dtype=torch.float32)),
+                 conv2=Prepared(w=r(cout, 9 * cout, scale=(9 * cout) ** -0.5), b=r(cout, dtype=torch.float32)),
+                 shortcut=Prepared(w=r(cout, cin, scale=cin ** -0.5), b=r(cout, dtype=torch.float32)))
+    x, skip = r(frames, hw, c1), r(frames, hw, c2)
+    temb = r(frames, cout, dtype=torch.float32)
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "CONV3_GN", [on])
+        ops.BLOCK_PATHS.clear()
+        o = blocks.resnet_block(P, x, frames, H, W, groups=groups, eps=1e-5, temb=temb, rows_per_group=hw, skip=skip)
+        outs[on] = o
+        path = [v for k, v in ops.block_paths().items() if k.startswith("resnet_conv3x3")]
+        assert len(path) == 2 and all(("vx_conv3x3_gn" in v) == on for v in path), path
+        assert ops.gn_of(o) is not None and ops.gn_of(o).fits(frames, hw, groups, cout)
+    assert torch.equal(outs[True], outs[False])

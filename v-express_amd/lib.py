@@ -39,6 +39,21 @@ class TBlockParams(C.Structure):
     ]
 
 
+class Conv3Params(C.Structure):
+    """Mirror of `vx_conv3_params` (include/vexpress_hip.h)."""
+    _fields_ = [
+        ("x1", C.c_void_p), ("x2", C.c_void_p),
+        ("c1", C.c_int32), ("c2", C.c_int32), ("ldx1", C.c_int32), ("ldx2", C.c_int32),
+        ("frames", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+        ("w_perm", C.c_void_p), ("n", C.c_int32),
+        ("ab", C.c_void_p), ("ab_ld", C.c_int32), ("silu", C.c_int32),
+        ("bias", C.c_void_p), ("rowbias", C.c_void_p), ("rowbias_ld", C.c_int32), ("rows_per_group", C.c_int32),
+        ("residual", C.c_void_p), ("ldr", C.c_int32),
+        ("out", C.c_void_p), ("ldc", C.c_int32),
+        ("gn_ws", C.c_void_p), ("gn_groups", C.c_int32), ("gn_hw", C.c_int32),
+    ]
+
+
 class GemmParams(C.Structure):
     """Mirror of `vx_gemm_params` (include/vexpress_hip.h).""" 
     _fields_ = [
@@ -118,6 +133,9 @@ def _load():
     lib.vx_ff_fused.argtypes = [C.POINTER(FfParams), vp]
     lib.vx_ff_pack_weights.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     lib.vx_tblock_fused.argtypes = [C.POINTER(TBlockParams), vp]
+    lib.vx_conv3x3_gn.argtypes = [C.POINTER(Conv3Params), vp]
+    lib.vx_conv3x3_gn_supported.argtypes = [C.POINTER(Conv3Params)]
+    lib.vx_groupnorm_scale_shift.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, vp]
     lib.vx_tblock_pack.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.vx_groupnorm_fold_linear.argtypes = [vp, i32, i32, i32, i32, f32, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.vx_layernorm.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp]

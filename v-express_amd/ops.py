@@ -509,6 +509,7 @@ def clear_caches():
     _FP8_W.clear()
     _FF_PACKED.clear()
     _TB_PACKED.clear()
+    _C3_W.clear()
 
 
 _ITEMS = [None]
@@ -927,6 +928,108 @@ def groupnorm_fold_linear(ws, gamma, w, bias_beta, *, frames, hw, groups, eps, s
                                           _ptr(w), _ptr(bias_beta), n, _ptr(w_f), _ptr(b_f), _stream()),
             "vx_groupnorm_fold_linear")
     return w_f, b_f
+
+
+# GroupNorm + SiLU + 3x3 convolution of a resnet block as ONE pass over the raw tensor (csrc/vx_conv3.hip, round 5): the
+# normalised, zero-bordered copy that groupnorm(pad_hw=...) + gemm(3x3) went through is never written, and a tile's
+# activations cross the CU's L1 once per 32-channel chunk instead of nine times.  VX_CONV3_GN=0 restores the two launches.
+CONV3_GN = [os.environ.get("VX_CONV3_GN", "1") != "0"]
+_C3_W = {}
+C3_AB_LD = 1024
+
+
+def conv3_weight(w):
+    """[N, 9 C] conv weight with K = (ky, kx, c) -> the kernel's K order (32-channel chunk, tap, 32); cached per tensor."""
+    key = (w.data_ptr(), tuple(w.shape))
+    hit = _C3_W.get(key)
+    if hit is None:
+        n, k = w.shape
+        c = k // 9
+        wp = w.view(n, 9, c // 32, 32).permute(0, 2, 1, 3).reshape(n, k).contiguous()
+        hit = _C3_W[key] = (w, wp)                     # keep `w` alive: the key is its address
+    return hit[1]
+
+
+def _conv3_params(x1, x2, frames, H, W, n):
+    p = L.Conv3Params()
+    p.x1, p.c1, p.ldx1 = x1.data_ptr(), x1.shape[-1], x1.stride(-2)
+    if x2 is not None:
+        p.x2, p.c2, p.ldx2 = x2.data_ptr(), x2.shape[-1], x2.stride(-2)
+    p.frames, p.h, p.w, p.n, p.ab_ld = frames, H, W, n, C3_AB_LD
+    return p
+
+
+def conv3_gn_applies(frames, H, W, c_in, n, c1=None):
+    """Whether the fused GroupNorm + SiLU + 3x3 convolution kernel takes a resnet convolution: a function of the per-frame
+    geometry and the channel counts only (W = 64 or 32, whole 256-pixel tiles per frame, channel multiples - see
+    vx_conv3x3_gn_supported), never of the number of frames in the launch."""
+    c1 = c_in if c1 is None else c1
+    ok = (CONV3_GN[0] and W in (64, 32) and (H * W) % 256 == 0 and c1 % 32 == 0 and (c_in - c1) % 32 == 0 and c_in % 64 == 0
+          and c_in <= C3_AB_LD and n % 320 == 0)
+    why = "" if ok else ("VX_CONV3_GN=0" if not CONV3_GN[0] else
+                         "needs image width 64 or 32 (whole 256-pixel tiles), channel counts in 32s / 64s up to 1024, "
+                         "output channels in 320s")
+    return _note_path("resnet_conv3x3", (("h", H), ("w", W), ("c_in", c_in), ("n", n)), ok,
+                      "GroupNorm + SiLU applied in the convolution's A path (vx_conv3x3_gn)" if ok else
+                      "GroupNorm apply pass into a zero-bordered image + implicit-GEMM convolution", why,
+                      cliff=(W in (96, 48)))
+
+
+def groupnorm_scale_shift(ws, slices, gamma, beta, *, frames, hw, groups, eps):
+    """float32 [frames, 1024, 2] = (scale, shift) per frame and channel from GroupNorm partial sums (vx_groupnorm_scale_shift)."""
+    c = gamma.numel()
+    ab = torch.empty((frames, C3_AB_LD, 2), device=ws.device, dtype=torch.float32)
+    L.check(_lib.vx_groupnorm_scale_shift(_ptr(ws), int(slices), frames, hw, groups, float(eps), _ptr(gamma), _ptr(beta), c,
+                                          _ptr(ab), C3_AB_LD, _stream()), "vx_groupnorm_scale_shift")
+    return ab
+
+
+def conv3_gn(x1, gamma, beta, w, bias, *, frames, H, W, groups, eps, x2=None, silu=True, rowbias=None, rows_per_group=0,
+             residual=None, gn=None):
+    """out = residual + conv3x3_pad1(act(GroupNorm(x1 | x2))) + bias + rowbias, act = SiLU (silu=True): ResnetBlock3D's
+    norm -> SiLU -> conv (modules/resnet.py:220-223, :235-244) without the normalised intermediate.
+    x1: [frames, H*W, C1] (+ x2: [frames, H*W, C2], the skip concat); w: [N, 9 (C1 + C2)] with K = (ky, kx, c).
+    The statistics come from the producer of x1 when it left them (`gn_of`), else from vx_groupnorm_stats.
+    gn=(groups, hw): as in `gemm` - the epilogue leaves the next GroupNorm's partial sums on the returned tensor."""
+    _chk_bf16(x1, "x1")
+    if not x1.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
+        raise ValueError("conv3_gn inputs must be contiguous")
+    hw = H * W
+    n = w.shape[0]
+    ws, slices = groupnorm_stats(x1, frames=frames, hw=hw, groups=groups, x2=x2)
+    ab = groupnorm_scale_shift(ws, slices, gamma, beta, frames=frames, hw=hw, groups=groups, eps=eps)
+    p = _conv3_params(x1, x2, frames, H, W, n)
+    wp = conv3_weight(w)
+    p.w_perm, p.ab, p.silu = wp.data_ptr(), ab.data_ptr(), int(bool(silu))
+    if bias is not None:
+        if bias.dtype != torch.float32:
+            raise TypeError("bias must be float32")
+        p.bias = bias.data_ptr()
+    if rowbias is not None:
+        if rowbias.dtype != torch.float32 or rowbias.stride(-1) != 1:
+            raise TypeError("rowbias must be float32 with contiguous columns")
+        p.rowbias, p.rowbias_ld, p.rows_per_group = rowbias.data_ptr(), rowbias.stride(0), rows_per_group
+    out = torch.empty((frames * hw, n), device=x1.device, dtype=BF16)
+    p.out, p.ldc = out.data_ptr(), n
+    if residual is not None:
+        _chk_bf16(residual, "residual")
+        p.residual, p.ldr = residual.data_ptr(), _row_stride(residual)[0]
+    gst = None
+    if gn is not None and GN_FUSED[0]:
+        g_groups, g_hw = gn
+        cg = n // g_groups if g_groups else 0
+        if g_groups > 0 and n % g_groups == 0 and (frames * hw) % g_hw == 0 and g_hw % 128 == 0 and cg and 80 % cg == 0:
+            slabs = g_hw // 128
+            gst = GnStats(torch.empty((frames * hw // g_hw, slabs, g_groups, 2), device=x1.device, dtype=torch.float32),
+                          slabs, g_groups, frames * hw // g_hw, g_hw, n)
+            p.gn_ws, p.gn_groups, p.gn_hw = gst.ws.data_ptr(), int(g_groups), int(g_hw)
+    cin = p.c1 + p.c2
+    # reads the raw rows once, the weights once, writes the output once (+ residual); 2 m n 9 cin FLOP
+    with _hbm_op("conv3_gn", 2 * (frames * hw * (cin + n * (2 if residual is not None else 1)) + n * 9 * cin),
+                 flops=2.0 * frames * hw * n * 9 * cin):
+        L.check(_lib.vx_conv3x3_gn(C.byref(p), _stream()), "vx_conv3x3_gn")
+    _set_gn(out, gst)
+    return out
 
 
 def layernorm(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_entries=1, out=None):
