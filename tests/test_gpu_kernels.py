@@ -978,7 +978,7 @@ def test_conv3_gn_matches_groupnorm_plus_conv(ops, frames, H, W, c1, c2, n, res,
     launch (bit-identical: batch invariance)."""
     groups, hw = 32, H * W
     c = _conv3_case(ops, frames, H, W, c1, c2, n, res, rowb)
-    assert ops.conv3_gn_applies(frames, H, W, c1 + c2, n, c1)
+    assert ops.conv3_gn_supported(H, W, c1 + c2, n, c1)
     kw = dict(frames=frames, H=H, W=W, groups=groups, eps=1e-5, x2=c["x2"], rowbias=c["rowbias"],
               rows_per_group=hw if rowb else 0, residual=c["r"])
     got = ops.conv3_gn(c["x1"], c["gamma"], c["beta"], c["w2d"], c["bias"], gn=(groups, hw), **kw)
@@ -1020,7 +1020,7 @@ def test_conv3_gn_scale_shift_table_and_refusals(ops):
     assert ab.shape == (frames, 1024, 2) and torch.equal(ab[:, cch:], torch.zeros_like(ab[:, cch:]))
     assert torch.allclose(ab[:, :cch, 0].double(), sc, rtol=2e-6, atol=1e-6)
     assert torch.allclose(ab[:, :cch, 1].double(), sh, rtol=2e-5, atol=2e-6)
-    assert not ops.conv3_gn_applies(2, 96, 96, 320, 320) and not ops.conv3_gn_applies(2, 64, 64, 1280, 320)
+    assert not ops.conv3_gn_supported(96, 96, 320, 320) and not ops.conv3_gn_supported(64, 64, 1280, 320)
     p = ops._conv3_params(rnd(2, 48 * 48, 320), None, 2, 48, 48, 320)
     assert ops._lib.vx_conv3x3_gn_supported(p) == 0
     with pytest.raises(L.VxError):

@@ -625,6 +625,9 @@ def test_conv3_emulation_and_schedule():
     emu = load("conv3_emulate")
     for W, H, frames, c1, c2, n in ((32, 8, 2, 64, 0, 320), (32, 16, 1, 32, 96, 640), (64, 8, 1, 64, 0, 320)):
         assert emu.check(W, H, frames, c1, c2, n) < 1e-9, (W, H, frames, c1, c2, n)
+    # every fragment read is conflict-free under the real (non-contiguous) lane groups of ds_read_b128
+    assert emu.fragment_read_conflicts(64) == 0 and emu.fragment_read_conflicts(32) == 0
+    assert emu.fragment_read_conflicts(64, "quad") > 0          # (the first version's swizzle was not)
     sch = load("conv3_schedule_check")
     pw, imm = sch.kernel_immediates()
     assert sch.run(pw, imm) == []

@@ -197,10 +197,13 @@ def _build_identity():
     """Identity of the LOADED binary: `vx_build_id()` = "<source hash the Makefile stamped>|<extra -D flags>".
     * stamped, no extra flags, hash == the sources on disk: that hash (what committed profiles are keyed by);
     * stamped with extra -D flags (make EXTRA_DEFS=...): "<hash>+<flags>" - never equal to a plain hash;
-    * unstamped (tools/build_*_variants.sh, VX_LIBRARY A/B builds): "unstamped:<file name>";
+    * loaded through VX_LIBRARY (A/B builds of tools/build_*_variants.sh): "variant:<file name>"; unstamped: "unstamped:<file name>";
     * stamped with ANOTHER hash than the sources on disk: the .so is stale -> ImportError (VX_ALLOW_STALE_LIB=1: a warning
       and the identity "stale:<hash>", so that no committed measurement is paired with it)."""
     src, _, defs = lib.vx_build_id().decode().partition("|")
+    if os.environ.get("VX_LIBRARY"):
+        # an explicitly chosen A/B build (tools/build_*_variants.sh link the product's stamped vx_api.o): never the product
+        return "variant:" + os.path.basename(LIB_PATH)
     if src == "unstamped":
         return "unstamped:" + os.path.basename(LIB_PATH)
     disk = source_id()

@@ -932,8 +932,12 @@ def groupnorm_fold_linear(ws, gamma, w, bias_beta, *, frames, hw, groups, eps, s
 
 # GroupNorm + SiLU + 3x3 convolution of a resnet block as ONE pass over the raw tensor (csrc/vx_conv3.hip, round 5): the
 # normalised, zero-bordered copy that groupnorm(pad_hw=...) + gemm(3x3) went through is never written, and a tile's
-# activations cross the CU's L1 once per 32-channel chunk instead of nine times.  VX_CONV3_GN=0 restores the two launches.
-CONV3_GN = [os.environ.get("VX_CONV3_GN", "1") != "0"]
+# activations cross the CU's L1 once per 32-channel chunk instead of nine times.  Correct (kernel, model and full-size
+# parity) but NOT faster than the two launches it replaces: 250 - 260 us against 220 + 34 us at the 64x64 level, whole path
+# -0.8 ... -1.5 % in same-box A/B (profiles/r05b ... r05g: the in-LDS normalisation lengthens the L slots of four of every
+# nine K-tiles by what the apply pass cost, and moved into the M slots its v_exp / v_rcp do not hide under the same
+# wave's MFMAs).  OFF by default; VX_CONV3_GN=1 turns it on.
+CONV3_GN = [os.environ.get("VX_CONV3_GN", "0") == "1"]
 _C3_W = {}
 C3_AB_LD = 1024
 
@@ -959,20 +963,25 @@ def _conv3_params(x1, x2, frames, H, W, n):
     return p
 
 
-def conv3_gn_applies(frames, H, W, c_in, n, c1=None):
-    """Whether the fused GroupNorm + SiLU + 3x3 convolution kernel takes a resnet convolution: a function of the per-frame
-    geometry and the channel counts only (W = 64 or 32, whole 256-pixel tiles per frame, channel multiples - see
-    vx_conv3x3_gn_supported), never of the number of frames in the launch."""
+def conv3_gn_supported(H, W, c_in, n, c1=None):
+    """Geometries vx_conv3x3_gn takes (vx_conv3x3_gn_supported): W = 64 or 32 with whole 256-pixel tiles per frame, source
+    channel counts multiples of 32 summing to a multiple of 64 (<= 1024), output channels a multiple of 320."""
     c1 = c_in if c1 is None else c1
-    ok = (CONV3_GN[0] and W in (64, 32) and (H * W) % 256 == 0 and c1 % 32 == 0 and (c_in - c1) % 32 == 0 and c_in % 64 == 0
-          and c_in <= C3_AB_LD and n % 320 == 0)
-    why = "" if ok else ("VX_CONV3_GN=0" if not CONV3_GN[0] else
+    return (W in (64, 32) and (H * W) % 256 == 0 and c1 % 32 == 0 and (c_in - c1) % 32 == 0 and c_in % 64 == 0
+            and c_in <= C3_AB_LD and n % 320 == 0)
+
+
+def conv3_gn_applies(frames, H, W, c_in, n, c1=None):
+    """Whether a resnet convolution runs on the fused GroupNorm + SiLU + 3x3 convolution kernel: the switch is on and the
+    geometry is supported - a function of the per-frame geometry and the channel counts only, never of the number of
+    frames in the launch."""
+    ok = CONV3_GN[0] and conv3_gn_supported(H, W, c_in, n, c1)
+    why = "" if ok else ("off by default (not faster than the two launches: VX_CONV3_GN=1 turns it on)" if not CONV3_GN[0] else
                          "needs image width 64 or 32 (whole 256-pixel tiles), channel counts in 32s / 64s up to 1024, "
                          "output channels in 320s")
     return _note_path("resnet_conv3x3", (("h", H), ("w", W), ("c_in", c_in), ("n", n)), ok,
                       "GroupNorm + SiLU applied in the convolution's A path (vx_conv3x3_gn)" if ok else
-                      "GroupNorm apply pass into a zero-bordered image + implicit-GEMM convolution", why,
-                      cliff=(W in (96, 48)))
+                      "GroupNorm apply pass into a zero-bordered image + implicit-GEMM convolution", why)
 
 
 def groupnorm_scale_shift(ws, slices, gamma, beta, *, frames, hw, groups, eps):
