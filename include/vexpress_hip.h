@@ -204,14 +204,15 @@ int vx_ff_fused(const vx_ff_params* p, void* stream);
  * x <- x + to_out(softmax_over_frames(q k^T * scale) v),  [q | k | v] = (LN(x) + pe[frame]) Wqkv^T + b   in ONE launch:
  * VersatileAttention.forward inside TemporalTransformerBlock.forward (modules/motion_module.py:243-256, :351-388: the two
  * rearranges, pos_encoder, to_q / to_k / to_v, attention over the frame axis per (pixel, head), to_out, residual) - the
- * [m, 3C] projections and the [m, C] attention output never reach memory.  C = 320, 8 heads, f = 16 frames only (a tile =
- * 8 pixels x their 16 frames; the x rows of a tile live in registers); rows are [(b f), hw] frame-major as everywhere
- * (row = (item * f + frame) * hw + pixel), hw % 8 == 0.  The LayerNorm is folded in as in vx_gemm_params.ln_stats: wqkv =
+ * [m, 3C] projections and the [m, C] attention output never reach memory.  C = 320, 8 heads; f = 16 frames (a tile = 8
+ * pixels x their 16 frames, hw % 8 == 0) or - round 5 - f = 24, the reference's default window (inference.py:67: a tile = 4
+ * pixels x two 16-row blocks, the second one frames 16-23 + 8 masked padding rows; hw % 4 == 0); the x rows of a tile live
+ * in registers; rows are [(b f), hw] frame-major as everywhere (row = (item * f + frame) * hw + pixel).  The LayerNorm is folded in as in vx_gemm_params.ln_stats: wqkv =
  * the folded weight, bias / colsum its bias and column sums, pe_rows = the positional table pushed through the weight
  * (float32 [f][3C]: row `frame` is added to every row of that frame).  ln_stats = (mean, rstd) per row, or NULL: the
  * kernel then takes them from the rows it holds (two-pass, float32).  vx_tblock_pack re-tiles the weights and tables once
- * per layer:  wqkv_t 720896 B (weights and the bias / positional table of each 16-column block together), wo_t 204800 B,
- * colsum_p 4096 B. */
+ * per layer AND window length f:  wqkv_t vx_tblock_packed_bytes(f) = 720896 / 786432 B (weights and the bias / positional
+ * tables of each 16-column block together), wo_t 204800 B, colsum_p 4096 B. */
 typedef struct {
   void* x;                   /* bf16 [b f hw, ldx], updated in place */
   int32_t ldx, b, f, hw, c, heads;
@@ -228,6 +229,7 @@ typedef struct {
 int vx_tblock_pack(const void* wqkv, const float* bias, const float* colsum, const float* pe_rows, int pe_ld,
                    const void* wo, void* wqkv_t, void* wo_t, float* colsum_p, int c, int heads, int f, void* stream);
 int vx_tblock_fused(const vx_tblock_params* p, void* stream);
+int64_t vx_tblock_packed_bytes(int f);
 
 /* ---- 3x3 convolution with the GroupNorm + SiLU in front of it applied in its A-staging path (round 5) ------------
  * out[f, oy, ox, n] = residual + bias[n] + rowbias[m / rows_per_group][n]

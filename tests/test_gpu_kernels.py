@@ -1056,8 +1056,8 @@ def test_ff_fused_prototype_matches_the_two_launches(ops, m):
 
 
 # ------------------------------------------------------------- round 4: the temporal attention block in one launch
-def _tblock_problem(b, hw, seed=0):
-    c, heads, f = 320, 8, 16
+def _tblock_problem(b, hw, seed=0, f=16):
+    c, heads = 320, 8
     x = rnd(b * f * hw, c, seed=seed) * 1.5 + 0.3
     wqkv = rnd(3 * c, c, scale=c ** -0.5, seed=seed + 1)
     wo = rnd(c, c, scale=c ** -0.5, seed=seed + 2)
@@ -1068,7 +1068,8 @@ def _tblock_problem(b, hw, seed=0):
     return x, wqkv, wo, bq, bo, pe, colsum
 
 
-def test_tblock_pack_matches_the_emulated_layout(ops):
+@pytest.mark.parametrize("f", [16, 24])
+def test_tblock_pack_matches_the_emulated_layout(ops, f):
     """vx_tblock_pack against tools/tblock_emulate.pack - the numpy statement of the fragment-major layouts that the
     lane-level emulation of the kernel (tests/test_host_logic.py) checks against plain float64 math."""
     import sys
@@ -1077,33 +1078,39 @@ def test_tblock_pack_matches_the_emulated_layout(ops):
     from v_express_amd import lib as L
     _, wqkv, wo, bq, _, pe, colsum = _tblock_problem(1, 8)
     dev = wqkv.device
-    wqkv_t = torch.empty(720896 // 2, device=dev, dtype=BF)
+    nbytes = int(L.lib.vx_tblock_packed_bytes(f))
+    assert nbytes == 32 * (20480 + (2048 if f == 16 else 4096))
+    wqkv_t = torch.empty(nbytes // 2, device=dev, dtype=BF)
     wo_t = torch.empty(204800 // 2, device=dev, dtype=BF)
     cs = torch.empty(1024, device=dev, dtype=torch.float32)
     L.check(L.lib.vx_tblock_pack(wqkv.data_ptr(), bq.data_ptr(), colsum.data_ptr(), pe.data_ptr(), pe.stride(0),
-                                 wo.data_ptr(), wqkv_t.data_ptr(), wo_t.data_ptr(), cs.data_ptr(), 320, 8, 16,
+                                 wo.data_ptr(), wqkv_t.data_ptr(), wo_t.data_ptr(), cs.data_ptr(), 320, 8, f,
                                  torch.cuda.current_stream().cuda_stream), "vx_tblock_pack")
     e_w, e_tab, e_wo, e_cs = E.pack(wqkv.float().cpu().numpy(), bq.cpu().numpy(), colsum.cpu().numpy(),
-                                    pe[:16].cpu().numpy(), wo.float().cpu().numpy())
-    chunks = wqkv_t.view(torch.uint8).cpu().view(32, 22528)          # a chunk: 20480 B of bf16 weights, 2048 B of fp32 table
+                                    pe[:f].cpu().numpy(), wo.float().cpu().numpy(), f)
+    chunks = wqkv_t.view(torch.uint8).cpu().view(32, nbytes // 32)   # a chunk: 20480 B of bf16 weights, then its fp32 tables
     assert torch.equal(chunks[:, :20480].contiguous().view(torch.bfloat16).float(), torch.from_numpy(e_w).reshape(32, -1))
     assert torch.equal(chunks[:, 20480:].contiguous().view(torch.float32), torch.from_numpy(e_tab).reshape(32, -1))
     assert torch.equal(wo_t.float().cpu(), torch.from_numpy(e_wo).reshape(-1))
     assert torch.equal(cs.cpu(), torch.from_numpy(e_cs))
 
 
-@pytest.mark.parametrize("b,hw,given_stats", [(1, 8, True), (2, 64, False), (2, 4096, True), (2, 4096, False), (3, 1160, False)])
-def test_tblock_fused_matches_the_three_launches(ops, b, hw, given_stats):
-    """vx_tblock_fused (C = 320, 8 heads, 16 frames): LayerNorm-folded QKV projection + positional rows, attention over the
+@pytest.mark.parametrize("b,hw,given_stats,f", [(1, 8, True, 16), (2, 64, False, 16), (2, 4096, True, 16), (2, 4096, False, 16),
+                                                (3, 1160, False, 16), (1, 4, True, 24), (2, 64, False, 24), (2, 4096, True, 24),
+                                                (3, 1156, False, 24)])
+def test_tblock_fused_matches_the_three_launches(ops, b, hw, given_stats, f):
+    """vx_tblock_fused (C = 320, 8 heads, 16 frames - or 24, the reference's default window, inference.py:67: two 16-row
+    blocks per pixel, the padded key frames masked): LayerNorm-folded QKV projection + positional rows, attention over the
     frame axis, out-projection and residual in ONE launch (VersatileAttention inside TemporalTransformerBlock,
     modules/motion_module.py:243-256, :351-388) against the three launches it replaces - same rounding points, so the two
     differ only by the summation order inside the 16 x 16 products: a few bf16 ulps on a few elements - and against
     float32 math.  given_stats = False: the kernel takes the LayerNorm statistics from the rows it holds.
     (3, 1160): a tile count that is no multiple of the grid, pixels per item no power of two."""
-    c, heads, f = 320, 8, 16
+    c, heads = 320, 8
     d = c // heads
-    x, wqkv, wo, bq, bo, pe, colsum = _tblock_problem(b, hw)
+    x, wqkv, wo, bq, bo, pe, colsum = _tblock_problem(b, hw, f=f)
     m = b * f * hw
+    assert ops.tblock_fused_applies(c, heads, f, hw)
     stats = ops.row_stats(x)
     with ops.frame_rows(hw, items=b):
         qkv = ops.gemm(x, wqkv, bq, rowbias=pe[:f].repeat(b, 1).contiguous(), rows_per_group=hw, ln=(stats, colsum))
@@ -1122,7 +1129,7 @@ def test_tblock_fused_matches_the_three_launches(ops, b, hw, given_stats):
     diff = (got.float() - want.float()).abs()
     frac = (got != want).float().mean().item()
     scale = want.float().abs().max().item()
-    print(f"[tblock_fused b={b} hw={hw} stats={'given' if given_stats else 'own'}] max|diff| vs three launches "
+    print(f"[tblock_fused f={f} b={b} hw={hw} stats={'given' if given_stats else 'own'}] max|diff| vs three launches "
           f"{diff.max().item():.4g} (max |out| {scale:.3g}), differing elements {100 * frac:.3g} %, "
           f"rel-L2 {(diff.norm() / want.float().norm()).item():.3g}")
     assert diff.max().item() <= 2 ** -5 * scale and (diff.norm() / want.float().norm()).item() <= 2e-3
@@ -1134,7 +1141,7 @@ def test_tblock_fused_matches_the_three_launches(ops, b, hw, given_stats):
     q, k, v = (t.reshape(b, f, hw, heads, d).permute(0, 2, 3, 1, 4) for t in q3.to(BF).float().chunk(3, dim=-1))
     o = F.scaled_dot_product_attention(q, k, v).permute(0, 3, 1, 2, 4).reshape(m, c)
     ref = xf + o.to(BF).float() @ wo.float().t() + bo
-    check(got, ref, f"tblock_fused b={b} hw={hw} vs float32", rel=8e-3)
+    check(got, ref, f"tblock_fused f={f} b={b} hw={hw} vs float32", rel=8e-3)
 
 
 # ------------------------------------------------------------- round 4: row statistics in two parts (n = k = 640)

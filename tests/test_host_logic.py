@@ -578,6 +578,7 @@ def test_tblock_lane_level_emulation_matches_plain_math():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import tblock_emulate as E
     assert E.self_check(seed=1) < 2e-3
+    assert E.self_check(seed=2, F=24) < 2e-3          # the reference's default window: two blocks per pixel, masked padding
     # every column of q | k | v appears exactly once in the packed order, 8 pad rows per head
     cols = [E.src_col(h, blk, r) for h in range(8) for blk in range(8) for r in range(16)]
     assert sorted(c for c in cols if c >= 0) == list(range(960)) and cols.count(-1) == 64

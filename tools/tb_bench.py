@@ -1,5 +1,5 @@
-"""Time vx_tblock_fused against the three launches it replaces at the 64x64 level (b = 2, 16 frames, 4096 pixels):
-    python tools/tb_bench.py [iters]"""
+"""Time vx_tblock_fused against the three launches it replaces at the 64x64 level (b = 2, f frames, 4096 pixels):
+    python tools/tb_bench.py [iters] [f = 16 | 24]"""
 import sys
 
 import os
@@ -16,7 +16,7 @@ BF = torch.bfloat16
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    b, f, hw, c, heads = 2, 16, 4096, 320, 8
+    b, f, hw, c, heads = 2, (int(sys.argv[2]) if len(sys.argv) > 2 else 16), 4096, 320, 8
     g = torch.Generator().manual_seed(0)
     r = lambda *s, scale=1.0, dt=BF: (torch.randn(*s, generator=g) * scale).to("cuda").to(dt)
     x = r(b * f * hw, c) + 0.3
@@ -49,7 +49,7 @@ def main():
             fn(hs[i % 4])
         e1.record()
         torch.cuda.synchronize()
-        print(f"{name:70s} {1e3 * e0.elapsed_time(e1) / iters:8.1f} us")
+        print(f"f={f} {name:70s} {1e3 * e0.elapsed_time(e1) / iters:8.1f} us")
 
 
 if __name__ == "__main__":

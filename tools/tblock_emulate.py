@@ -10,7 +10,24 @@ MFMA lane layouts (gfx950, as used by every kernel of this library):
 """
 import numpy as np
 
-C, HEADS, D, F, PIX = 320, 8, 40, 16, 8
+C, HEADS, D, BLOCKS = 320, 8, 40, 8
+# window length F = 16: one 16-row block per pixel, 8 pixels per tile; F = 24 (round 5): two blocks per pixel (frames 0-15,
+# frames 16-23 + 8 padding rows that repeat frame 23), 4 pixels per tile
+
+
+def geo(F):
+    HB = 2 if F > 16 else 1
+    return HB, BLOCKS // HB
+
+
+def blk_pix(b, HB):
+    return b if HB == 1 else b >> 1
+
+
+def blk_frames(b, HB, F):
+    """frame of each of the 16 rows of block b (padding rows re-read the last frame)"""
+    fr = np.arange(16) if HB == 1 else 16 * (b & 1) + np.arange(16)
+    return np.minimum(fr, F - 1)
 KS = C // 32
 PCOLS = HEADS * 8 * 16
 NW, NPX = 8, 2
@@ -52,12 +69,14 @@ def src_col(head, blk, r):
     return v + 32 + r if r < 8 else -1
 
 
-def pack(wqkv, bias, colsum, pe, wo):
-    """tblock_pack_kernel: returns wqkv_t [32 chunks][10][2][64][8] (the weights of a chunk), tab [32 chunks][2][256] (the
-    fp32 table behind them: bias + positional row, [frame][column] for blocks 0..4, [column][frame] for the V blocks),
-    wo_t [4][25600] in elements, colsum_p [1024]"""
+def pack(wqkv, bias, colsum, pe, wo, F=16):
+    """tblock_pack_kernel: returns wqkv_t [32 chunks][10][2][64][8] (the weights of a chunk), tab [32 chunks][2 HB][256]
+    (the fp32 tables behind them, one per (head of the pair, block half): bias + positional row of frame 16 half + row,
+    [row][column] for blocks 0..4, [column][row] for the V blocks; frames >= F: 0), wo_t [4][25600] in elements,
+    colsum_p [1024]"""
+    HB, _ = geo(F)
     wqkv_t = np.zeros((32, KS, 2, 64, 8), np.float32)
-    tab = np.zeros((32, 2, 256), np.float32)
+    tab = np.zeros((32, 2 * HB, 256), np.float32)
     for ch in range(32):
         hp, blk = ch >> 3, ch & 7
         for wn in range(2):
@@ -68,11 +87,13 @@ def pack(wqkv, bias, colsum, pe, wo):
                     continue
                 for ks in range(KS):
                     wqkv_t[ch, ks, wn, lane] = wqkv[col, 32 * ks + 8 * (lane >> 4): 32 * ks + 8 * (lane >> 4) + 8]
-            for e in range(256):
-                fr, r = (e >> 4, e & 15) if blk < 5 else (e & 15, e >> 4)
-                col = src_col(head, blk, r)
-                if col >= 0:
-                    tab[ch, wn, e] = bias[col] + pe[fr, col]
+            for hh in range(HB):
+                for e in range(256):
+                    fr, r = (e >> 4, e & 15) if blk < 5 else (e & 15, e >> 4)
+                    fr += 16 * hh
+                    col = src_col(head, blk, r)
+                    if col >= 0 and fr < F:
+                        tab[ch, wn * HB + hh, e] = bias[col] + pe[fr, col]
     wo_t = np.zeros((4, 25600), np.float32)          # per head pair: part0 10240 | part1 10240 | part2 5120 elements
     for hp in range(4):
         for part in range(2):
@@ -100,16 +121,20 @@ def pack(wqkv, bias, colsum, pe, wo):
 
 
 def run_tile(x_tile, packed, scale_log2e, eps):
-    """x_tile: [8 pixels][16 frames][320] (bf16 values as float32) -> the tile's output rows, same shape"""
+    """x_tile: [PIX pixels][F frames][320] (bf16 values as float32) -> the tile's output rows, same shape"""
     wqkv_t, tab, wo_t, colsum_p = packed
-    o_lds = np.zeros((4, PIX, 1280), np.float32)       # per head pair, pixel: kb0 512 elements | kb1 512 | kb2 256
-    st_lds = np.zeros((PIX, F, 2), np.float32)
+    PIX, F = x_tile.shape[0], x_tile.shape[1]
+    HB, pix_ = geo(F)
+    assert pix_ == PIX
+    o_lds = np.zeros((4, BLOCKS, 1280), np.float32)    # per head pair, block: kb0 512 elements | kb1 512 | kb2 256
+    st_lds = np.zeros((BLOCKS, 16, 2), np.float32)
     for wave in range(NW):
         wm, wn = wave >> 1, wave & 1
         xa = np.zeros((NPX, KS, 64, 8), np.float32)
         rs, rm = np.zeros((NPX, 64), np.float32), np.zeros((NPX, 64), np.float32)
         for i in range(NPX):
-            rows = x_tile[NPX * wm + i]                  # [frame][320]
+            b_ = NPX * wm + i
+            rows = x_tile[blk_pix(b_, HB)][blk_frames(b_, HB, F)]      # [row of the block][320]
             for ks in range(KS):
                 for e in range(8):
                     xa[i, ks, :, e] = rows[LROW, 32 * ks + 8 * LQ + e]
@@ -130,7 +155,7 @@ def run_tile(x_tile, packed, scale_log2e, eps):
                 c = 8 * hp + blk
                 pc = (head * 8 + blk) * 16
                 plain = blk >= 5
-                tq = np.stack([tab[c, wn, LROW * 16 + 4 * LQ + r] for r in range(4)], axis=1)   # slot + 20480 + wn * 1024
+                tqh = [np.stack([tab[c, wn * HB + hh, LROW * 16 + 4 * LQ + r] for r in range(4)], axis=1) for hh in range(HB)]
                 P = np.zeros((NPX, 64, 4), np.float32)
                 for ks in range(KS):
                     wf = wqkv_t[c, ks, wn]               # smem + slot + ks * 2048 + wn * 1024 + lane * 16
@@ -139,6 +164,7 @@ def run_tile(x_tile, packed, scale_log2e, eps):
                 if blk < 5:
                     s4 = np.stack([colsum_p[pc + 4 * LQ + r] for r in range(4)], axis=1)
                     for i in range(NPX):
+                        tq = tqh[0 if HB == 1 else i]
                         v = rs[i][:, None] * P[i] + (rm[i][:, None] * s4 + tq)
                         v = bf16(v)
                         if blk < 2: Qp[i, blk] = v
@@ -147,28 +173,42 @@ def run_tile(x_tile, packed, scale_log2e, eps):
                 else:
                     s1 = colsum_p[pc + LROW]
                     for i in range(NPX):
+                        tq = tqh[0 if HB == 1 else i]
                         a = np.stack([st_lds[NPX * wm + i, 4 * LQ + r, 0] for r in range(4)], axis=1)
                         b = np.stack([st_lds[NPX * wm + i, 4 * LQ + r, 1] for r in range(4)], axis=1)
                         Vp[i, blk - 5] = bf16(a * P[i] + (b * s1[:, None] + tq))
+            # permlane32_swap(M, 0): [0] = (M lanes 0-31 | 0) = q 32..39, [1] = (M lanes 32-63 moved to 0-31 | 0) = k 32..39
+            mq, mk = [], []
             for i in range(NPX):
-                ka = np.concatenate([Kp[i, 0], Kp[i, 1]], axis=1)
-                qa = np.concatenate([Qp[i, 0], Qp[i, 1]], axis=1)
-                sc = mfma(ka, qa, np.zeros((64, 4), np.float32), 8)
-                # permlane32_swap(M, 0): [0] = (M lanes 0-31 | 0), [1] = (M lanes 32-63 moved to 0-31 | 0)
-                qm = np.where((LANES < 32)[:, None], Mp[i], 0.0).astype(np.float32)
+                mq.append(np.where((LANES < 32)[:, None], Mp[i], 0.0).astype(np.float32))
                 km = np.zeros((64, 4), np.float32)
                 km[:32] = Mp[i][32:]
-                sc = mfma(km, qm, sc, 4)
-                mx = sc.max(axis=1)
+                mk.append(km)
+            for i in range(NPX):                       # query block i against HB key blocks
+                qa = np.concatenate([Qp[i, 0], Qp[i, 1]], axis=1)
+                scs = []
+                for kbi in range(HB):
+                    kb = i if HB == 1 else kbi
+                    ka = np.concatenate([Kp[kb, 0], Kp[kb, 1]], axis=1)
+                    sc = mfma(ka, qa, np.zeros((64, 4), np.float32), 8)
+                    sc = sc + mfma(mk[kb], mq[i], np.zeros((64, 4), np.float32), 4)
+                    if HB == 2 and kbi == 1:
+                        sc = np.where((LQ >= 2)[:, None], -np.inf, sc).astype(np.float32)   # frames 24 .. 31 do not exist
+                    scs.append(sc)
+                mx = np.max(np.stack([sc.max(axis=1) for sc in scs]), axis=0)
                 mx = np.maximum(mx, mx[LANES ^ 16])
                 mx = np.maximum(mx, mx[LANES ^ 32])
-                pr = np.exp2(sc * scale_log2e - (mx * scale_log2e)[:, None]).astype(np.float32)
-                sm = pr.sum(axis=1)
+                prs = [np.exp2(sc * scale_log2e - (mx * scale_log2e)[:, None]).astype(np.float32) for sc in scs]
+                sm = sum(pr.sum(axis=1) for pr in prs)
                 sm = sm + sm[LANES ^ 16]
                 sm = sm + sm[LANES ^ 32]
                 inv_l = (1.0 / sm).astype(np.float32)
-                pb = bf16(pr)
-                o = [bf16(mfma(Vp[i, vb], pb, np.zeros((64, 4), np.float32), 4) * inv_l[:, None]) for vb in range(3)]
+                o = []
+                for vb in range(3):
+                    a = np.zeros((64, 4), np.float32)
+                    for kbi in range(HB):
+                        a = mfma(Vp[i if HB == 1 else kbi, vb], bf16(prs[kbi]), a, 4)
+                    o.append(bf16(a * inv_l[:, None]))
                 pix = NPX * wm + i
                 for lane in range(64):
                     base = wn * 512 + lane * 8
@@ -201,15 +241,19 @@ def run_tile(x_tile, packed, scale_log2e, eps):
                             bw = wo_t[hp2, 20480 + jj * 256: 20480 + (jj + 1) * 256].reshape(64, 4)
                             Y[i, j] = mfma(bw, oa, Y[i, j], 4)
         for i in range(4):
+            b_ = s2_pix0 + i
+            fr = (np.arange(16) if HB == 1 else 16 * (b_ & 1) + np.arange(16))[LROW]
+            keep = fr < F                                  # padding rows are never stored
             for j in range(SNJ):
                 for r in range(4):
                     col = s2_col0 + 16 * j + 4 * LQ + r
-                    out[s2_pix0 + i, LROW, col] = Y[i, j][:, r]
+                    out[blk_pix(b_, HB), fr[keep], col[keep]] = Y[i, j][keep, r]
     return out          # the out-projection WITHOUT bias / residual
 
 
 def reference(x_tile, wqkv, bias, colsum, pe, wo, scale_log2e, eps):
-    """The same block in float64 with the same rounding points: [8][16][320] -> out-projection without bias / residual"""
+    """The same block in float64 with the same rounding points: [PIX][F][320] -> out-projection without bias / residual"""
+    PIX, F = x_tile.shape[0], x_tile.shape[1]
     x = x_tile.astype(np.float64)
     mean = x.mean(axis=2, keepdims=True)
     var = ((x - mean) ** 2).mean(axis=2, keepdims=True)
@@ -230,8 +274,9 @@ def reference(x_tile, wqkv, bias, colsum, pe, wo, scale_log2e, eps):
     return out
 
 
-def self_check(seed=0):
+def self_check(seed=0, F=16):
     rng = np.random.default_rng(seed)
+    PIX = geo(F)[1]
     x = bf16(rng.standard_normal((PIX, F, C)) * 1.5 + 0.3 * rng.standard_normal((PIX, F, 1)))
     wqkv = bf16(rng.standard_normal((3 * C, C)) * C ** -0.5)
     wo = bf16(rng.standard_normal((C, C)) * C ** -0.5)
@@ -239,11 +284,12 @@ def self_check(seed=0):
     colsum = wqkv.astype(np.float64).sum(axis=1).astype(np.float32)
     pe = (0.5 * rng.standard_normal((F, 3 * C))).astype(np.float32)
     scale_log2e, eps = np.float32(D ** -0.5 * 1.4426950408889634), 1e-5
-    got = run_tile(x, pack(wqkv, bias, colsum, pe, wo), scale_log2e, eps)
+    got = run_tile(x, pack(wqkv, bias, colsum, pe, wo, F), scale_log2e, eps)
     ref = reference(x, wqkv, bias, colsum, pe, wo, scale_log2e, eps)
     err = np.abs(got - ref).max() / np.abs(ref).max()
     return float(err)
 
 
 if __name__ == "__main__":
-    print("max |emulated - reference| / max |reference| =", self_check())
+    for F_ in (16, 24):
+        print(f"F = {F_}: max |emulated - reference| / max |reference| =", self_check(F=F_))

@@ -23,13 +23,15 @@ SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 def constants():
     s = open(SRC).read()
     nw = int(re.search(r"#define VX_TB_WAVES (\d+)", s).group(1))
-    assert "constexpr int CPW = (22 + NW - 1) / NW;" in s and "constexpr int NX = NPX * TB_KS;" in s
+    assert "constexpr int CPW = (NBLK + NW - 1) / NW;" in s and "constexpr int NX = NPX * TB_KS;" in s
+    assert "static constexpr int NBLK = 20 + 2 * HB;" in s          # 22 copy blocks per QKV chunk at F = 16, 24 at F = 24
     assert "TB_QKV_CHUNKS = 32, TB_TILE_CHUNKS = 44" in s and "constexpr int JB = 3;" in s
     # the three waits of the protocol, as written in the kernel
     assert s.count("tb_wait_vm<CPW>();") == 2 and "tb_wait_vm<CPW + NX>();" in s
     assert "if (hp2 == 0 && part > 0 && more) tb_wait_vm<CPW + NX>();" in s
     assert "load_x(0);       // BEFORE the first copies" in s
     cpw = (22 + nw - 1) // nw
+    assert cpw == (24 + nw - 1) // nw                                 # the same number of copies per wave for both window lengths
     nx = (16 // nw) * 10
     return dict(NW=nw, CPW=cpw, NX=nx, QKV=32, CHUNKS=44, SNJ=20 // (nw // 2), JB=3)
 

@@ -23,6 +23,11 @@
 //     head in flight + accumulators + operands = ~265 of 256 registers with eight waves, ~480 of 512 with four: the first
 //     build spilled 320 / 407 registers.  In two phases the peak is x 80 + q/k/v 32 + 30 resp. Y 80 + x 80.)
 //   * LayerNorm statistics come from the x rows the wave holds (two-pass, in registers) unless the caller passes them.
+// Round 5: F = 24 frames (the reference's default window, inference.py:67) as well.  A pixel's 24 frames are TWO 16-row MFMA
+// blocks (frames 0-15, frames 16-23 + 8 padding rows that re-read frame 23): a tile = 4 pixels x 2 blocks = the same 8
+// blocks, a wave holds both blocks of its pixel, the attention of a (pixel, head) is 2 x 2 score blocks with the padded
+// keys masked to -inf (their probabilities are exactly 0) and the padded query rows never stored; the bias / positional
+// tables of a chunk grow to one 16 x 16 table per (head, block half).  25 % of the projection MFMAs multiply padding.
 // Rounding points are those of the three launches (q, k, v, P, O rounded to bf16; fp32 accumulation in k order; the
 // LayerNorm fold as two FMAs), so the result differs from theirs only by the summation order inside the 16 x 16 products.
 #include "vx_common.h"
@@ -36,7 +41,7 @@
 
 namespace {
 
-constexpr int TB_C = 320, TB_HEADS = 8, TB_D = 40, TB_F = 16, TB_PIX = 8;
+constexpr int TB_C = 320, TB_HEADS = 8, TB_D = 40;
 #ifndef VX_TB_WAVES
 #define VX_TB_WAVES 8
 #endif
@@ -44,17 +49,26 @@ constexpr int TB_NW = VX_TB_WAVES, TB_NPX = 16 / TB_NW;   // waves per workgroup
 constexpr int TB_KS = TB_C / 32;                 // 10 k-steps of 32
 constexpr int TB_PCOLS = TB_HEADS * 8 * 16;      // 1024 packed columns: 8 blocks of 16 per head
 constexpr int TB_WBYTES = 2 * 16 * TB_C * 2;     // 20480 B of weights per QKV chunk: [k-step 10][head of the pair 2][lane 64][16 B]
-constexpr int TB_SLOT = TB_WBYTES + 2 * 1024;    // + the chunk's bias / positional table, 16 x 16 fp32 per head: 22528 B
 constexpr int TB_QKV_CHUNKS = 32, TB_TILE_CHUNKS = 44;   // + 4 head pairs x 3 out-projection parts
 constexpr int WO_P01 = 20 * 1024, WO_P2 = 20 * 512;
 constexpr int WO_PAIR = 2 * WO_P01 + WO_P2;      // 51200 B per head pair
 constexpr int RING_OFF = 0;                      // 3 slots
-constexpr int O_OFF = 3 * TB_SLOT;               // 67584: O^T of the tile, [head pair][pixel][kb0 1024 | kb1 1024 | kb2 512]
-constexpr int O_PIX = 2560, O_PAIR = TB_PIX * O_PIX;     // 20480 per head pair
-constexpr int CS_OFF = O_OFF + 4 * O_PAIR;       // 149504: column sums of the folded weight, packed column order (fp32)
-constexpr int BO_OFF = CS_OFF + TB_PCOLS * 4;    // 153600: out-projection bias (fp32)
-constexpr int ST_OFF = BO_OFF + TB_C * 4;        // 154880: (rstd, -mean rstd) of the tile's rows, [pixel][frame]
-constexpr int TB_LDS = ST_OFF + TB_PIX * TB_F * 8;   // 155904 <= 163840
+constexpr int TB_BLOCKS = 8;                     // 16-row MFMA blocks per tile
+constexpr int O_PIX = 2560, O_PAIR = TB_BLOCKS * O_PIX;  // O^T of a block: [kb0 1024 | kb1 1024 | kb2 512]; 20480 per head pair
+// geometry that depends on the window length F (16 or 24 frames): HB blocks per pixel, PIX pixels per tile
+template <int F>
+struct TbGeo {
+  static_assert(F == 16 || F == 24, "vx_tblock: 16 or 24 frames");
+  static constexpr int HB = F > 16 ? 2 : 1;
+  static constexpr int PIX = TB_BLOCKS / HB;
+  static constexpr int NBLK = 20 + 2 * HB;              // 1-KiB copy blocks of a QKV chunk: 20 of weights + the tables
+  static constexpr int SLOT = TB_WBYTES + 2 * HB * 1024;  // + bias / positional tables, 16 x 16 fp32 per (head, block half): 22528 / 24576 B
+  static constexpr int O_OFF = 3 * SLOT;                // O^T of the tile, [head pair][block]
+  static constexpr int CS_OFF = O_OFF + 4 * O_PAIR;     // column sums of the folded weight, packed column order (fp32)
+  static constexpr int BO_OFF = CS_OFF + TB_PCOLS * 4;  // out-projection bias (fp32)
+  static constexpr int ST_OFF = BO_OFF + TB_C * 4;      // (rstd, -mean rstd) of the tile's rows, [block][row]
+  static constexpr int LDS = ST_OFF + TB_BLOCKS * 16 * 8;   // 155904 / 162048 <= 163840
+};
 
 // Compile-time ablation switches (tools/build_tb_variants.sh; never defined for the product library):
 //   1 no weight copies after the prologue   2 no attention (O = the V rows)   4 no LayerNorm fold / tables
@@ -107,10 +121,15 @@ __host__ __device__ inline int tb_src_col(int head, int blk, int r) {
   }
 }
 
+template <int F>
 __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(const vx_tblock_params p,
                                                                                  const float scale_log2e) {
+  using G_ = TbGeo<F>;
+  constexpr int HB = G_::HB, TB_PIX = G_::PIX, TB_SLOT = G_::SLOT, NBLK = G_::NBLK;
+  constexpr int O_OFF = G_::O_OFF, CS_OFF = G_::CS_OFF, BO_OFF = G_::BO_OFF, ST_OFF = G_::ST_OFF;
   constexpr int NW = TB_NW, NT = 64 * NW, NPX = TB_NPX;
-  constexpr int CPW = (22 + NW - 1) / NW;         // copies per wave and chunk (slots past the end repeat a block)
+  static_assert(HB == 1 || NPX == 2, "F = 24: a wave must hold both blocks of its pixel");
+  constexpr int CPW = (NBLK + NW - 1) / NW;       // copies per wave and chunk (slots past the end repeat a block)
   constexpr int SNJ = 20 / (NW / 2);              // out-projection column blocks per wave
   constexpr int NX = NPX * TB_KS;                 // loads of one wave's x rows
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
   auto tile_row0 = [&](int ti) {                         // row of (frame 0, first pixel) of the ti-th tile of this block
     const int t = tfirst + ti * G;
     const int bb = t / tiles_per_item, px = (t - bb * tiles_per_item) * TB_PIX;
-    return (size_t)bb * TB_F * p.hw + px;
+    return (size_t)bb * F * p.hw + px;
   };
 
   const char* __restrict__ wq = (const char*)p.wqkv_t;
@@ -149,12 +168,19 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
   const float* bo_tab = reinterpret_cast<const float*>(smem + BO_OFF);
 
   // ---- x rows of the wave: lane = frame lrow of pixel NPX wm + i, k group lq (second MFMA operand of Q / K, first of V)
+  // block NPX wm + i of the tile = (pixel, block half): F = 16: (NPX wm + i, 0); F = 24: (wm, i) - rows 16 half + lrow of the
+  // pixel's frames, rows past the last frame re-read it (padding: masked as keys, never stored as queries)
+  auto blk_pix = [&](int b) { return HB == 1 ? b : b >> 1; };
+  auto blk_frame = [&](int b, int r) {
+    const int fr = HB == 1 ? r : 16 * (b & 1) + r;
+    return fr < F ? fr : F - 1;
+  };
   uint4 xa[NPX][TB_KS];
   auto load_x = [&](int ti) {
-    const size_t r0 = tile_row0(ti) + NPX * wm;
+    const size_t r0 = tile_row0(ti);
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
-      const bf16_t* row = x + (r0 + i) * p.ldx + lrow * frame_stride + 8 * lq;
+      const bf16_t* row = x + (r0 + blk_pix(NPX * wm + i)) * p.ldx + blk_frame(NPX * wm + i, lrow) * frame_stride + 8 * lq;
 #pragma unroll
       for (int ks = 0; ks < TB_KS; ++ks) xa[i][ks] = *reinterpret_cast<const uint4*>(row + 32 * ks);
     }
@@ -170,7 +196,7 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
   auto issue = [&](int c, int slot, int q) {        // q-th copy of this wave for chunk c (0 .. 43) into ring slot `slot`
     if (TABL(1) && in_loop) return;
     const char* src;
-    int nblk = 22;
+    int nblk = NBLK;
     if (c < TB_QKV_CHUNKS) {
       src = wq + (size_t)c * TB_SLOT;
     } else {
@@ -180,7 +206,7 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
       if (part == 2) nblk = 10;
     }
     const int iq = wave + NW * q;                                   // constant divisors: no scalar division sequence
-    const int blk = nblk == 10 ? iq % 10 : (nblk == 20 ? iq % 20 : iq % 22);
+    const int blk = nblk == 10 ? iq % 10 : (nblk == 20 ? iq % 20 : iq % NBLK);
     glds16_s(src + blk * 1024, lane16, lds0 + RING_OFF + slot * TB_SLOT + blk * 1024);
   };
   {
@@ -205,7 +231,7 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
 #pragma unroll
     for (int i = 0; i < NPX; ++i) {
       if (st_in != nullptr) {
-        const float2 t = st_in[row0 + NPX * wm + i + (size_t)lrow * p.hw];
+        const float2 t = st_in[row0 + blk_pix(NPX * wm + i) + (size_t)blk_frame(NPX * wm + i, lrow) * p.hw];
         rs[i] = t.y;
         rm[i] = -t.x * t.y;
       } else {
@@ -245,7 +271,7 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
       // the V blocks need the scalars of frames 4 lq .. 4 lq + 3 (their accumulator rows): [pixel][frame] table in LDS.
       // Both waves of a pixel group write the same values; the first reader is five barriers away.
       if (lq == 0)
-        *reinterpret_cast<float2*>(smem + ST_OFF + ((NPX * wm + i) * TB_F + lrow) * 8) = make_float2(rs[i], rm[i]);
+        *reinterpret_cast<float2*>(smem + ST_OFF + ((NPX * wm + i) * 16 + lrow) * 8) = make_float2(rs[i], rm[i]);
     }
 
     // ======================================================================= phase 1: q, k, v and the attention, per head pair
@@ -267,9 +293,15 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
         const char* wb = smem + RING_OFF + slot * TB_SLOT + wn * 1024 + lane * 16;
         // bias + positional row of the block's 16 columns, travelling with the chunk: [frame][column] for the transposed
         // blocks, [column][frame] for the V blocks - either way this lane's four values sit at [lrow][4 lq .. + 3]
-        float4 tq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!TABL(4))
-          tq = *reinterpret_cast<const float4*>(smem + RING_OFF + slot * TB_SLOT + TB_WBYTES + wn * 1024 + (lrow * 16 + 4 * lq) * 4);
+        // (F = 24: one table per block half - the half = the wave's block index i)
+        float4 tqh[HB];
+#pragma unroll
+        for (int hh = 0; hh < HB; ++hh) {
+          tqh[hh] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!TABL(4))
+            tqh[hh] = *reinterpret_cast<const float4*>(smem + RING_OFF + slot * TB_SLOT + TB_WBYTES + (wn * HB + hh) * 1024 +
+                                                       (lrow * 16 + 4 * lq) * 4);
+        }
         const int cn = next2(c), sn = slot2();
         f32x4_t P[NPX];
 #pragma unroll
@@ -301,6 +333,7 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
           const float4 s4 = *reinterpret_cast<const float4*>(cs_tab + pc + 4 * lq);
 #pragma unroll
           for (int i = 0; i < NPX; ++i) {
+            const float4 tq = tqh[HB == 1 ? 0 : i];
             const float v0 = fmaf(rs[i], P[i][0], fmaf(rm[i], s4.x, tq.x));
             const float v1 = fmaf(rs[i], P[i][1], fmaf(rm[i], s4.y, tq.y));
             const float v2 = fmaf(rs[i], P[i][2], fmaf(rm[i], s4.z, tq.z));
@@ -318,8 +351,9 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
 #pragma unroll
           for (int i = 0; i < NPX; ++i) {
             // (rstd, -mean rstd) of frames 4 lq .. 4 lq + 3 of pixel NPX wm + i
-            const float4 a = *reinterpret_cast<const float4*>(smem + ST_OFF + ((NPX * wm + i) * TB_F + 4 * lq) * 8);
-            const float4 b = *reinterpret_cast<const float4*>(smem + ST_OFF + ((NPX * wm + i) * TB_F + 4 * lq + 2) * 8);
+            const float4 tq = tqh[HB == 1 ? 0 : i];
+            const float4 a = *reinterpret_cast<const float4*>(smem + ST_OFF + ((NPX * wm + i) * 16 + 4 * lq) * 8);
+            const float4 b = *reinterpret_cast<const float4*>(smem + ST_OFF + ((NPX * wm + i) * 16 + 4 * lq + 2) * 8);
             const float v0 = fmaf(a.x, P[i][0], fmaf(a.y, s1, tq.x));
             const float v1 = fmaf(a.z, P[i][1], fmaf(a.w, s1, tq.y));
             const float v2 = fmaf(b.x, P[i][2], fmaf(b.y, s1, tq.z));
@@ -340,7 +374,17 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
       chunk(std::integral_constant<int, 6>{});
       chunk(std::integral_constant<int, 7>{});
 
-      // ---- attention over the 16 frames of (pixel NPX wm + i, head): everything in this wave's registers
+      // ---- attention over the frames of (pixel, head): everything in this wave's registers.  Query block i against HB key
+      // blocks: F = 16: its own; F = 24: both blocks of the pixel (keys 16 + 4 lq + r >= 24 are padding: -inf)
+      // channels 32..39: the mixed block holds q in lanes 0-31 and k in lanes 32-63 -> (q | 0), (k | 0)
+      uint2 mq[NPX], mk[NPX];
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        auto m0 = __builtin_amdgcn_permlane32_swap(Mp[i].x, 0u, false, false);
+        auto m1 = __builtin_amdgcn_permlane32_swap(Mp[i].y, 0u, false, false);
+        mq[i] = make_uint2(m0[0], m1[0]);
+        mk[i] = make_uint2(m0[1], m1[1]);
+      }
 #pragma unroll
       for (int i = 0; i < NPX; ++i) {
         uint2 o01[2], o2;
@@ -349,41 +393,53 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
           o01[1] = Vp[i][1];
           o2 = Vp[i][2];
         } else {
-          // S^T[key frame 4 lq + r][query frame lrow] = sum_d K[key][d] Q[query][d]
-          const f32x4_t s_main = mfma16(make_uint4(Kp[i][0].x, Kp[i][0].y, Kp[i][1].x, Kp[i][1].y),
-                                        make_uint4(Qp[i][0].x, Qp[i][0].y, Qp[i][1].x, Qp[i][1].y),
-                                        f32x4_t{0.f, 0.f, 0.f, 0.f});
-          // channels 32..39: the mixed block holds q in lanes 0-31 and k in lanes 32-63 -> (q | 0), (k | 0)
-          auto m0 = __builtin_amdgcn_permlane32_swap(Mp[i].x, 0u, false, false);
-          auto m1 = __builtin_amdgcn_permlane32_swap(Mp[i].y, 0u, false, false);
-          // Its own accumulator, added on the VALU - NOT chained through the C operand: a v_mfma_f32_16x16x16_bf16 that
-          // takes the result of the v_mfma_f32_16x16x32_bf16 right in front of it as C read it too early on the hardware
-          // (hipcc 7.2 puts no wait states between that pair; measured: the 32-channel term of S went missing for whichever
-          // pixel had fewer than ~5 instructions between the two, run-to-run different for the late waves;
-          // profiles/r04m_tblock_probes.txt).  VALU reads of MFMA results are interlocked by the compiler as everywhere.
-          const f32x4_t s_mix = mfma16k(make_uint2(m0[1], m1[1]), make_uint2(m0[0], m1[0]), f32x4_t{0.f, 0.f, 0.f, 0.f});
-          f32x4_t sc;
+          f32x4_t sc[HB];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sc[r] = s_main[r] + s_mix[r];
-          float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+          for (int kbi = 0; kbi < HB; ++kbi) {
+            const int kb = HB == 1 ? i : kbi;
+            // S^T[key frame 16 kb + 4 lq + r][query row lrow] = sum_d K[key][d] Q[query][d]
+            const f32x4_t s_main = mfma16(make_uint4(Kp[kb][0].x, Kp[kb][0].y, Kp[kb][1].x, Kp[kb][1].y),
+                                          make_uint4(Qp[i][0].x, Qp[i][0].y, Qp[i][1].x, Qp[i][1].y),
+                                          f32x4_t{0.f, 0.f, 0.f, 0.f});
+            // Its own accumulator, added on the VALU - NOT chained through the C operand: a v_mfma_f32_16x16x16_bf16 that
+            // takes the result of the v_mfma_f32_16x16x32_bf16 right in front of it as C read it too early on the hardware
+            // (hipcc 7.2 puts no wait states between that pair; measured: the 32-channel term of S went missing for whichever
+            // pixel had fewer than ~5 instructions between the two, run-to-run different for the late waves;
+            // profiles/r04m_tblock_probes.txt).  VALU reads of MFMA results are interlocked by the compiler as everywhere.
+            const f32x4_t s_mix = mfma16k(mk[kb], mq[i], f32x4_t{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[kbi][r] = s_main[r] + s_mix[r];
+            if (HB == 2 && kbi == 1 && lq >= 2) {      // frames 24 .. 31 do not exist
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sc[kbi][r] = -INFINITY;
+            }
+          }
+          float mx = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
+          if (HB == 2) mx = fmaxf(mx, fmaxf(fmaxf(sc[HB - 1][0], sc[HB - 1][1]), fmaxf(sc[HB - 1][2], sc[HB - 1][3])));
           mx = wave_xor_max(mx, 16);
           mx = wave_xor_max(mx, 32);
           const float ms = mx * scale_log2e;
-          float pr[4], sum = 0.f;
+          float sum = 0.f;
+          uint2 pb[HB];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            pr[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], scale_log2e, -ms));
-            sum += pr[r];
+          for (int kbi = 0; kbi < HB; ++kbi) {
+            float pr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              pr[r] = __builtin_amdgcn_exp2f(fmaf(sc[kbi][r], scale_log2e, -ms));
+              sum += pr[r];
+            }
+            pb[kbi] = make_uint2(pack_bf16x2(pr[0], pr[1]), pack_bf16x2(pr[2], pr[3]));
           }
           sum = wave_xor_sum(sum, 16);
           sum = wave_xor_sum(sum, 32);
           const float inv_l = 1.0f / sum;
-          const uint2 pb = make_uint2(pack_bf16x2(pr[0], pr[1]), pack_bf16x2(pr[2], pr[3]));
-          // O^T[channel 4 lq + r of block vb][query frame lrow] = sum_key V[key][channel] P[query][key]
+          // O^T[channel 4 lq + r of block vb][query row lrow] = sum_key V[key][channel] P[query][key]
           uint2 o[3];
 #pragma unroll
           for (int vb = 0; vb < 3; ++vb) {
-            const f32x4_t a = mfma16k(Vp[i][vb], pb, f32x4_t{0.f, 0.f, 0.f, 0.f});
+            f32x4_t a = mfma16k(Vp[HB == 1 ? i : 0][vb], pb[0], f32x4_t{0.f, 0.f, 0.f, 0.f});
+            if (HB == 2) a = mfma16k(Vp[1][vb], pb[HB - 1], a);      // (same MFMA shape chained through C: fine)
             o[vb] = make_uint2(pack_bf16x2(a[0] * inv_l, a[1] * inv_l), pack_bf16x2(a[2] * inv_l, a[3] * inv_l));
           }
           o01[0] = o[0];
@@ -468,6 +524,17 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
     // JB column blocks: all residual loads of a batch first, then its arithmetic and stores (a load -> use -> store
     // chain per item would drain the store queue at every step: vmcnt counts stores too)
     bf16_t* __restrict__ out = (bf16_t*)p.x;
+    // row of (block s2_pix0 + i, lrow): F = 24: the padding rows of the second block half (frame >= 24) are read from the
+    // last frame and never stored
+    // (element offsets fit 32 bits: the tensor is < 4 G elements - checked by the launcher)
+    uint32_t erow[4];
+    bool estore[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = s2_pix0 + i;
+      erow[i] = (uint32_t)((row0 + blk_pix(b)) * p.ldx + (size_t)blk_frame(b, lrow) * frame_stride);
+      estore[i] = HB == 1 || 16 * (b & 1) + lrow < F;
+    }
     float so_s[4] = {0.f, 0.f, 0.f, 0.f}, so_q[4] = {0.f, 0.f, 0.f, 0.f};   // stats_out: this lane's share of row (pixel i, lrow)
     constexpr int JB = 3;       // column blocks per batch (rv = 4 JB uint2: the epilogue is the register peak of the kernel)
 #pragma unroll
@@ -478,8 +545,7 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (jb + j < SNJ)
-            rv[i][j] = *reinterpret_cast<const uint2*>(out + (row0 + s2_pix0 + i) * p.ldx + lrow * frame_stride + s2_col0 +
-                                                       16 * (jb + j) + 4 * lq);
+            rv[i][j] = *reinterpret_cast<const uint2*>(out + erow[i] + s2_col0 + 16 * (jb + j) + 4 * lq);
 #pragma unroll
       for (int j = 0; j < JB; ++j) {
         if (jb + j >= SNJ) continue;
@@ -493,7 +559,7 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
           const float v2 = Y[i][jb + j][2] + b4.z + __uint_as_float(r2.y << 16);
           const float v3 = Y[i][jb + j][3] + b4.w + __uint_as_float(r2.y & 0xffff0000u);
           const uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-          *reinterpret_cast<uint2*>(out + (row0 + s2_pix0 + i) * p.ldx + lrow * frame_stride + col) = pk;
+          if (estore[i]) *reinterpret_cast<uint2*>(out + erow[i] + col) = pk;
           if (p.stats_out != nullptr) {        // of the STORED values, as vx_row_stats would read them back
             const float r0 = __uint_as_float(pk.x << 16), r1 = __uint_as_float(pk.x & 0xffff0000u);
             const float r2_ = __uint_as_float(pk.y << 16), r3 = __uint_as_float(pk.y & 0xffff0000u);
@@ -516,11 +582,11 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
         float a = so_s[i], b = so_q[i];
         a = wave_xor_sum(a, 16); a = wave_xor_sum(a, 32);
         b = wave_xor_sum(b, 16); b = wave_xor_sum(b, 32);
-        if (lq == 0) scr[((s2_pix0 + i) * TB_F + lrow) * (NW / 2) + s2_cg] = make_float2(a, b);
+        if (lq == 0) scr[((s2_pix0 + i) * 16 + lrow) * (NW / 2) + s2_cg] = make_float2(a, b);
       }
       tb_barrier();
       if (lane < 16) {
-        const int rl = 16 * wave + lane;                 // row of the tile: pixel rl / 16, frame rl % 16 (NW == 8: 128 rows)
+        const int rl = 16 * wave + lane;                 // row of the tile: block rl / 16, row rl % 16 (NW == 8: 128 rows)
         float a = 0.f, b = 0.f;
 #pragma unroll
         for (int cgi = 0; cgi < NW / 2; ++cgi) {
@@ -530,7 +596,9 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
         }
         const float mean = a * (1.0f / TB_C);
         const float var = fmaxf(b * (1.0f / TB_C) - mean * mean, 0.f);
-        reinterpret_cast<float2*>(p.stats_out)[row0 + (rl >> 4) + (size_t)(rl & 15) * p.hw] = make_float2(mean, rsqrtf(var + p.ln_eps));
+        const int fr = HB == 1 ? (rl & 15) : 16 * ((rl >> 4) & 1) + (rl & 15);
+        if (fr < F)
+          reinterpret_cast<float2*>(p.stats_out)[row0 + blk_pix(rl >> 4) + (size_t)fr * p.hw] = make_float2(mean, rsqrtf(var + p.ln_eps));
       }
     }
   }
@@ -542,9 +610,11 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
 __global__ void tblock_pack_kernel(const bf16_t* __restrict__ wqkv, const float* __restrict__ bias,
                                    const float* __restrict__ colsum, const float* __restrict__ pe, int pe_ld,
                                    const bf16_t* __restrict__ wo, char* __restrict__ wqkv_t, bf16_t* __restrict__ wo_t,
-                                   float* __restrict__ colsum_p) {
+                                   float* __restrict__ colsum_p, int f) {
+  const int HB = f > 16 ? 2 : 1;                                 // table halves per head (TbGeo<F>::HB)
+  const int TB_SLOT = TB_WBYTES + 2 * HB * 1024;
   const int n_w = TB_QKV_CHUNKS * (TB_WBYTES / 16);              // 16-byte weight items of the QKV stream
-  const int n_t = TB_QKV_CHUNKS * 2 * 256;                       // table floats of the QKV stream
+  const int n_t = TB_QKV_CHUNKS * 2 * HB * 256;                  // table floats of the QKV stream
   const int n_o01 = 4 * 2 * 20 * 64, n_o2 = 4 * 20 * 64;         // 16-byte items of parts 0 / 1, 8-byte items of part 2
   const int total = n_w + n_t + n_o01 + n_o2 + TB_PCOLS;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -557,16 +627,16 @@ __global__ void tblock_pack_kernel(const bf16_t* __restrict__ wqkv, const float*
       if (col >= 0) v = *reinterpret_cast<const uint4*>(wqkv + (size_t)col * TB_C + 32 * ks + 8 * (lane >> 4));
       *reinterpret_cast<uint4*>(wqkv_t + (size_t)ch * TB_SLOT + (size_t)(idx - ch * (128 * TB_KS)) * 16) = v;
     } else if (idx < n_w + n_t) {
-      // behind the chunk's weights: [head of the pair][16][16] fp32 = bias + positional row, [frame][column] for the
-      // transposed blocks (0..4), [column][frame] for the V blocks
+      // behind the chunk's weights: [head of the pair][block half][16][16] fp32 = bias + positional row of frame 16 half +
+      // row, [row][column] for the transposed blocks (0..4), [column][row] for the V blocks; frames >= f (padding): 0
       const int k = idx - n_w;
-      const int e = k & 255, wn = (k >> 8) & 1, ch = k >> 9;
+      const int e = k & 255, hh = (k >> 8) % HB, wn = ((k >> 8) / HB) & 1, ch = k / (512 * HB);
       const int hp = ch >> 3, blk = ch & 7, head = 2 * hp + wn;
-      const int fr = blk < 5 ? e >> 4 : e & 15, r = blk < 5 ? e & 15 : e >> 4;
+      const int fr = 16 * hh + (blk < 5 ? e >> 4 : e & 15), r = blk < 5 ? e & 15 : e >> 4;
       const int col = tb_src_col(head, blk, r);
       float v = 0.f;
-      if (col >= 0) v = (bias != nullptr ? bias[col] : 0.f) + (pe != nullptr ? pe[(size_t)fr * pe_ld + col] : 0.f);
-      *reinterpret_cast<float*>(wqkv_t + (size_t)ch * TB_SLOT + TB_WBYTES + wn * 1024 + e * 4) = v;
+      if (col >= 0 && fr < f) v = (bias != nullptr ? bias[col] : 0.f) + (pe != nullptr ? pe[(size_t)fr * pe_ld + col] : 0.f);
+      *reinterpret_cast<float*>(wqkv_t + (size_t)ch * TB_SLOT + TB_WBYTES + (wn * HB + hh) * 1024 + e * 4) = v;
     } else if (idx < n_w + n_t + n_o01) {
       // [hp][part 0 / 1][column block j][lane][8]: out column 16 j + (lane & 15); k slots 8 lq .. + 7 =
       // channels 4 lq .. + 3 and 16 + 4 lq .. + 3 of head 2 hp + part
@@ -605,28 +675,25 @@ extern "C" int vx_tblock_pack(const void* wqkv, const float* bias, const float* 
                               void* stream_) {
   VX_REQUIRE(wqkv != nullptr && colsum != nullptr && wo != nullptr && wqkv_t != nullptr && wo_t != nullptr &&
                  colsum_p != nullptr, "vx_tblock_pack: null pointer");
-  VX_REQUIRE(c == TB_C && heads == TB_HEADS && f == TB_F,
-             "vx_tblock_pack: only C = %d, %d heads, %d frames (the 64x64 level) is built", TB_C, TB_HEADS, TB_F);
+  VX_REQUIRE(c == TB_C && heads == TB_HEADS && (f == 16 || f == 24),
+             "vx_tblock_pack: only C = %d, %d heads, 16 or 24 frames (the 64x64 level) is built", TB_C, TB_HEADS);
   VX_REQUIRE(pe_rows == nullptr || pe_ld >= 3 * TB_C, "vx_tblock_pack: pe_ld=%d", pe_ld);
   hipLaunchKernelGGL(tblock_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)wqkv, bias, colsum,
-                     pe_rows, pe_ld, (const bf16_t*)wo, (char*)wqkv_t, (bf16_t*)wo_t, colsum_p);
+                     pe_rows, pe_ld, (const bf16_t*)wo, (char*)wqkv_t, (bf16_t*)wo_t, colsum_p, f);
   return vx_check_launch("vx_tblock_pack");
 }
 
-extern "C" int vx_tblock_fused(const vx_tblock_params* pp, void* stream_) {
-  const vx_tblock_params& p = *pp;
-  VX_REQUIRE(p.x != nullptr && p.wqkv_t != nullptr && p.wo_t != nullptr && p.colsum_p != nullptr,
-             "vx_tblock_fused: null pointer");
-  VX_REQUIRE(p.c == TB_C && p.heads == TB_HEADS && p.f == TB_F,
-             "vx_tblock_fused: only C = %d, %d heads, %d frames (the 64x64 level) is built", TB_C, TB_HEADS, TB_F);
-  VX_REQUIRE(p.b > 0 && p.hw > 0 && (p.hw % TB_PIX) == 0, "vx_tblock_fused: hw=%d must be a multiple of %d", p.hw, TB_PIX);
-  VX_REQUIRE((p.ldx % 8) == 0 && p.ldx >= TB_C, "vx_tblock_fused: row stride");
+extern "C" int64_t vx_tblock_packed_bytes(int f) { return (int64_t)TB_QKV_CHUNKS * (TB_WBYTES + 2 * (f > 16 ? 2 : 1) * 1024); }
+
+template <int F>
+static int tblock_launch(const vx_tblock_params& p, hipStream_t stream) {
+  using G_ = TbGeo<F>;
   static bool attr_set = false;
   static int cus = 256;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)tblock_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)tblock_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);
     if (e != hipSuccess) {
-      vx_set_error("vx_tblock_fused: hipFuncSetAttribute(%d B LDS) failed: %s", TB_LDS, hipGetErrorString(e));
+      vx_set_error("vx_tblock_fused: hipFuncSetAttribute(%d B LDS) failed: %s", G_::LDS, hipGetErrorString(e));
       return VX_ERR_HIP;
     }
     int dev = 0, n = 0;
@@ -635,9 +702,22 @@ extern "C" int vx_tblock_fused(const vx_tblock_params* pp, void* stream_) {
       cus = n;
     attr_set = true;
   }
-  const int tiles = p.b * (p.hw / TB_PIX);
-  g_vx_last_kernel = "tblock_kernel";
-  hipLaunchKernelGGL(tblock_kernel, dim3(tiles < cus ? tiles : cus), dim3(64 * TB_NW), TB_LDS, (hipStream_t)stream_, p,
+  const int tiles = p.b * (p.hw / G_::PIX);
+  g_vx_last_kernel = F == 16 ? "tblock_kernel<16>" : "tblock_kernel<24>";
+  hipLaunchKernelGGL(tblock_kernel<F>, dim3(tiles < cus ? tiles : cus), dim3(64 * TB_NW), G_::LDS, stream, p,
                      p.scale * 1.4426950408889634f);
   return vx_check_launch("vx_tblock_fused");
+}
+
+extern "C" int vx_tblock_fused(const vx_tblock_params* pp, void* stream_) {
+  const vx_tblock_params& p = *pp;
+  VX_REQUIRE(p.x != nullptr && p.wqkv_t != nullptr && p.wo_t != nullptr && p.colsum_p != nullptr,
+             "vx_tblock_fused: null pointer");
+  VX_REQUIRE(p.c == TB_C && p.heads == TB_HEADS && (p.f == 16 || p.f == 24),
+             "vx_tblock_fused: only C = %d, %d heads, 16 or 24 frames (the 64x64 level) is built", TB_C, TB_HEADS);
+  const int pix = p.f == 16 ? TbGeo<16>::PIX : TbGeo<24>::PIX;
+  VX_REQUIRE(p.b > 0 && p.hw > 0 && (p.hw % pix) == 0, "vx_tblock_fused: hw=%d must be a multiple of %d", p.hw, pix);
+  VX_REQUIRE((p.ldx % 8) == 0 && p.ldx >= TB_C, "vx_tblock_fused: row stride");
+  VX_REQUIRE((unsigned long long)p.b * p.f * p.hw * p.ldx < (1ull << 32), "vx_tblock_fused: more than 4 G elements");
+  return p.f == 16 ? tblock_launch<16>(p, (hipStream_t)stream_) : tblock_launch<24>(p, (hipStream_t)stream_);
 }

@@ -137,6 +137,8 @@ def _load():
     lib.vx_conv3x3_gn_supported.argtypes = [C.POINTER(Conv3Params)]
     lib.vx_groupnorm_scale_shift.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, vp]
     lib.vx_tblock_pack.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.vx_tblock_packed_bytes.argtypes = [i32]
+    lib.vx_tblock_packed_bytes.restype = i64
     lib.vx_groupnorm_fold_linear.argtypes = [vp, i32, i32, i32, i32, f32, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.vx_layernorm.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp]
     lib.vx_row_stats.argtypes = [vp, i32, i32, i32, f32, vp, vp]
@@ -164,7 +166,8 @@ def _load():
     for name in declared_symbols():
         fn = getattr(lib, name)
         if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name",
-                        "vx_gemm_splitk_ws_bytes", "vx_gemm_last_kernel", "vx_last_kernel", "vx_build_id"):
+                        "vx_gemm_splitk_ws_bytes", "vx_gemm_last_kernel", "vx_last_kernel", "vx_build_id",
+                        "vx_tblock_packed_bytes"):
             fn.restype = i32
     if lib.vx_abi_version() != 12:
         raise ImportError("libvexpress_hip.so ABI version mismatch")

@@ -719,11 +719,12 @@ def ff_fused(h, w1_folded, b1, colsum, stats, w2, b2):
 
 
 # Temporal self-attention block of the 64x64 level in ONE launch (csrc/vx_tblock.hip): LayerNorm-folded QKV projection,
-# attention over the 16 frames, out-projection and residual; VX_TB_FUSED=0 restores the three launches (A/B knob).
+# attention over the window's frames (16, or - round 5 - the reference's default 24), out-projection and residual;
+# VX_TB_FUSED=0 restores the three launches (A/B knob).
 TB_FUSED = [os.environ.get("VX_TB_FUSED", "1") != "0"]
 # window lengths the one-launch kernel is built for -> pixels per tile (a tile = TB_PIX[f] pixels x their f frames)
-TB_FRAMES = (16,)
-TB_PIX = {16: 8}
+TB_FRAMES = (16, 24)
+TB_PIX = {16: 8, 24: 4}
 _TB_PACKED = {}
 
 
@@ -740,7 +741,7 @@ def tblock_fused_applies(c, heads, f, hw):
 
 def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, heads, stats=None, stats_out=None, eps=1e-5):
     """h += to_out(attention over f of (LN(h) + pe) Wqkv^T + b), in place on h [(b f) hw, C] (a tile of the kernel is 8
-    pixels x their 16 frames: rows of other pixels are independent).  stats: (mean, rstd) per row, or None - the kernel
+    pixels x their 16 frames, or 4 pixels x 24 frames: rows of other pixels are independent).  stats: (mean, rstd) per row, or None - the kernel
     then takes them from the rows it holds.  stats_out: float32 [rows, 2] that receives (mean, rstd) of the rows written
     (for the next LayerNorm fold; may be the same tensor as stats).  Weights and tables are re-tiled once per layer
     (vx_tblock_pack)."""
@@ -752,11 +753,11 @@ def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, hea
     for t_ in (stats, stats_out):
         if t_ is not None and (t_.dtype != torch.float32 or not t_.is_contiguous() or tuple(t_.shape) != (m, 2)):
             raise ValueError("tblock_fused: statistics must be contiguous float32 [rows, 2] (mean, rstd) tensors")
-    key = (wqkv_folded.data_ptr(), wo.data_ptr(), pe_rows.data_ptr() if pe_rows is not None else 0)
+    key = (wqkv_folded.data_ptr(), wo.data_ptr(), pe_rows.data_ptr() if pe_rows is not None else 0, f)
     hit = _TB_PACKED.get(key)
     if hit is None:
         dev = h.device
-        wqkv_t = torch.empty(720896 // 2, device=dev, dtype=BF16)
+        wqkv_t = torch.empty(int(_lib.vx_tblock_packed_bytes(f)) // 2, device=dev, dtype=BF16)
         wo_t = torch.empty(204800 // 2, device=dev, dtype=BF16)
         cs = torch.empty(1024, device=dev, dtype=torch.float32)
         L.check(_lib.vx_tblock_pack(_ptr(wqkv_folded), _ptr(bqkv) if bqkv is not None else None, _ptr(colsum),
