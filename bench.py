@@ -107,6 +107,8 @@ def _rocprof_launch_avg(symbol):
         if not lines or f"lib_sha256={sha}" not in lines[0]:
             continue
         for ln in lines:
+            if ln.startswith("#"):                        # header / gap-attribution comments of tools/trace_summary.py
+                continue
             m = re.search(r"n=\s*(\d+)\s+avg=\s*([0-9.]+) us\s+(?:void )?(.*)$", ln)     # (non-template kernels: no "void")
             if m and m.group(3).startswith(symbol + "("):
                 return dict(avg_launch_us=float(m.group(2)), launches=int(m.group(1)), file=os.path.relpath(path, ROOT))

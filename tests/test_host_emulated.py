@@ -426,3 +426,34 @@ def test_checkpoint_files_load_into_identical_models_unets(emulated, tmp_path, l
 def test_checkpoint_files_load_into_identical_models_vae_guider_projection(emulated, tmp_path):
     import ckpt_cases
     ckpt_cases.vae_guider_and_audio_projection_from_files(tmp_path, "cpu")
+
+
+def test_one_rank_group_forced_through_the_collective_path_equals_the_sequential_loop(emulated):
+    """`DistContext(force=True)` on a ONE-rank group: the per-timestep all-gather, the broadcast and a sub-group all-to-all
+    run as real collectives (what tools/rccl_world1_probe.py does on the one GPU that exists, over RCCL) and must change
+    nothing."""
+    import torch.distributed as dist
+    from v_express_amd.distributed import CommTimer, DistContext, FrameShard
+    F, cf, co = 14, 8, 2
+    ref = W.run(F, cf, co, 2, 0, device="cpu")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        dc = DistContext(0, 1, None, force=True)
+        assert dc.enabled and dc.backend == "gloo" and not DistContext().enabled
+        t = torch.randn(3, 5)
+        assert torch.equal(dc.broadcast(t.clone()), t) and torch.equal(dc.all_gather_units(t, 3)[0], t)
+        fs = FrameShard(0, 1, dist.new_group([0]))
+        x = torch.randn(2 * 4, 16, 8).to(torch.bfloat16)
+        assert torch.equal(fs.to_frame_shard(fs.to_pixel_shard(x, 2, 4), 2, 4), x)
+        pipe = W.build_pipeline("cpu")
+        pipe.dist = dc
+        with CommTimer() as tm:
+            lat = W._run(pipe, pipe.denoising_unet, pipe.reference_net, pipe.scheduler, cases.unet_cfg(cases.SMALL),
+                         F, cf, co, 2, 0, 16, "cpu")
+        assert pipe.last_schedule["kind"] == "whole units" and tm.summary()["all_gather"]["calls"] == 2
+        assert torch.equal(lat, ref)
+    finally:
+        dist.destroy_process_group()

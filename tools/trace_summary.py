@@ -14,9 +14,9 @@ with open(sys.argv[1]) as f:
     for row in r:
         name = row.get("Kernel_Name") or row.get("kernel_name")
         s, e = int(row["Start_Timestamp"]), int(row["End_Timestamp"])
-        spans.append((s, e))
         name = re.sub(r"\(anonymous namespace\)::", "", name)
         name = name[:110]
+        spans.append((s, e, name))
         rows[name][0] += 1
         rows[name][1] += (e - s) * 1e-3
 if len(sys.argv) > 2:
@@ -30,9 +30,23 @@ for k, v in sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]:
 # Gaps above 50 us are host stalls (model build, synchronisation points), not launch latency: listed apart.
 spans.sort()
 gaps = [spans[i + 1][0] - spans[i][1] for i in range(len(spans) - 1)]
+short = lambda n: re.sub(r"\(.*", "", re.sub(r"^void ", "", n))[:60]
 small = sorted(g * 1e-3 for g in gaps if 0 <= g < 50_000)
 big = [g * 1e-3 for g in gaps if g >= 50_000]
 if small:
     print(f"# inter-kernel gaps < 50 us: n={len(small)} total {sum(small) / 1e3:.1f} ms ({100 * sum(small) / 1e3 / (tot / 1e3):.1f} % of kernel time), "
           f"median {small[len(small) // 2]:.2f} us, p90 {small[int(0.9 * len(small))]:.2f} us; gaps >= 50 us: n={len(big)} total {sum(big) / 1e3:.1f} ms; "
           f"overlapping launches: {sum(1 for g in gaps if g < 0)}")
+    # where the idle time sits: gaps below 50 us by the kernel that FOLLOWS the gap (its dispatch waited) and by (before -> after)
+    after, pair = defaultdict(lambda: [0, 0.0]), defaultdict(lambda: [0, 0.0])
+    for i, g in enumerate(gaps):
+        if 0 <= g < 50_000:
+            for d, k in ((after, short(spans[i + 1][2])), (pair, short(spans[i][2]) + " -> " + short(spans[i + 1][2]))):
+                d[k][0] += 1
+                d[k][1] += g * 1e-3
+    print("# idle time by the kernel after the gap (top 12):")
+    for k, v in sorted(after.items(), key=lambda kv: -kv[1][1])[:12]:
+        print(f"#   {v[1] / 1e3:8.2f} ms n={v[0]:6d} avg={v[1] / v[0]:6.2f} us  {k}")
+    print("# idle time by (kernel before -> kernel after) (top 12):")
+    for k, v in sorted(pair.items(), key=lambda kv: -kv[1][1])[:12]:
+        print(f"#   {v[1] / 1e3:8.2f} ms n={v[0]:6d} avg={v[1] / v[0]:6.2f} us  {k}")

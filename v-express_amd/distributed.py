@@ -230,10 +230,11 @@ class DistContext:
     rank: int = 0
     world_size: int = 1
     group: Optional[object] = None
+    force: bool = False       # tools/rccl_world1_probe.py: run the collective code path on a one-rank group as well
 
     @property
     def enabled(self):
-        return self.world_size > 1
+        return self.world_size > 1 or self.force
 
     @property
     def backend(self):
