@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 12
+#define VX_ABI_VERSION 13
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
@@ -83,7 +83,16 @@ typedef struct {
   /* Kernel-selection hint for the persistent ring-staged kernel (its conv K order differs from the classic tiles', so
    * callers that need bit-identical results for any sub-batch must make the choice from batch-independent facts):
    * 0 = automatic (ring when eligible and the launch has >= 192 tiles), 1 = ring whenever structurally eligible,
-   * -1 = never. */
+   * -1 = never.
+   * 2 (round 5, ABI 13) = the persistent kernel with a COOPERATIVE two-way K split, for launches with fewer 256 x 320
+   * tiles than CUs (the 16x16 level: 8192 x 1280 = 128 tiles): set splitk = 2 and splitk_ws = a workspace of
+   * vx_gemm_splitk_ws_bytes(m, n, 2) bytes that the caller ZEROED once (the kernel keeps its flag words zero between
+   * launches; launches that share a workspace must be stream-ordered).  Each (tile, K half) is one work item; the two
+   * halves meet inside the launch (the first to finish parks its fp32 accumulators in the workspace, the second adds
+   * them and runs the epilogue: one launch, a fixed summation order, no reduce pass).  STORE epilogue (bias, row bias,
+   * SiLU, residual, GroupNorm partial sums), bf16 operands, (c1 + c2) / 64 even.  Ask vx_gemm_ring_coop_ok() - a function
+   * of the problem's shape only; callers that need batch-invariant bits must ALSO make the choice itself from per-item
+   * facts.  VX_ERR_UNSUPPORTED if the launch cannot run this way. */
   int32_t ring_hint;
   /* FP8 operands (BASELINE.json configs[4]: "fp8 MFMA QKV/out-proj"): a_fp8 = 1 -> a and w hold OCP e4m3 bytes
    * (v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, fp32 accumulation), row-scaled: the true operands are
@@ -155,6 +164,9 @@ int vx_gemm(const vx_gemm_params* p, void* stream);
  * cannot produce GroupNorm partial sums (the caller then leaves gn_ws NULL and runs vx_groupnorm as before) */
 int vx_gemm_gn_slabs(const vx_gemm_params* p);
 int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk);
+/* 1 if vx_gemm(p) could run with ring_hint = 2 (cooperative two-way K split on the persistent kernel; p's own ring_hint /
+ * splitk / splitk_ws are ignored), else 0 */
+int vx_gemm_ring_coop_ok(const vx_gemm_params* p);
 /* Kernel-selection knob (process-wide; default 2, or the VX_GEMM_RING environment variable): 0 = never use the
  * persistent ring-staged 256x320 kernel, 1 = only for K <= 1280, 2 = for every eligible problem.  Results differ only by
  * fp32 summation order (the ring kernel walks conv taps innermost).  For A/B measurements and cross-checking tests. */

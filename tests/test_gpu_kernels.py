@@ -934,6 +934,116 @@ def test_gemm_gn_partial_sums_downsample_conv_and_refusals(ops):
         L.check(ops._lib.vx_gemm(p, ops._stream()), "vx_gemm")
 
 
+# ------------------------------------------------------------------------------------------ cooperative two-way K split (ring_hint = 2)
+def _coop_used(prof):
+    return len(prof.records) > 0 and all(r[3].startswith("gemm_ring_kernel<") and r[3].endswith(",coop2>") for r in prof.records)
+
+
+@pytest.mark.parametrize("frames,n,k,res", [(32, 1280, 5120, True), (32, 1280, 2560, False), (16, 1280, 5120, True),
+                                            (64, 1280, 2560, True), (32, 1280, 2688, False)])
+def test_gemm_ring_coop_split_linear(ops, monkeypatch, frames, n, k, res):
+    """the 16x16-level launches (256 rows per frame, 128 tiles of 256 x 320 for a CFG pair) on the
+    persistent kernel with the two K halves of a tile on two CUs that meet inside the launch (vx_gemm_params.ring_hint = 2;
+    FF out-projection modules/attention FeedForward via mutual_self_attention.py:247, K = 5120).  Against fp32 math, against
+    the 128 x 160 tiles (other summation order: bf16 ulps), half the batch / twice the batch = the same bits, and launch
+    after launch on the same workspace (the flag words clean themselves)."""
+    hw, m = 256, frames * 256
+    monkeypatch.setattr(ops, "COOP_MIN_K", [2560])   # (the model's policy takes the split from K = 8192: the long 3x3 convs)
+    a, w = rnd(m, k), rnd(n, k, scale=k ** -0.5, seed=1)
+    bias = rnd(n, seed=2, dtype=torch.float32) + 0.3
+    r = rnd(m, n, seed=3) if res else None
+    items = frames // 16
+    with ops.frame_rows(hw, items=items), ops.GemmProfile() as prof:
+        out = ops.gemm(a, w, bias, residual=r, alpha=0.8)
+    if (k // 64) % 2:                                # an odd number of 64-channel chunks cannot be halved: classic tiles
+        assert not _coop_used(prof) and "gemm_ring" not in prof.records[0][3], prof.records[0][3]
+        return
+    assert _coop_used(prof), prof.records[0][3]
+    ref = (a.float() @ w.float().t() + bias) * 0.8 + (r.float() if res else 0.0)
+    check(out, ref, f"cooperative split {m}x{n}x{k}")
+    with ops.frame_rows(hw, items=items):
+        for _ in range(3):                           # same workspace, same bits
+            assert torch.equal(ops.gemm(a, w, bias, residual=r, alpha=0.8), out)
+        monkeypatch.setattr(ops, "RING_COOP", [False])
+        with ops.GemmProfile() as prof2:
+            classic = ops.gemm(a, w, bias, residual=r, alpha=0.8)
+        monkeypatch.setattr(ops, "RING_COOP", [True])
+    assert not _coop_used(prof2)
+    d = (out.float() - classic.float()).abs()
+    assert d.max().item() <= 2 ** -6 * ref.abs().max().item() and (d > 0).float().mean().item() < 0.2
+    if items >= 2:                                   # one item alone: same kernel, same halves, same bits
+        h = m // items
+        with ops.frame_rows(hw, items=1), ops.GemmProfile() as prof3:
+            one = ops.gemm(a[h:2 * h], w, bias, residual=None if r is None else r[h:2 * h], alpha=0.8)
+        assert _coop_used(prof3) and torch.equal(one, out[h:2 * h])
+
+
+@pytest.mark.parametrize("c1,c2,rowb,res", [(1280, 0, True, False), (1280, 1280, False, True), (640, 0, False, False)])
+def test_gemm_ring_coop_split_conv(ops, monkeypatch, c1, c2, rowb, res):
+    """The 16x16-level 3x3 convolutions of ResnetBlock3D (modules/resnet.py:223, 244; the up blocks' concatenated skip as a
+    second source, modules/unet_3d_blocks.py:694) through the cooperative split: the halves are whole channel chunks, each
+    walked taps-innermost; GroupNorm partial sums from the epilogue of whichever half arrives second."""
+    nb, hh, ww, cout = 32, 16, 16, 1280
+    cin = c1 + c2
+    monkeypatch.setattr(ops, "COOP_MIN_K", [2560])
+    x1 = torch.zeros(nb, hh + 2, ww + 2, c1, device="cuda", dtype=BF)
+    x1[:, 1:-1, 1:-1] = rnd(nb, hh, ww, c1)
+    x2 = None
+    if c2:
+        x2 = torch.zeros(nb, hh + 2, ww + 2, c2, device="cuda", dtype=BF)
+        x2[:, 1:-1, 1:-1] = rnd(nb, hh, ww, c2, seed=7)
+    wt = rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=1)
+    bias = rnd(cout, seed=2, dtype=torch.float32)
+    w2d = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    g = ops.ConvGeom(nb, hh + 2, ww + 2, 3, 3, 1, 0)
+    rows = hh * ww * 16
+    rowbias = rnd(2, cout, seed=5, dtype=torch.float32) if rowb else None
+    r = rnd(nb * hh * ww, cout, seed=6) if res else None
+    with ops.frame_rows(hh * ww, items=2), ops.GemmProfile() as prof:
+        out = ops.gemm(x1.view(-1, c1), w2d, bias, geom=g, a2=None if x2 is None else x2.view(-1, c2), rowbias=rowbias,
+                       rows_per_group=rows if rowb else 0, residual=r, gn=(32, hh * ww))
+        again = ops.gemm(x1.view(-1, c1), w2d, bias, geom=g, a2=None if x2 is None else x2.view(-1, c2), rowbias=rowbias,
+                         rows_per_group=rows if rowb else 0, residual=r, gn=(32, hh * ww))
+    assert _coop_used(prof), prof.records[0][3]
+    x = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+    ref = _conv_ref(x, wt, bias, 1, 0, 0).reshape(nb * hh * ww, cout)
+    if rowb:
+        ref = ref + rowbias.repeat_interleave(rows, 0)
+    if res:
+        ref = ref + r.float()
+    check(out, ref, f"cooperative split conv {c1}+{c2}")
+    assert torch.equal(out, again) and torch.equal(ops.gn_of(out).ws, ops.gn_of(again).ws)
+    st = _gn_check(ops, out, nb, hh * ww, 32, "cooperative split conv")
+    assert st.slabs == 2
+    with ops.frame_rows(hh * ww, items=1):      # the conditional half alone
+        one = ops.gemm(x1[16:].reshape(-1, c1), w2d, bias, geom=ops.ConvGeom(16, hh + 2, ww + 2, 3, 3, 1, 0),
+                       a2=None if x2 is None else x2[16:].reshape(-1, c2),
+                       rowbias=None if rowbias is None else rowbias[1:], rows_per_group=rows if rowb else 0,
+                       residual=None if r is None else r[16 * hh * ww:], gn=(32, hh * ww))
+    assert torch.equal(one, out[16 * hh * ww:]) and torch.equal(ops.gn_of(one).ws, st.ws[16:])
+
+
+def test_gemm_ring_coop_split_refusals(ops):
+    """The library answers for its own limits (vx_gemm_ring_coop_ok) and a forced request that cannot run is an error."""
+    from v_express_amd import lib as L
+    a, w = rnd(8192, 2560), rnd(1280, 2560, scale=0.02, seed=1)
+    o = torch.empty((8192, 1280), device="cuda", dtype=BF)
+    p, _ = ops._base_params(a, w, None)
+    p.epi, p.out, p.ldc, p.alpha = L.VX_EPI_STORE, o.data_ptr(), 1280, 1.0
+    assert ops._lib.vx_gemm_ring_coop_ok(p) == 1
+    p2, _ = ops._base_params(a[:, :2496].contiguous(), w[:, :2496].contiguous(), None)      # 39 chunks
+    p2.epi, p2.out, p2.ldc, p2.alpha = L.VX_EPI_STORE, o.data_ptr(), 1280, 1.0
+    assert ops._lib.vx_gemm_ring_coop_ok(p2) == 0
+    p2.ring_hint, p2.splitk = 2, 2
+    ws = torch.zeros(int(ops._lib.vx_gemm_splitk_ws_bytes(8192, 1280, 2)), device="cuda", dtype=torch.uint8)
+    p2.splitk_ws = ws.data_ptr()
+    with pytest.raises(L.VxError):
+        L.check(ops._lib.vx_gemm(p2, ops._stream()), "vx_gemm")
+    p.ring_hint, p.splitk = 2, 2                       # no workspace
+    with pytest.raises(L.VxError):
+        L.check(ops._lib.vx_gemm(p, ops._stream()), "vx_gemm")
+
+
 # ------------------------------------------------------------------------------------------ conv3x3 with GroupNorm + SiLU in its A path
 def _conv3_case(ops, frames, H, W, c1, c2, n, res, rowb, seed=0):
     hw = H * W

@@ -20,7 +20,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for n in names:
         assert hasattr(so, n), n
-    assert lib.lib.vx_abi_version() == 12
+    assert lib.lib.vx_abi_version() == 13
     # the binary says which sources it was compiled from (stamped by csrc/Makefile) and lib.py has compared that with the
     # sources on disk at import: a stale .so does not get this far
     src, _, defs = lib.lib.vx_build_id().decode().partition("|")
@@ -674,3 +674,42 @@ def test_resnet_block_conv3_path_composes_like_the_two_launch_path(monkeypatch):
         assert len(path) == 2 and all(("vx_conv3x3_gn" in v) == on for v in path), path
         assert ops.gn_of(o) is not None and ops.gn_of(o).fits(frames, hw, groups, cout)
     assert torch.equal(outs[True], outs[False])
+
+
+def test_ring_coop_split_policy_is_a_function_of_per_item_facts():
+    """ops.ring_coop_applies (the cooperative two-way K split of the persistent kernel, vx_gemm_params.ring_hint = 2): the
+    16x16-level long-K launches take it whatever the number of CFG halves / windows in the call; shorter K, other levels,
+    an odd number of 64-channel chunks, a folded LayerNorm or fp32 output do not.  Host code only (the library's
+    eligibility function needs no GPU)."""
+    import ctypes as C
+    from v_express_amd import lib as L, ops
+
+    def params(m, n, k, **kw):
+        p = L.GemmParams()
+        p.m, p.n, p.k, p.c1, p.c2, p.kh, p.kw, p.stride = m, n, k, k, 0, 1, 1, 1
+        p.nb, p.h_in, p.w_in, p.h_out, p.w_out = m // 256, 16, 16, 16, 16
+        p.lda1, p.ldc, p.epi, p.alpha = k, n, L.VX_EPI_STORE, 1.0
+        p.a = p.w = p.out = C.c_void_p(256)            # (never dereferenced by the eligibility functions)
+        for key, v in kw.items():
+            setattr(p, key, v)
+        return p
+
+    assert L.lib.vx_gemm_ring_coop_ok(C.byref(params(8192, 1280, 11520))) == 1
+    assert L.lib.vx_gemm_ring_coop_ok(C.byref(params(8192, 1280, 64 * 45))) == 0          # odd chunk count
+    assert L.lib.vx_gemm_ring_coop_ok(C.byref(params(8192, 1280, 11520, out_f32=1))) == 0
+    assert L.lib.vx_gemm_ring_coop_ok(C.byref(params(8192, 1280, 11520, epi=L.VX_EPI_GEGLU))) == 0
+    assert L.lib.vx_gemm_ring_coop_ok(C.byref(params(8192, 1200, 11520))) == 0            # n % 320
+    for items in (1, 2, 4, 6):
+        with ops.frame_rows(256, items=items):
+            assert ops.ring_coop_applies(params(items * 4096, 1280, 11520))
+            assert ops.ring_coop_applies(params(items * 4096, 1280, 23040))
+            assert not ops.ring_coop_applies(params(items * 4096, 1280, 5120))         # below COOP_MIN_K
+            assert not ops.ring_coop_applies(params(items * 4096, 2560, 11520))        # 256 tiles per pair: plain ring
+            assert not ops.ring_coop_applies(params(items * 1024, 1280, 11520))        # the 8x8 level (classic split-K)
+    assert not ops.ring_coop_applies(params(8192, 1280, 11520))                        # no frame_rows context: no per-item facts
+    with ops.frame_rows(256, items=2):
+        ops.RING_COOP[0] = False
+        try:
+            assert not ops.ring_coop_applies(params(8192, 1280, 11520))
+        finally:
+            ops.RING_COOP[0] = True

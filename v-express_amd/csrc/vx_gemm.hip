@@ -831,10 +831,11 @@ int store_tile(const vx_gemm_params& p, bool gn = false) {
 extern "C" int vx_gemm_gn_slabs(const vx_gemm_params* pp) {
   const vx_gemm_params& p = *pp;
   if (p.epi != VX_EPI_STORE || p.a_fp8 || p.out_f32 || p.ln_stats != nullptr || p.row_stats_out != nullptr ||
-      p.splitk > 1 || p.w_group_rows != 0)
+      (p.splitk > 1 && p.ring_hint != 2) || p.w_group_rows != 0)
     return 0;
   if (p.gn_groups <= 0 || p.gn_hw <= 0 || p.n <= 0 || (p.n % p.gn_groups) != 0 || (p.m % p.gn_hw) != 0) return 0;
   if (vx_gemm_ring_eligible(p)) return vx_gemm_ring_gn_slabs(p);
+  if (p.splitk > 1) return 0;
   const int cg = p.n / p.gn_groups;
   const int tile = store_tile(p, true);
   if (tile != T_SMALL64 && tile != T_128x160) return 0;
@@ -853,6 +854,16 @@ thread_local const char* g_vx_last_kernel = "";
 extern "C" const char* vx_gemm_last_kernel(void) { return g_vx_last_kernel; }
 extern "C" const char* vx_last_kernel(void) { return g_vx_last_kernel; }
 
+// whether the launch described by *pp could run as the persistent kernel's cooperative two-way K split (ring_hint = 2,
+// splitk = 2, splitk_ws = zeroed vx_gemm_splitk_ws_bytes(m, n, 2) bytes): pp's own ring_hint / splitk / splitk_ws are ignored
+extern "C" int vx_gemm_ring_coop_ok(const vx_gemm_params* pp) {
+  vx_gemm_params q = *pp;
+  q.ring_hint = 2;
+  q.splitk = 2;
+  if (q.splitk_ws == nullptr) q.splitk_ws = (void*)16;   // (only tested for null)
+  return vx_gemm_ring_eligible(q) ? 1 : 0;
+}
+
 extern "C" int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk) {
   return splitk > 1 ? (int64_t)splitk * m * n * (int64_t)sizeof(float) : 0;
 }
@@ -870,7 +881,9 @@ extern "C" const char* vx_gemm_config_name(const vx_gemm_params* pp) {
     return b8;
   }
   if (vx_gemm_ring_eligible(p))
-    return p.epi == VX_EPI_GEGLU ? "gemm_ring_kernel<256x320x64,8w,GEGLU,fast>" : "gemm_ring_kernel<256x320x64,8w,STORE,fast>";
+    return p.epi == VX_EPI_GEGLU ? "gemm_ring_kernel<256x320x64,8w,GEGLU,fast>"
+                                 : (p.ring_hint == 2 ? "gemm_ring_kernel<256x320x64,8w,STORE,fast,coop2>"
+                                                     : "gemm_ring_kernel<256x320x64,8w,STORE,fast>");
   if (p.epi == VX_EPI_STORE && p.n <= 32) tile = "256x32x64,4w";
   else if (use_big(p)) tile = "256x320x64,8w";
   else if (p.epi == VX_EPI_STORE && use_small64(p)) tile = "64x160x64,2w";
@@ -965,6 +978,12 @@ static int vx_gemm_dispatch(const vx_gemm_params& p, hipStream_t stream) {
     VX_REQUIRE(p.residual == nullptr || (p.ldr % 8) == 0, "vx_gemm: ldr%%8");
     VX_REQUIRE(p.rowbias == nullptr || p.rows_per_group > 0, "vx_gemm: rows_per_group");
     if (vx_gemm_ring_eligible(p)) return vx_gemm_ring_launch(p, stream);
+    if (p.ring_hint == 2) {
+      vx_set_error("vx_gemm: ring_hint = 2 (cooperative two-way K split on the persistent kernel) needs splitk == 2, a zeroed "
+                   "workspace, m %% 256 == 0, n %% 320 == 0, an even number of 64-channel chunks and the plain STORE epilogue "
+                   "(m=%d n=%d k=%d splitk=%d): ask vx_gemm_ring_coop_ok() first", p.m, p.n, p.k, p.splitk);
+      return VX_ERR_UNSUPPORTED;
+    }
     if (p.w_group_rows != 0) {
       vx_set_error("vx_gemm: per-row-group weights (w_group_rows=%d) need a launch the persistent 256 x 320 kernel "
                    "accepts (m %% 256, n %% 320, w_group_rows %% 256, plain addressing)", p.w_group_rows);

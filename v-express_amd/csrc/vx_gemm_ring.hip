@@ -160,8 +160,40 @@ __device__ __forceinline__ f32x4_t ring_mfma_f8(const uint4& a_lo, const uint4& 
 // GNS (round 4; STORE): the epilogue also writes the GroupNorm partial sums of the STORED bf16 values to p.gn_ws in the
 // workspace layout of vx_groupnorm ([frame][slab][group] (sum, sum of squares); one slab = the 128 rows of a wave row),
 // so the statistics pass of the GroupNorm that reads this tensor next never runs (vx_gemm_params.gn_ws).
-template <int EPI, bool RES, bool F8 = false, bool STATS = false, bool LNF = false, bool GNS = false>
+// exchange of the cooperative split (SK): explicit cache scopes instead of agent-scope fences.  A release fence at agent
+// scope is a write-back of the XCD's whole L2 (buffer_wbl2) and an acquire an invalidate (buffer_inv) - 1024 of each per
+// launch cost more than the split saves.  Instead: the parked accumulators are stored WRITE-THROUGH (sc0 sc1: the line is
+// updated in this XCD's L2 and in memory; buffer instructions, so that the compiler sees them and counts its own waits), the
+// flag is stored / polled at agent scope (sc1), and the reader loads with sc1 (misses its CU's L1).  Partner work items are adjacent walk positions, i.e. run on the same XCD on every part seen so far;
+// the flag carries the writer's XCC id, and only a reader on ANOTHER XCD pays the L2 invalidate.
+typedef int sk_i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sk_store16(__amdgpu_buffer_rsrc_t ws, uint32_t voff, uint32_t soff, const f32x4_t& v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sk_i32x4_t, v), ws, voff, soff, 17);   // sc0 sc1
+}
+__device__ __forceinline__ f32x4_t sk_load16(__amdgpu_buffer_rsrc_t ws, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ws, voff, soff, 16));    // sc1
+}
+__device__ __forceinline__ uint32_t sk_xcc_id() {
+  uint32_t x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+  return x;
+}
+
+// SK (round 5; STORE, bf16 operands, no LayerNorm fold / row statistics): cooperative two-way K split for launches with
+// fewer 256 x 320 tiles than CUs (the 16x16 level: 8192 x 1280 = 128 tiles).  A work item = (tile, K half): items 2t and
+// 2t + 1 sit next to each other in the walk, i.e. on the same XCD in the same round.  Per WAVE (the STORE / GNS epilogues
+// are wave-local): lane 0 counts the wave's arrival at flag word [t][wave][0]; the FIRST of the two partner waves writes its
+// 160 accumulators per lane to splitk_ws (40 KB per wave, lane-linear float4), releases flag word [1] and goes on to its
+// next item - it never waits, so no co-residency of the two blocks is assumed; the SECOND waits for [1] (its partner is by
+// construction already past its K loop), adds the partner's accumulators to its own (a + b: the same bits whichever half
+// arrives first), zeroes both words for the next launch and runs the normal epilogue.  The K halves are whole channel
+// chunks ((c1 + c2) / 64 even), each walked taps-innermost like the unsplit loop.
+template <int EPI, bool RES, bool F8 = false, bool STATS = false, bool LNF = false, bool GNS = false, bool SK = false>
 __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params p) {
+  static_assert(!SK || (EPI == VX_EPI_STORE && !F8 && !STATS && !LNF), "cooperative split: plain STORE / GNS epilogues");
+#ifdef VX_RING_TAP_OUTER
+  static_assert(!SK, "cooperative split: taps-innermost K order only");
+#endif
   constexpr int ES = F8 ? 1 : 2;      // bytes per operand element
   constexpr int BKE = 128 / ES;       // elements per K-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,11 +216,13 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
   // Off: the round-1 walk lb = xcd_remap(b), stride G (first round contiguous per XCD, later rounds elsewhere).
   const int n_tiles = p.n / R_BN;
   const int total_tiles = (p.m / R_BM) * n_tiles;
+  const int total_items = SK ? 2 * total_tiles : total_tiles;   // SK: item = 2 * tile + K half
   const int G = gridDim.x;
 #if VX_XCD_ROWS
   const int nxcd = G < 8 ? G : 8;
   const int xcd = (int)blockIdx.x % nxcd, xidx = (int)blockIdx.x / nxcd;
   const int stride = (G - xcd + nxcd - 1) / nxcd;                      // blocks of this launch on this XCD
+  static_assert(!SK, "cooperative split: round-1 walk only");
   const int t0 = (int)((long)total_tiles * xcd / nxcd), t1 = (int)((long)total_tiles * (xcd + 1) / nxcd);
   const int lb = t0 + xidx;
   const int my_tiles = lb < t1 ? (t1 - lb + stride - 1) / stride : 0;
@@ -196,9 +230,9 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
 #else
   const int stride = G;
   const int lb = xcd_remap(blockIdx.x, G);
-  const int my_tiles = (total_tiles - lb + G - 1) / G;
+  const int my_tiles = (total_items - lb + G - 1) / G;
 #endif
-  const int nk = p.k / BKE;
+  const int nk = (p.k / BKE) >> (SK ? 1 : 0);   // K-tiles per work item
   const int S = my_tiles * nk;   // K-tile sequence length of this block
 
   const char* __restrict__ A1 = (const char*)p.a;
@@ -240,12 +274,13 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
   // walked channel-chunk-major, taps innermost, so the nine shifted reads of an activation chunk are back to back
   // (they hit the XCD's L2 instead of travelling from the Infinity Cache nine times).
   int iss_lid = lb, iss_kt = 0;
-  int s_ci = 0, s_kx = 0, s_ky = 0;
+  int s_ci = SK ? (lb & 1) * (cin >> 1) : 0, s_kx = 0, s_ky = 0;
   const char* bbase_tile = nullptr;
   long pix0 = 0;   // input pixel of the issue tile's first output row (wave-uniform)
 
   auto setup_issue_tile = [&]() {
-    const int tile_m = iss_lid / n_tiles, tile_n = iss_lid - tile_m * n_tiles;
+    const int iss_tile = SK ? iss_lid >> 1 : iss_lid;
+    const int tile_m = iss_tile / n_tiles, tile_n = iss_tile - tile_m * n_tiles;
     const int m0 = tile_m * R_BM;
     bbase_tile = Wt + (long)(tile_n * R_BN) * p.k * ES;
     if (p.w_group_rows > 0) bbase_tile += (long)(m0 / p.w_group_rows) * ((long)p.n * p.k * ES);   // per-group weights
@@ -312,8 +347,9 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
     }
 #endif
     if (iss_kt == nk) {
-      iss_kt = 0; s_ci = 0; s_kx = 0; s_ky = 0;
+      iss_kt = 0; s_kx = 0; s_ky = 0;
       iss_lid += stride;
+      s_ci = SK ? (iss_lid & 1) * (cin >> 1) : 0;
       if (more) setup_issue_tile();
     }
     if (more) refresh_issue_bases();
@@ -500,7 +536,59 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
 
     // ---------------------------------------------------------------- epilogue (no barriers, no LDS)
     // acc[i][j][r] = C[m0 + 128 grp + 16 i + lrow][n0 + 80 wc + 16 j + 4 lq + r].
-    const int tile_m = cmp_lid / n_tiles, tile_n = cmp_lid - tile_m * n_tiles;
+    const int cmp_tile = SK ? cmp_lid >> 1 : cmp_lid;
+    // SK: this wave's 40 KB of the tile's exchange area, lane-linear float4 [i * 5 + j][lane]
+    // (wave-uniform base + one 32-bit lane offset: the scalar-base addressing form, no 64-bit address registers per item)
+    const __amdgpu_buffer_rsrc_t wsr =
+        __builtin_amdgcn_make_buffer_rsrc(SK ? p.splitk_ws : nullptr, 0, SK ? total_tiles * (R_BM * R_BN * 4) : 0, 0x00020000);
+    const uint32_t wsb = (uint32_t)(cmp_tile * 8 + wave) * (40u * 1024u);   // < 4 GiB: m * n * 4 bytes (eligibility)
+    const uint32_t wsl = (uint32_t)lane * 16u;
+    if constexpr (SK) {
+      // rendezvous of the two K halves of this tile, per wave (see the kernel's head comment); the partner's accumulators
+      // are added in the bias pass below (a separate "acc += partner" pass here makes hipcc spill 100-200 registers)
+      int* fl = (int*)((char*)p.splitk_ws + (size_t)total_tiles * (R_BM * R_BN * 4)) + (cmp_tile * 8 + wave) * 2;
+      int arrival = 0;
+      if (lane == 0) arrival = __hip_atomic_fetch_add(fl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      arrival = __builtin_amdgcn_readfirstlane(arrival);
+      if (arrival == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j) sk_store16(wsr, wsl, wsb + (i * 5 + j) * 1024, acc[i][j]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-through stores have reached L2 / memory
+        if (lane == 0) __hip_atomic_store(fl + 1, (int)(1u + sk_xcc_id()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cmp_lid += stride;
+        continue;                                  // (the epilogue below has no barriers: waves may skip it one by one)
+      }
+      uint32_t pollv, polls, polln;
+      {
+        // wait for flag word [1] (agent-scope loads, every lane the same word).  Bounded (~2^20 polls): a lost partner must
+        // show up as a wrong result in the tests, never as a hung GPU.  An asm loop on purpose: with a C++ loop here the
+        // 160 accumulators are "live through a loop" for the register allocator, which then spills ~100-200 of them (and
+        // puts scratch reloads into the K loop).
+        asm volatile("s_mov_b32 %2, 0\n"
+                     "1:\n\t"
+                     "global_load_dword %0, %3, %4 offset:4 sc1\n\t"
+                     "s_waitcnt vmcnt(0)\n\t"
+                     "v_readfirstlane_b32 %1, %0\n\t"
+                     "s_cmp_lg_u32 %1, 0\n\t"
+                     "s_cbranch_scc1 2f\n\t"
+                     "s_sleep 2\n\t"
+                     "s_add_u32 %2, %2, 1\n\t"
+                     "s_cmp_lt_u32 %2, 0x100000\n\t"
+                     "s_cbranch_scc1 1b\n"
+                     "2:"
+                     : "=&v"(pollv), "=&s"(polls), "=&s"(polln)
+                     : "v"(0u), "s"(fl)
+                     : "memory", "scc");
+      }
+      if (polls != 1u + sk_xcc_id()) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // writer on another XCD (or lost)
+      if (lane == 0) {
+        __hip_atomic_store(fl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(fl + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    const int tile_m = cmp_tile / n_tiles, tile_n = cmp_tile - tile_m * n_tiles;
     const int row_base = tile_m * R_BM + 128 * grp + lrow;
     if constexpr (F8) {
       // dequantise: acc[m][n] *= a_scale[m] * w_scale[n]
@@ -517,6 +605,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
         }
       }
     }
+    float4 sk_b4[SK ? 5 : 1];   // SK: bias (+ row bias) of this lane's columns, per fragment j
     {
       // Bias (+ the tile's time-embedding / per-item row) and the folded LayerNorm in ONE pass over the raw accumulators,
       // on every lane's OWN columns (before any lane exchange): with the fold, acc <- rstd[m] * acc + (bias[n] -
@@ -567,6 +656,8 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
             acc[i][j][2] = fmaf(rs[i], acc[i][j][2], fmaf(rm[i], s4.z, b4.z));
             acc[i][j][3] = fmaf(rs[i], acc[i][j][3], fmaf(rm[i], s4.w, b4.w));
           }
+        } else if constexpr (SK) {
+          sk_b4[j] = b4;   // added per row block in the item walk below, together with the partner's accumulators
         } else if (bias != nullptr || rb_row0 != nullptr) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -583,7 +674,7 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
       // the 160 contiguous bytes of an output row within one step (partial lines meet in L2 right away); bias and the
       // tile's time-embedding / per-item row are already in the accumulators (pass above), and the residual loads run
       // RES_DEPTH items ahead of their use: the epilogue of a short-K tile is a string of HBM round trips otherwise.
-      constexpr int N_ITEMS = 24, RES_DEPTH = LNF ? 4 : VX_RING_RES_DEPTH;   // (LNF + RES: unused by the model, keep it spill-free)
+      constexpr int N_ITEMS = 24, RES_DEPTH = (LNF || SK) ? 4 : VX_RING_RES_DEPTH;   // (LNF + RES: unused by the model, keep it spill-free)
       const int col_p = tile_n * R_BN + 80 * wc + 8 * (lq >> 1) + 16 * (lq & 1);   // + 32 t  (pair t = 0, 1)
       const int col_4 = tile_n * R_BN + 80 * wc + 64 + 4 * lq;
       // byte offsets (32-bit: eligibility bounds m * ld * 2 < 4 GiB) = per-lane base + wave-uniform item part
@@ -623,6 +714,21 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
       for (int k = 0; k < N_ITEMS; ++k) {
         if (RES && !RABL(64) && k + RES_DEPTH < N_ITEMS) load_res(k + RES_DEPTH);
         const int i = k / 3, kind = k % 3;
+        if constexpr (SK) {
+          // (own half + partner's half) + bias, one row block at a time right before its three items: five 16-byte loads
+          // in flight and a shrinking set of live accumulators (all 40 loads in the bias pass: every loaded value was
+          // spilled the moment it arrived, one memory round trip each - 50 us per launch)
+          if (kind == 0) {
+            f32x4_t pv[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) pv[j] = sk_load16(wsr, wsl, wsb + (i * 5 + j) * 1024);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+              acc[i][j][0] = (acc[i][j][0] + pv[j][0]) + sk_b4[j].x; acc[i][j][1] = (acc[i][j][1] + pv[j][1]) + sk_b4[j].y;
+              acc[i][j][2] = (acc[i][j][2] + pv[j][2]) + sk_b4[j].z; acc[i][j][3] = (acc[i][j][3] + pv[j][3]) + sk_b4[j].w;
+            }
+          }
+        }
         if (kind == 2) {
           float v[4];
 #pragma unroll
@@ -896,7 +1002,15 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
     }
     if (!on || p.epi != VX_EPI_STORE || (p.k % 128) != 0 || p.kh != 1 || p.kw != 1 || p.a2 != nullptr) return false;
   }
-  if ((p.epi != VX_EPI_STORE && p.epi != VX_EPI_GEGLU) || p.out_f32 || p.splitk > 1 || p.act == VX_ACT_GELU) return false;
+  // ring_hint == 2: the cooperative two-way K split (gemm_ring_kernel<..., SK>; splitk == 2 + a ZEROED workspace of
+  // vx_gemm_splitk_ws_bytes(m, n, 2) bytes).  Any other split-K request belongs to the classic tiles.
+  const bool coop = p.ring_hint == 2;
+  if (coop && p.splitk != 2) return false;
+  if (coop && (p.epi != VX_EPI_STORE || p.a_fp8 || p.ln_stats != nullptr || vx_gemm_ring_writes_row_stats(p) ||
+               p.splitk_ws == nullptr || p.w_group_rows != 0 || (unsigned long long)p.m * p.n * 4ull >= (1ull << 32) || (((p.c1 + p.c2) / 64) & 1) != 0 || ((p.c1 + p.c2) % 64) != 0 ||
+               VX_XCD_ROWS))
+    return false;
+  if ((p.epi != VX_EPI_STORE && p.epi != VX_EPI_GEGLU) || p.out_f32 || (p.splitk > 1 && !coop) || p.act == VX_ACT_GELU) return false;
   if ((p.m % R_BM) != 0 || (p.n % R_BN) != 0) return false;
   if (p.w_group_rows != 0 && (p.w_group_rows < 0 || (p.w_group_rows % R_BM) != 0 || p.a_fp8)) return false;
   if ((p.ldc % 8) != 0 || (p.residual != nullptr && (p.ldr % 8) != 0)) return false;
@@ -922,10 +1036,10 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
   return mode == 2 || p.k <= 1280;
 }
 
-template <int EPI, bool RES, bool F8 = false, bool STATS = false, bool LNF = false, bool GNS = false>
+template <int EPI, bool RES, bool F8 = false, bool STATS = false, bool LNF = false, bool GNS = false, bool SK = false>
 static int ring_launch(const vx_gemm_params& p, hipStream_t stream) {
   static bool attr_set = false;
-  auto kern = gemm_ring_kernel<EPI, RES, F8, STATS, LNF, GNS>;
+  auto kern = gemm_ring_kernel<EPI, RES, F8, STATS, LNF, GNS, SK>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_TOTAL);
     if (e != hipSuccess) {
@@ -939,12 +1053,16 @@ static int ring_launch(const vx_gemm_params& p, hipStream_t stream) {
     g_cu_count = cus;
     attr_set = true;
   }
-  const long tiles = (long)(p.m / R_BM) * (p.n / R_BN);
-  const unsigned grid = (unsigned)(tiles < g_cu_count ? tiles : g_cu_count);
-  static char sym[96] = "";
+  const long tiles = (long)(p.m / R_BM) * (p.n / R_BN) * (SK ? 2 : 1);   // work items
+  unsigned grid = (unsigned)(tiles < g_cu_count ? tiles : g_cu_count);
+  if (SK) grid &= ~1u;   // both K halves of a tile in the same round
+  static char sym[104] = "";
   if (!sym[0]) {
     auto b = [](bool v) { return v ? "true" : "false"; };
-    snprintf(sym, sizeof(sym), "gemm_ring_kernel<%d, %s, %s, %s, %s, %s>", EPI, b(RES), b(F8), b(STATS), b(LNF), b(GNS));
+    if (SK)
+      snprintf(sym, sizeof(sym), "gemm_ring_kernel<%d, %s, %s, %s, %s, %s, true>", EPI, b(RES), b(F8), b(STATS), b(LNF), b(GNS));
+    else
+      snprintf(sym, sizeof(sym), "gemm_ring_kernel<%d, %s, %s, %s, %s, %s>", EPI, b(RES), b(F8), b(STATS), b(LNF), b(GNS));
   }
   g_vx_last_kernel = sym;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(R_NT), R_LDS_TOTAL, stream, p);
@@ -959,6 +1077,13 @@ int vx_gemm_ring_launch(const vx_gemm_params& p, hipStream_t stream) {
   if (p.epi == VX_EPI_GEGLU)
     return ln ? ring_launch<VX_EPI_GEGLU, false, false, false, true>(p, stream) : ring_launch<VX_EPI_GEGLU, false>(p, stream);
   const bool res = p.residual != nullptr;
+  if (p.splitk == 2) {   // (vx_gemm_ring_eligible: ring_hint == 2, STORE, no fold / row statistics)
+    if (p.gn_ws != nullptr)
+      return res ? ring_launch<VX_EPI_STORE, true, false, false, false, true, true>(p, stream)
+                 : ring_launch<VX_EPI_STORE, false, false, false, false, true, true>(p, stream);
+    return res ? ring_launch<VX_EPI_STORE, true, false, false, false, false, true>(p, stream)
+               : ring_launch<VX_EPI_STORE, false, false, false, false, false, true>(p, stream);
+  }
   if (ln) {
     // the folded projections (q / qkv) never carry a residual in this model; the combination exists for completeness
     if (vx_gemm_ring_writes_row_stats(p))

@@ -124,6 +124,7 @@ def _load():
     lib.vx_build_id.restype = C.c_char_p
     lib.vx_gemm_splitk_ws_bytes.argtypes = [i32, i32, i32]
     lib.vx_gemm_splitk_ws_bytes.restype = i64
+    lib.vx_gemm_ring_coop_ok.argtypes = [C.POINTER(GemmParams)]
     lib.vx_groupnorm_ws_floats.restype = i64
     lib.vx_groupnorm_ws_floats.argtypes = [i32, i32, i32]
     lib.vx_groupnorm.argtypes = [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, i32, i32, i32, vp]
@@ -169,7 +170,7 @@ def _load():
                         "vx_gemm_splitk_ws_bytes", "vx_gemm_last_kernel", "vx_last_kernel", "vx_build_id",
                         "vx_tblock_packed_bytes"):
             fn.restype = i32
-    if lib.vx_abi_version() != 12:
+    if lib.vx_abi_version() != 13:
         raise ImportError("libvexpress_hip.so ABI version mismatch")
     return lib
 

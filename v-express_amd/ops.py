@@ -582,6 +582,42 @@ def _splitk(p, geom, device, plain):
     p.splitk, p.splitk_ws = s, ws.data_ptr()
 
 
+# the 16x16-level launches (256 rows per frame, N = 1280: 128 tiles of 256 x 320 for a CFG pair) on
+# the persistent kernel with a cooperative two-way K split (vx_gemm_params.ring_hint = 2).  VX_RING_COOP=0 keeps them on
+# the 128 x 160 tiles (A/B knob); COOP_MIN_K: shortest K that takes the split.
+RING_COOP = [os.environ.get("VX_RING_COOP", "1") != "0"]
+COOP_MIN_K = [int(os.environ.get("VX_RING_COOP_MIN_K", "8192"))]
+_COOP_WS = {}
+
+
+def ring_coop_applies(p):
+    """Whether the launch p takes the cooperative split - a function of batch-independent facts only (rows of ONE item, N,
+    K, the epilogue; never of how many items share the launch), so a CFG half computed alone sums in the same order.
+    Only where `_ring_hint` said "not the ring kernel" because a CFG pair has too few tiles: rows of an item a multiple of
+    256, 96 <= tiles of the nominal pair < 192, K >= COOP_MIN_K; the kernel's own limits are asked of the library."""
+    items = _ITEMS[0]
+    if not RING_COOP[0] or items is None or items <= 0 or p.m % items or p.k < COOP_MIN_K[0]:
+        return False
+    rows_item = p.m // items
+    if rows_item % 256 or p.n % 320:
+        return False
+    tiles_pair = (2 * rows_item // 256) * (p.n // 320)
+    return 96 <= tiles_pair < 192 and bool(_lib.vx_gemm_ring_coop_ok(C.byref(p)))
+
+
+def _ring_coop(p, device):
+    """Switch p over to the cooperative split (ring_hint = 2, splitk = 2, a zeroed workspace) when `ring_coop_applies`."""
+    if not ring_coop_applies(p):
+        return False
+    nbytes = int(_lib.vx_gemm_splitk_ws_bytes(p.m, p.n, 2))
+    key = (device, _stream_key(device), nbytes)
+    ws = _COOP_WS.get(key)
+    if ws is None:
+        ws = _COOP_WS[key] = torch.zeros(nbytes, device=device, dtype=torch.uint8)   # flag words start (and stay) zero
+    p.splitk, p.splitk_ws, p.ring_hint = 2, ws.data_ptr(), 2
+    return True
+
+
 def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L.VX_ACT_NONE, rowbias=None,
          rows_per_group=0, out=None, out_f32=False, ln=None, stats_out=None, stats_eps=1e-5, w_group_rows=0, gn=None):
     """out[m, n] = residual + alpha * act(sum_k A[m,k] W[n,k] + bias[n] + rowbias[m // rows_per_group, n]).
@@ -641,6 +677,8 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
                 # holds only under `with ops.frame_rows(hw, items=...)`, as every call site in blocks.py has it
                 _warn_once("two-part row statistics requested outside ops.frame_rows(items=...): the kernel that sums "
                            "them is chosen by the launch size, so the low bits depend on the batch")
+    if not p.a_fp8 and p.ring_hint == -1 and p.splitk <= 1 and not out_f32:
+        _ring_coop(p, a.device)
     gst = None
     if gn is not None and GN_FUSED[0] and not p.a_fp8:
         groups, hw = gn
