@@ -69,6 +69,16 @@ def _lib_sha():
     return lib.LIB_SHA256
 
 
+def _symbol_forms(symbol):
+    """The names a kernel instantiation can carry in a profiler file: the library prints a gemm_ring_kernel instantiation
+    without a trailing default template argument (the cooperative-split flag, false for every launch but ring_hint = 2);
+    the demangled symbol has it."""
+    forms = [symbol]
+    if symbol.startswith("gemm_ring_kernel<") and symbol.endswith(">") and symbol.count(",") == 5:
+        forms.append(symbol[:-1] + ", false>")
+    return forms
+
+
 def _pmc_traffic(symbol):
     """HBM-side bytes per launch of one kernel instantiation from a committed rocprofv3 PMC file (tools/exp_pmc_bench.sh:
     FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; the
@@ -86,7 +96,7 @@ def _pmc_traffic(symbol):
             continue
         ks = d.get("kernels", {})
         # (GEMM instantiations are keyed without their parameter list, every other kernel with it)
-        v = ks.get(symbol) or next((x for k, x in ks.items() if k.startswith(symbol + "(")), None)
+        v = next((x for f in _symbol_forms(symbol) for k, x in ks.items() if k == f or k.startswith(f + "(")), None)
         if v and v.get("launches") and v.get("fetch_bytes_per_launch", 0) > 0:
             return v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"], os.path.relpath(path, ROOT)
     return None, (f"no counter file for library build {sha}" + (f" (newest other build: {seen_other})" if seen_other else ""))
@@ -110,7 +120,7 @@ def _rocprof_launch_avg(symbol):
             if ln.startswith("#"):                        # header / gap-attribution comments of tools/trace_summary.py
                 continue
             m = re.search(r"n=\s*(\d+)\s+avg=\s*([0-9.]+) us\s+(?:void )?(.*)$", ln)     # (non-template kernels: no "void")
-            if m and m.group(3).startswith(symbol + "("):
+            if m and any(m.group(3).startswith(f + "(") for f in _symbol_forms(symbol)):
                 return dict(avg_launch_us=float(m.group(2)), launches=int(m.group(1)), file=os.path.relpath(path, ROOT))
     return None
 
