@@ -596,13 +596,19 @@ def ring_coop_applies(p):
     Only where `_ring_hint` said "not the ring kernel" because a CFG pair has too few tiles: rows of an item a multiple of
     256, 96 <= tiles of the nominal pair < 192, K >= COOP_MIN_K; the kernel's own limits are asked of the library."""
     items = _ITEMS[0]
-    if not RING_COOP[0] or items is None or items <= 0 or p.m % items or p.k < COOP_MIN_K[0]:
+    if items is None or items <= 0 or p.m % items:
         return False
     rows_item = p.m // items
     if rows_item % 256 or p.n % 320:
         return False
     tiles_pair = (2 * rows_item // 256) * (p.n // 320)
-    return 96 <= tiles_pair < 192 and bool(_lib.vx_gemm_ring_coop_ok(C.byref(p)))
+    if not 96 <= tiles_pair < 192:
+        return False
+    why = ("VX_RING_COOP=0" if not RING_COOP[0] else f"K below {COOP_MIN_K[0]}: break-even" if p.k < COOP_MIN_K[0] else
+           "" if _lib.vx_gemm_ring_coop_ok(C.byref(p)) else "the kernel's limits (epilogue / odd number of 64-channel chunks)")
+    # logged once per (rows of an item, N, K) like the one-launch blocks' decisions (bench.py: block_paths)
+    return _note_path("gemm_too_few_tiles", (("rows_item", rows_item), ("n", p.n), ("k", p.k)), not why,
+                      "persistent kernel, cooperative two-way K split" if not why else "128 x 160 tiles", why)
 
 
 def _ring_coop(p, device):
