@@ -713,3 +713,18 @@ def test_ring_coop_split_policy_is_a_function_of_per_item_facts():
             assert not ops.ring_coop_applies(params(8192, 1280, 11520))
         finally:
             ops.RING_COOP[0] = True
+
+
+def test_cooperative_split_rendezvous_protocol_all_interleavings():
+    """tools/coop_protocol_check.py: every interleaving of the two partner waves of the cooperative K split (and of the
+    asynchronous drain of the first wave's stores), twice in a row on the same workspace slot - the second wave reads only
+    complete partner data, exactly one runs the epilogue, nobody blocks, the flag words end zero; and each of the three
+    ingredients (wait before the flag, flag reset, data before flag) is necessary."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "coop_protocol_check.py")
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    for brk in (1, 2, 3):
+        r = subprocess.run([sys.executable, tool, "--break", str(brk)], capture_output=True, text=True)
+        assert r.returncode == 1 and "FAILED" in r.stdout, (brk, r.stdout)
