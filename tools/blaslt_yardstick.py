@@ -56,9 +56,12 @@ def main():
         out = torch.empty((m, n), device=dev, dtype=torch.bfloat16)
         t_ref = timed(lambda: torch.matmul(a, w.t(), out=out), reps)
         with ops.frame_rows(m // 32 if m % 32 == 0 else m, items=2):
+            with ops.GemmProfile() as prof:
+                ops.gemm(a, w, b, out=out)
             t_vx = timed(lambda: ops.gemm(a, w, b, out=out), reps)
+        kern = prof.records[0][3].replace("gemm_", "").replace("_kernel", "")
         fl = 2.0 * m * n * k
-        print(f"{m:8d} {n:6d} {k:6d} {t_ref:10.1f} {fl / t_ref * 1e-6:8.1f} {t_vx:11.1f} {fl / t_vx * 1e-6:8.1f}  {note}")
+        print(f"{m:8d} {n:6d} {k:6d} {t_ref:10.1f} {fl / t_ref * 1e-6:8.1f} {t_vx:11.1f} {fl / t_vx * 1e-6:8.1f}  {note}  [{kern}]")
         del a, w, out
 
 
