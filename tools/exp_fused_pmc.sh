@@ -25,8 +25,9 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for r in rows:
     k = r.get("Kernel_Name", "")
-    if not any(t in k for t in ("tblock_kernel", "ff_fused_kernel", "attn3_kernel", "gemm_ring_kernel<1")): continue
-    k = k.replace("(anonymous namespace)::", "")[:60]
+    if not any(t in k for t in ("tblock_kernel", "ff_fused_kernel", "attn3_kernel", "gemm_ring_kernel<1", "true, true>(",
+                                "gemm_ring_kernel<0, false, false, false, false, true, false>")): continue
+    k = k.replace("(anonymous namespace)::", "")[:84]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
 for k, d in sorted(agg.items()):
     print(k, {c: round(v / cnt[(k, c)]) for c, v in d.items()}, "launches", max(cnt[(k, c)] for c in d))
