@@ -18,21 +18,22 @@ F = 12*N + 4 (one window per GPU per step).  value = F*K / max-over-ranks time.
 `python bench.py --gpus N` without a torchrun environment re-launches itself under torch.distributed.run with N ranks
 (one per GPU, RCCL); a world size that differs from --gpus is an error.
 
-Extra objects in the JSON line:
+The printed line is ONE compact JSON object (< 4 KB: `compact_line`; the 23 KB line of round 5 could not be parsed by the
+driver): the contract's keys + `roofline` + `cpu_baseline`; every table (ranking, per-kernel, per-instantiation, HBM kernels,
+block paths, the CPU workers) goes to the side file named by its `detail` key (`--detail`, default gpurun_out/bench_detail.json).
   roofline      dominant kernel = the ONE kernel instantiation with the most time in a whole clip, chosen over ALL profiled
                 kernels - every vx_gemm launch (2*M*N*K FLOP), the attention kernels (4*B*H*Nq*Nkv*d at the true head dim),
                 the one-launch feed-forward / temporal blocks and the HBM-bound kernels (algorithmic bytes) - from HIP-event
                 durations of ONE extra instrumented DDIM step + the decode of 4 frames after the timed region (events on
-                the launch stream, each launch weighted by how often it runs per clip); `ranking` lists the top kernels
-                the same way; `whole_path` = fps * algorithmic FLOP per frame (66.4 TFLOP/frame at F=16) /
-                peak.
-  cpu_baseline  the fp32 oracle (port of the reference path) on the host cores (thread count picked by probing the three
-                op classes of the UNet itself - conv, linear, SDPA - over powers of two up to the physical core count):
-                a CFG UNet3D forward at 512^2 with a 2-frame window, one untimed warm-up + two timed runs (mean), + one
-                warmed frame of VAE decode (a bounded sample), extrapolated linearly (x8 frames - the reference's own
-                modules scale 18.1 s -> 78.1 s from f=4 to f=16, SURVEY.md E6 - x25 steps, x16 frames of decode); the
-                all-physical-cores figure and the reference-module figure of SURVEY.md E6 are printed beside it, with
-                core-seconds per frame for both.
+                the launch stream, each launch weighted by how often it runs per clip); `rocprof` / `traffic` only from
+                committed rocprofv3 files stamped with the loaded binary's identity; `whole_path` = fps * algorithmic FLOP
+                per frame (66.4 TFLOP/frame at F=16) / peak.  Side file: `ranking`, `per_kernel`, ...
+  cpu_baseline  kind "port": the fp32 oracle (`oracle/`, attention through F.scaled_dot_product_attention as the reference's
+                AttnProcessor2_0 runs it) on the host cores, USING THE BOX: N worker processes pinned to disjoint sets of 8
+                physical cores (frames are independent), each one frame pair - a CFG UNet3D forward at 512^2 with a 2-frame
+                window (warmed at a quarter of the pixels) + one frame of VAE decode - extrapolated linearly (x8 frame pairs
+                x25 steps + x16 frames of decode per clip; N clips side by side); `cores` = N x 8, hard 40 s bound.  The
+                reference-module figure of SURVEY.md E6 (dev container) is in the side file beside it.
 """
 import argparse
 import json
@@ -128,88 +129,38 @@ def _rocprof_launch_avg(symbol):
 HBM_PEAK_GBS = 8000.0              # HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy reaches
 
 
-def _physical_cores(avail):
-    """Physical cores inside the affinity mask (one per (package, core id) pair of /proc/cpuinfo); `avail` if unknown."""
-    try:
-        allowed = os.sched_getaffinity(0)
-        cores, cpu, pkg = set(), None, 0
-        with open("/proc/cpuinfo") as f:
-            for ln in f:
-                if ln.startswith("processor"):
-                    cpu = int(ln.split(":")[1])
-                elif ln.startswith("physical id"):
-                    pkg = int(ln.split(":")[1])
-                elif ln.startswith("core id") and cpu in allowed:
-                    cores.add((pkg, int(ln.split(":")[1])))
-        n = min(len(cores), avail) if cores else avail
-        # a virtualised topology may report one core id for every CPU (seen on the GPU boxes: 256 CPUs, "1 core"): only a
-        # count between avail / 2 (two hardware threads per core) and avail is believed
-        return n if 2 * n >= avail else max(1, avail // 2)
-    except (OSError, ValueError, AttributeError):
-        return avail
+def _core_cpus():
+    """One logical CPU per physical core inside the affinity mask, in id order: the first sibling of every
+    /sys/.../topology/thread_siblings_list group (a virtualised box whose sysfs lists no siblings counts every second CPU
+    as a core when /proc/cpuinfo says "siblings" = 2 x "cpu cores", every CPU otherwise)."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    firsts, ok = [], True
+    for c in allowed:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                txt = f.read().strip()
+            sib = []
+            for part in txt.split(","):
+                lo, _, hi = part.partition("-")
+                sib += list(range(int(lo), int(hi or lo) + 1))
+            if c == min(x for x in sib if x in allowed):
+                firsts.append(c)
+        except (OSError, ValueError):
+            ok = False
+            break
+    if ok and firsts:
+        return firsts, len(allowed)
+    return allowed[:max(1, len(allowed) // 2)] if len(allowed) >= 16 else allowed, len(allowed)
 
 
-def _pick_threads():
-    """Thread count for the CPU leg: the fastest of a few candidates - powers of two up to the PHYSICAL core count inside
-    the affinity mask, and that count itself - on a probe made of the UNet's own three op classes at the 64x64 level (3x3
-    conv, short-K linear, 4096-token SDPA with d = 40), two frames like the measured sample: a 256-thread box runs the
-    fp32 oracle several times SLOWER with all hardware threads than with one thread per few cores, and a conv-only probe
-    picked counts that were wrong for the attention half of the forward.  Returns (chosen, physical cores, {threads: s})."""
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    phys = _physical_cores(avail)
-    cands = sorted({c for c in (8, 16, 32, 64, 128, 256, phys) if c <= phys} or {phys})
-    F = torch.nn.functional
-    x = torch.randn(4, 320, 64, 64)
-    wt = torch.randn(320, 320, 3, 3)
-    tok = torch.randn(4 * 4096, 320)
-    wl = torch.randn(2560, 320)
-    q = torch.randn(4, 8, 4096, 40)
-
-    def probe():
-        F.conv2d(x, wt, padding=1)
-        F.linear(tok, wl)
-        F.scaled_dot_product_attention(q, q, q)
-    best, best_t, seen = cands[0], float("inf"), {}
-    for c in cands:
-        torch.set_num_threads(c)
-        probe()                                  # warm: thread team, primitive caches
-        t0 = time.time()
-        probe()
-        probe()
-        dt = (time.time() - t0) / 2
-        seen[c] = dt
-        best_t = min(best_t, dt)
-    # the SMALLEST count within 20 % of the fastest: on a 128-core box the probe is flat from 16 to 32 threads, and the
-    # whole forward scales worse than the probe (32 threads: 14.8 s for the f = 2 forward, what 8 dev-container cores take)
-    best = min(c for c in cands if seen[c] <= 1.2 * best_t)
-    return best, phys, seen
+CPU_WORKER_THREADS = 8     # threads per worker process = the core count the dev-container Tier-A figure was taken on
 
 
-def cpu_baseline(size, seconds_budget):
-    """Port (`oracle/`) of the reference path timed on the host cores, bounded sample: one CFG UNet3D
-    forward at 512x512 with a 2-frame window, run ONCE untimed (page-in of the weights, allocator and primitive caches,
-    thread team) and then TWICE timed - the mean of the two is the figure - plus, when the chosen thread count is not the
-    physical core count and the budget allows, one more timed forward on all physical cores (`all_cores`), plus one frame
-    of VAE decode (warmed the same way).  Threads: see _pick_threads (inside the affinity mask; OMP_PROC_BIND / OMP_PLACES
-    are whatever the caller exported - reported, never set here: pinning by a virtualised topology put every thread on
-    one core on a GPU box)."""
-    import oracle
-    from oracle import unet as OU
-    from oracle import vae as OV
-    from v_express_amd import synth
-    t_all = time.time()
-    threads, phys, probe = _pick_threads()
-    torch.set_num_threads(threads)
-    cfg, ocfg = synth.UNetConfig(), oracle.UNetConfig()
-    h = w = size // 8
-    f = 2
-    sd3 = synth.unet3d_state_dict(cfg)
-    inp = synth.synthetic_inputs(cfg, f, h, w)
-    banks = {}
+def _reader_banks_for(cfg, h, OU):
     from v_express_amd.synth import block_plan
     plan = block_plan(cfg)
     g = torch.Generator().manual_seed(1)
-    hh = h
+    banks, hh = {}, h
     for blk in plan["down"]:
         if blk["attn"]:
             for j in range(len(blk["layers"])):
@@ -223,51 +174,107 @@ def cpu_baseline(size, seconds_budget):
                 banks[f"{blk['prefix']}.attentions.{j}"] = torch.randn(1, hh * hh, blk["c"], generator=g)
         if blk["sampler"]:
             hh *= 2
-    rb = OU.reader_banks(banks)
-    x = inp["latents"].repeat(2, 1, 1, 1, 1)
-    ehs = inp["audio_embeddings"].reshape(-1, 5, 768)
+    return OU.reader_banks(banks)
 
-    def fwd():
+
+def cpu_worker(size, cpus, threads):
+    """One worker of the CPU leg (its own process, `python bench.py --cpu-worker`): pinned to `cpus`, `threads` intra-op
+    threads, the fp32 oracle (`oracle/`, a port of the reference path; attention through F.scaled_dot_product_attention as
+    AttnProcessor2_0 runs it) on ONE frame pair: CFG UNet3D forward at size x size with a 2-frame window - warmed by the same
+    forward at a quarter of the pixels (weights paged in, thread team and primitive caches up) - and one frame of VAE decode
+    (warmed the same way).  Prints one JSON line."""
+    t_all = time.time()
+    if cpus and hasattr(os, "sched_setaffinity"):
+        os.sched_setaffinity(0, cpus)
+    torch.set_num_threads(threads)
+    import oracle
+    from oracle import leaf as OLF
+    from oracle import unet as OU
+    from oracle import vae as OV
+    from v_express_amd import synth
+    OLF.USE_SDPA[0] = True
+    cfg, ocfg = synth.UNetConfig(), oracle.UNetConfig()
+    f = 2
+    t0 = time.time()
+    sd3 = synth.unet3d_state_dict(cfg, timing_only=True)
+    sdv = synth.vae_decoder_state_dict(synth.VaeConfig(), timing_only=True)
+    weights_s = time.time() - t0
+
+    def fwd(h):
+        inp = synth.synthetic_inputs(cfg, f, h, h)
+        rb = _reader_banks_for(cfg, h, OU)
+        x = inp["latents"].repeat(2, 1, 1, 1, 1)
+        ehs = inp["audio_embeddings"].reshape(-1, 5, 768)
         t0 = time.time()
         OU.unet3d_forward(sd3, ocfg, x, 519, ehs, inp["kps_features"], rb, 0.95, 3.0)
-        return time.time() - t0
+        return time.time() - t0, inp
+
     with torch.no_grad():
-        warm_s = fwd()
-        # two timed forwards when they fit (the leg is bounded: ~2 x seconds_budget in all), one otherwise
-        timed = [fwd()]
-        if (time.time() - t_all) + 1.2 * timed[0] < 1.5 * seconds_budget:
-            timed.append(fwd())
-        unet_s = sum(timed) / len(timed)
-        all_cores = None
-        if phys != threads and (time.time() - t_all) + 1.5 * unet_s < 2 * seconds_budget:
-            torch.set_num_threads(phys)
-            torch.nn.functional.conv2d(torch.randn(2, 320, 64, 64), torch.randn(320, 320, 3, 3), padding=1)   # wake the new team
-            all_cores = dict(threads=phys, unet_forward_s=fwd())
-            torch.set_num_threads(threads)
-        elif phys != threads:
-            all_cores = dict(threads=phys, unet_forward_s=None, note="skipped: outside the time budget of the CPU leg")
-        del sd3
-        vcfg = synth.VaeConfig()
-        sdv = synth.vae_decoder_state_dict(vcfg)
+        warm_s, _ = fwd(size // 16)
+        unet_s, inp = fwd(size // 8)
         z = inp["latents"][0, :, :1].permute(1, 0, 2, 3).contiguous()
-        OV.vae_decode(sdv, oracle.VaeConfig(), z)       # warm
+        OV.vae_decode(sdv, oracle.VaeConfig(), z[:, :, :size // 16, :size // 16].contiguous())     # warm
         t0 = time.time()
         OV.vae_decode(sdv, oracle.VaeConfig(), z)
         vae_s = time.time() - t0
+    print(json.dumps(dict(unet_forward_s=unet_s, vae_frame_s=vae_s, warm_s=warm_s, weights_s=weights_s, frames=f,
+                          threads=threads, cpus=list(cpus or []), total_s=time.time() - t_all)))
+
+
+def cpu_baseline(size, seconds_budget, max_workers=16):
+    """The reference path's port (`oracle/`) on the host cores, using the box: N independent worker
+    processes, each pinned to its own CPU_WORKER_THREADS physical cores (os.sched_setaffinity; frames of a window are
+    independent work, so N frame pairs run side by side), every worker one frame pair - see cpu_worker.  Whole-box figure:
+    N workers finish N x 2 frame-forwards in the mean worker time, so a 16-frame clip of 25 steps + decode takes
+    clip_s = mean(unet_s) x 8 x 25 + mean(vae_s) x 16 per worker and the box delivers N clips in that time.  Hard bound:
+    workers still running `seconds_budget` + 10 s after the start are killed and the leg reports what finished."""
+    import subprocess
+    t_all = time.time()
+    cores, logical = _core_cpus()
+    T = min(CPU_WORKER_THREADS, len(cores))
+    n = max(1, min(len(cores) // T, max_workers))
+    try:                                   # ~7 GB per worker (fp32 weights + activations): stay under half the free memory
+        with open("/proc/meminfo") as fm:
+            avail_kb = next(int(ln.split()[1]) for ln in fm if ln.startswith("MemAvailable"))
+        n = max(1, min(n, int(avail_kb / 1e6 / 2 / 7)))
+    except (OSError, StopIteration, ValueError):
+        pass
+    env = dict(os.environ, OMP_NUM_THREADS=str(T), MKL_NUM_THREADS=str(T), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    procs = []
+    for i in range(n):
+        cpus = cores[i * T:(i + 1) * T]
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "--size", str(size),
+                                       "--cpu-list", ",".join(map(str, cpus)), "--cpu-threads", str(T)],
+                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env))
+    deadline = t_all + seconds_budget + 10
+    done, killed = [], 0
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=max(0.1, deadline - time.time()))
+            rows = [ln for ln in out.splitlines() if ln.startswith("{")]
+            if pr.returncode == 0 and rows:
+                done.append(json.loads(rows[-1]))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            pr.communicate()
+            killed += 1
+    leg_s = time.time() - t_all
+    if not done:
+        return dict(value=None, unit="frames/s", cores=n * T, kind="port", processes=n, threads_per_process=T,
+                    sample=f"oracle fp32 CPU leg: no worker of {n} finished within {seconds_budget + 10} s", cpu_leg_s=leg_s)
+    f = done[0]["frames"]
+    unet_s = sum(d["unet_forward_s"] for d in done) / len(done)
+    vae_s = sum(d["vae_frame_s"] for d in done) / len(done)
     clip_s = unet_s * (16 / f) * 25 + vae_s * 16
-    # the same sample per core-second next to the dev-container figure of the reference's own modules (SURVEY.md E6:
-    # 78.1 s for the f = 16 CFG forward on 8 cores = 39.1 core-seconds per frame of the window)
-    core_s_per_frame = unet_s * threads / f
-    return dict(value=16.0 / clip_s, unit="frames/s", cores=threads, physical_cores=phys, host_cpus=os.cpu_count(),
-                kind="port",
-                sample=(f"oracle fp32: CFG UNet3D forward {size}x{size} f={f}, 1 untimed warm-up ({warm_s:.1f} s) + {len(timed)} timed "
-                        f"({', '.join(f'{t_:.1f} s' for t_ in timed)}; mean used) + 1 frame VAE decode, warmed ({vae_s:.1f} s) on "
-                        f"{threads} threads; extrapolated x(16/{f}) frames x25 steps + x16 frames = {clip_s:.0f} s per "
-                        "16-frame clip"),
-                unet_forward_s=unet_s, unet_forward_timed_s=timed, unet_forward_warmup_s=warm_s, vae_frame_s=vae_s,
-                thread_probe_s={str(k): v for k, v in probe.items()}, all_cores=all_cores,
-                omp=dict(OMP_PROC_BIND=os.environ.get("OMP_PROC_BIND"), OMP_PLACES=os.environ.get("OMP_PLACES")),
-                unet_core_seconds_per_frame=core_s_per_frame, cpu_leg_s=time.time() - t_all,
+    nd = len(done)
+    return dict(value=nd * 16.0 / clip_s, unit="frames/s", cores=nd * T, kind="port", processes=nd, threads_per_process=T,
+                sample=(f"oracle/ (fp32 port of the reference path, SDPA attention) in {nd} pinned processes x {T} threads, "
+                        f"each: CFG UNet3D forward {size}x{size} f={f} ({unet_s:.1f} s mean, warmed at quarter size) + 1 frame "
+                        f"VAE decode ({vae_s:.1f} s); per process x{16 // f} frame pairs x25 steps + x16 frames = {clip_s:.0f} s "
+                        f"per 16-frame clip, {nd} clips side by side"),
+                unet_forward_s=unet_s, vae_frame_s=vae_s, workers=done, workers_killed=killed, workers_started=n,
+                physical_cores=len(cores), host_cpus=logical,
+                unet_core_seconds_per_frame=unet_s * T / f, cpu_leg_s=leg_s,
                 reference_modules_dev_container=dict(
                     value=16.0 / (25 * 78.1 + 16 * 5.5), cores=8, unet_forward_s=78.1, unet_core_seconds_per_frame=78.1 * 8 / 16,
                     note="SURVEY.md E6: the reference's own modules (fp32, f=16 CFG forward) on the 8 cores of the dev "
@@ -305,6 +312,76 @@ def rank_kernels(launches, top=12):
     return ranking, allk, clip_s, clip_total
 
 
+LINE_LIMIT = 4096                  # bytes of the printed JSON line (tests/test_host_logic.py holds it there)
+
+
+def _rounded(obj, sig=6):
+    """Floats to `sig` significant digits, recursively (the line is read by people and a parser, not re-computed from)."""
+    if isinstance(obj, float):
+        return float(f"{obj:.{sig}g}") if obj == obj and abs(obj) != float("inf") else None
+    if isinstance(obj, dict):
+        return {k: _rounded(v, sig) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_rounded(v, sig) for v in obj]
+    return obj
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if k in d}
+
+
+def write_detail(result, path):
+    """The full result (every table) as a side file; returns the path relative to the repo root, or None if unwritable."""
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(result, f, indent=1)
+        return os.path.relpath(os.path.abspath(path), ROOT)
+    except OSError as e:
+        print(f"bench.py: detail file {path} not written: {e}", file=sys.stderr)
+        return None
+
+
+def compact_line(result, detail_path=None):
+    """The ONE JSON line bench.py prints: the contract's keys + `roofline` (dominant kernel) + `cpu_baseline`, nothing
+    that grows with the number of kernels or blocks.  Everything else is in the side file named by `detail`."""
+    line = _pick(result, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                          "vs_baseline", "dtype", "data"))
+    line["config"] = _pick(result["config"], ("workload", "frames", "windows", "parallelism"))
+    line.update(_pick(result, ("lib_sha256", "prologue_ms")))
+    rf = result.get("roofline")
+    if rf:
+        c = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_source", "traffic", "traffic_source",
+                       "algorithmic_flop_per_launch", "algorithmic_bytes_per_launch", "avg_launch_us", "launches",
+                       "share_of_clip_kernel_time", "all_mfma_tflops"))
+        rp = rf.get("rocprof")
+        c["rocprof"] = dict(avg_launch_us=rp["avg_launch_us"], frac=rp["frac"], source=rp["file"]) if rp else None
+        c["whole_path"] = _pick(rf["whole_path"], ("tflop_per_frame", "achieved", "frac"))
+        line["roofline"] = c
+    cb = result.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "processes", "threads_per_process",
+                                          "unet_core_seconds_per_frame", "cpu_leg_s"))
+        line["speedup_vs_cpu"] = result.get("speedup_vs_cpu")
+    if result.get("n_gpus", 1) > 1:
+        pr = result.get("per_rank")
+        if pr:
+            line["per_rank"] = _pick(pr, ("ms_per_step_min", "ms_per_step_max", "compute_ms_min", "compute_ms_max"))
+        co = result.get("collectives_rank0")
+        if co:
+            line["collectives_rank0"] = {k: _pick(v, ("calls", "ms", "share_of_clip")) for k, v in co.items()}
+        line.update(_pick(result, ("collective_backend", "measurement", "note", "same_clip_1gpu_fps",
+                                   "speedup_vs_1gpu_same_clip")))
+    line["detail"] = detail_path
+    line = _rounded(line)
+    if len(json.dumps(line)) >= LINE_LIMIT:              # never let free text push the line over what the driver parses
+        for path in (("cpu_baseline", "sample"), ("config", "workload"), ("roofline", "traffic_source")):
+            d = line.get(path[0])
+            if isinstance(d, dict) and isinstance(d.get(path[1]), str):
+                d[path[1]] = d[path[1]][:160]
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -323,9 +400,18 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[4]: attention q/k/v/out projections on the fp8 (e4m3) MFMA GEMM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)     # one worker of the CPU leg (cpu_worker)
+    ap.add_argument("--cpu-list", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=CPU_WORKER_THREADS, help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-shapes", default="", help="write the per-shape vx_gemm timing table of the roofline leg here")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="side file for the full tables (ranking, per-kernel, HBM kernels, block paths, CPU-leg probes)")
     args = ap.parse_args()
+
+    if args.cpu_worker:
+        cpu_worker(args.size, [int(c) for c in args.cpu_list.split(",") if c], args.cpu_threads)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as plain `python bench.py --gpus N`: become N ranks (one per GPU) under torch.distributed.run
@@ -648,9 +734,13 @@ def main():
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.size, 30)
-        result["speedup_vs_cpu"] = fps / result["cpu_baseline"]["value"]
+        if result["cpu_baseline"]["value"]:
+            result["speedup_vs_cpu"] = fps / result["cpu_baseline"]["value"]
     if rank == 0:
-        print(json.dumps(result))
+        # ONE compact line for the driver (< LINE_LIMIT bytes; BENCH_r05.json could not be parsed at 23 KB); every table
+        # (ranking, per-kernel, per-instantiation, HBM kernels, block paths, the CPU leg's probes) goes to the side file
+        detail_path = write_detail(result, args.detail)
+        print(json.dumps(compact_line(result, detail_path)))
     if world > 1:
         dist.destroy_process_group()
 

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 13
+#define VX_ABI_VERSION 14
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
@@ -83,11 +83,15 @@ typedef struct {
   /* Kernel-selection hint for the persistent ring-staged kernel (its conv K order differs from the classic tiles', so
    * callers that need bit-identical results for any sub-batch must make the choice from batch-independent facts):
    * 0 = automatic (ring when eligible and the launch has >= 192 tiles), 1 = ring whenever structurally eligible,
-   * -1 = never.
+   * -1 = never.  The choice is a PER-CALL fact (ABI 14: the process-wide vx_gemm_set_ring_mode / vx_gemm_set_fp8_ring
+   * switches of ABI <= 13 are gone - two pipelines in one process raced on them; what is left in the library are A/B
+   * environment knobs read once at first use, none of them settable through the ABI).
+   * 3 (ABI 14) = fp8 operands (a_fp8) on the persistent kernel: an explicit opt-in per call - fp8 launches with any other
+   * hint run on the classic fp8 tiles, which measure faster (tests/test_gpu_kernels.py::test_gemm_fp8_ring_vs_classic_tiles).
    * 2 (round 5, ABI 13) = the persistent kernel with a COOPERATIVE two-way K split, for launches with fewer 256 x 320
    * tiles than CUs (the 16x16 level: 8192 x 1280 = 128 tiles): set splitk = 2 and splitk_ws = a workspace of
-   * vx_gemm_splitk_ws_bytes(m, n, 2) bytes that the caller ZEROED once (the kernel keeps its flag words zero between
-   * launches; launches that share a workspace must be stream-ordered).  Each (tile, K half) is one work item; the two
+   * vx_gemm_splitk_ws_bytes(m, n, 2) bytes that the caller ZEROED once, and coop_epoch (below) = that workspace's launch
+   * counter; launches that share a workspace must be stream-ordered.  Each (tile, K half) is one work item; the two
    * halves meet inside the launch (the first to finish parks its fp32 accumulators in the workspace, the second adds
    * them and runs the epilogue: one launch, a fixed summation order, no reduce pass).  STORE epilogue (bias, row bias,
    * SiLU, residual, GroupNorm partial sums), bf16 operands, (c1 + c2) / 64 even.  Ask vx_gemm_ring_coop_ok() - a function
@@ -157,6 +161,12 @@ typedef struct {
    * variance, see row_stats_out).  0 / 1 = the (mean, rstd) format. */
   int32_t row_stats_parts, ln_stats_parts;
   float ln_eps;
+  /* Epoch of a cooperative-split launch (ring_hint == 2; ABI 14): a counter the caller keeps PER WORKSPACE, starting at 1
+   * after zeroing it and incremented for every launch on it (1 <= coop_epoch < 2^27; re-zero the workspace before wrapping).
+   * The rendezvous words of the workspace carry the epoch of the launch that wrote them and are never reset, so a launch
+   * that gave up on a lost partner (the poll is bounded) or was aborted cannot poison later launches: they wait for THEIR
+   * epoch.  VX_ERR_INVALID for a value outside the range. */
+  int32_t coop_epoch;
 } vx_gemm_params;
 
 int vx_gemm(const vx_gemm_params* p, void* stream);
@@ -167,15 +177,6 @@ int64_t vx_gemm_splitk_ws_bytes(int m, int n, int splitk);
 /* 1 if vx_gemm(p) could run with ring_hint = 2 (cooperative two-way K split on the persistent kernel; p's own ring_hint /
  * splitk / splitk_ws are ignored), else 0 */
 int vx_gemm_ring_coop_ok(const vx_gemm_params* p);
-/* Kernel-selection knob (process-wide; default 2, or the VX_GEMM_RING environment variable): 0 = never use the
- * persistent ring-staged 256x320 kernel, 1 = only for K <= 1280, 2 = for every eligible problem.  Results differ only by
- * fp32 summation order (the ring kernel walks conv taps innermost).  For A/B measurements and cross-checking tests. */
-int vx_gemm_set_ring_mode(int mode);
-int vx_gemm_get_ring_mode(void);   /* the mode in force (0 / 1 / 2): callers that need the persistent kernel (w_group_rows) ask first */
-/* fp8 operands (a_fp8) on the persistent ring kernel: 1 = on, 0 = off (product default: it measures slower than the
- * classic fp8 tiles), -1 = re-read the VX_FP8_RING environment variable at the next fp8 launch.  Process-wide; for the
- * kernel-level cross-check test, so that model-level fp8 tests run the product default. */
-int vx_gemm_set_fp8_ring(int on);
 /* name of the tile configuration vx_gemm would launch for p (profiling / roofline reports); thread-local storage */
 const char* vx_gemm_config_name(const vx_gemm_params* p);
 /* the kernel instantiation the LAST vx_gemm call of this thread launched, spelled as rocprofv3 prints it without the
@@ -242,52 +243,6 @@ int vx_tblock_pack(const void* wqkv, const float* bias, const float* colsum, con
                    const void* wo, void* wqkv_t, void* wo_t, float* colsum_p, int c, int heads, int f, void* stream);
 int vx_tblock_fused(const vx_tblock_params* p, void* stream);
 int64_t vx_tblock_packed_bytes(int f);
-
-/* ---- 3x3 convolution with the GroupNorm + SiLU in front of it applied in its A-staging path (round 5) ------------
- * out[f, oy, ox, n] = residual + bias[n] + rowbias[m / rows_per_group][n]
- *                     + sum_{ky, kx, c} act(x[f, oy + ky - 1, ox + kx - 1, c]) w[n][ky][kx][c],
- * act(v) = silu(v * scale[f][c] + shift[f][c]) inside the image (silu = 0: no activation), 0 outside (padding 1).
- * Replaces InflatedGroupNorm -> SiLU -> InflatedConv3d of ResnetBlock3D (modules/resnet.py:220-223 norm1 / conv1,
- * :235-244 norm2 / conv2, incl. the skip concat of the up blocks as the dual source x1 | x2): the normalised, zero-bordered
- * copy of the tensor that vx_groupnorm_apply + vx_gemm went through is never written; a tile's activations cross the
- * CU's L1 once per 32-channel chunk instead of nine times (haloed tile resident in LDS, normalised in place).
- *   x1 / x2   RAW (un-normalised) bf16 NHWC inputs [frames, h, w, c1 | c2], pixel strides ldx1 / ldx2 (elements)
- *   ab        float32 [frames][ab_ld][2] = (scale, shift) per frame and (concatenated) channel: vx_groupnorm_scale_shift
- *             (ab_ld must be 1024: the kernel stages one 8 KiB row per tile)
- *   w_perm    bf16 [n][9 (c1 + c2)], the conv weight [n][ky][kx][c] with K re-ordered to (32-channel chunk, tap, 32):
- *             w_perm[n][(chunk * 9 + tap) * 32 + i] = w[n][tap][chunk * 32 + i]
- *   gn_ws     NULL, or GroupNorm partial sums of the STORED output for the next GroupNorm, exactly as
- *             vx_gemm_params.gn_ws ([frame][gn_hw / 128 slabs][gn_groups] (sum, sum of squares))
- * Supported (vx_conv3x3_gn_supported; VX_ERR_UNSUPPORTED otherwise): w = 64 or 32, h * w a multiple of 256, c1, c2
- * multiples of 32 with c1 + c2 a multiple of 64 and <= 1024, n a multiple of 320, bf16 output.  Deterministic; every
- * output element's summation order is a function of the per-frame geometry only (batch-invariant). */
-typedef struct {
-  const void* x1;
-  const void* x2;            /* or NULL (c2 = 0) */
-  int32_t c1, c2, ldx1, ldx2;
-  int32_t frames, h, w;
-  const void* w_perm;
-  int32_t n;
-  const float* ab;
-  int32_t ab_ld;
-  int32_t silu;
-  const float* bias;         /* [n] or NULL */
-  const float* rowbias;      /* [m / rows_per_group][rowbias_ld] or NULL (time-embedding row of the frame's batch item) */
-  int32_t rowbias_ld, rows_per_group;
-  const void* residual;      /* bf16 [m, ldr] or NULL */
-  int32_t ldr;
-  void* out;                 /* bf16 [m, ldc], m = frames * h * w */
-  int32_t ldc;
-  float* gn_ws;
-  int32_t gn_groups, gn_hw;
-} vx_conv3_params;
-int vx_conv3x3_gn_supported(const vx_conv3_params* p);   /* 1 / 0 */
-int vx_conv3x3_gn(const vx_conv3_params* p, void* stream);
-/* (scale, shift) = (gamma rstd, beta - mean gamma rstd) per frame and channel from GroupNorm partial sums (`stat_slices`
- * per frame, as written by vx_groupnorm_stats or a producer's gn_ws): what the apply pass of vx_groupnorm builds in LDS,
- * same re-reduction order (float64).  ab: float32 [frames][ab_ld][2], entries c .. ab_ld - 1 zero. */
-int vx_groupnorm_scale_shift(const float* ws, int stat_slices, int frames, int hw, int groups, float eps,
-                             const float* gamma, const float* beta, int c, float* ab, int ab_ld, void* stream);
 
 /* ---- GroupNorm (+SiLU), per-frame statistics, NHWC, optional dual (concat) source --------------------------
  * Replaces F.group_norm via InflatedGroupNorm (modules/resnet.py:20-28; :220-221,:235,:241), Transformer3DModel.norm

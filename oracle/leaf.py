@@ -46,6 +46,9 @@ def time_embedding(w, t, dim0):
     return linear(w, "time_embedding.linear_2", F.silu(e))
 
 
+USE_SDPA = [False]
+
+
 def attention(w, p, x, ctx, heads):
     """diffusers Attention + AttnProcessor2_0 (instantiated modules/attention.py:321-360,
     modules/motion_module.py:280-290): q=xWq, k=cWk, v=cWv (no bias), softmax(qk^T/sqrt(d))v, Wo+bias."""
@@ -57,8 +60,13 @@ def attention(w, p, x, ctx, heads):
     q = q.view(B, -1, heads, d).transpose(1, 2)
     k = k.view(B, -1, heads, d).transpose(1, 2)
     v = v.view(B, -1, heads, d).transpose(1, 2)
-    s = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
-    o = torch.matmul(torch.softmax(s, dim=-1), v)
+    if USE_SDPA[0]:
+        # what AttnProcessor2_0 itself calls (same value, no [N, N] score tensor: 2 GB per call at 4096 tokens);
+        # bench.py's cpu_baseline leg times the oracle this way, the parity tests keep the explicit form below
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False)
+    else:
+        s = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
+        o = torch.matmul(torch.softmax(s, dim=-1), v)
     o = o.transpose(1, 2).reshape(B, -1, heads * d)
     return linear(w, p + ".to_out.0", o)
 

@@ -65,16 +65,6 @@ def groupnorm_stats(x1, *, frames, hw, groups, x2=None):
     return _gn_ws(x, frames, hw, groups), 1
 
 
-def conv3_gn(x1, gamma, beta, w, bias, *, frames, H, W, groups, eps, x2=None, silu=True, rowbias=None, rows_per_group=0,
-             residual=None, gn=None):
-    """vx_conv3x3_gn = groupnorm (+ SiLU, bf16 rounding of the normalised values, as the kernel rounds them into LDS)
-    followed by the pad-1 3x3 convolution, with gemm's epilogue options."""
-    from v_express_amd.ops import ConvGeom
-    n = groupnorm(x1, gamma, beta, frames=frames, hw=H * W, groups=groups, eps=eps, silu=silu, x2=x2)
-    return gemm(n.view(frames * H * W, -1), w, bias, geom=ConvGeom(frames, H, W, 3, 3, 1, 1), rowbias=rowbias,
-                rows_per_group=rows_per_group, residual=residual, gn=gn)
-
-
 def groupnorm_fold_linear(ws, gamma, w, bias_beta, *, frames, hw, groups, eps, slices=None):
     n, c = w.shape
     mean = ws[..., 0].repeat_interleave(c // groups, dim=1)                                    # [frames, c]
@@ -396,7 +386,7 @@ def vae_postprocess(x, n, c, h, w):
     return (x[:, :c].float().reshape(n, h, w, c).permute(0, 3, 1, 2) / 2 + 0.5).clamp(0, 1).contiguous()
 
 
-ALL = ("wave_conv1d", "groupnorm", "groupnorm_stats", "conv3_gn", "groupnorm_fold_linear", "layernorm", "row_stats", "layernorm_fp8", "quantize_fp8", "gemm", "geglu", "ff_fused", "tblock_fused", "alloc_vt", "gemm_split", "key_norm_max", "attention",
+ALL = ("wave_conv1d", "groupnorm", "groupnorm_stats", "groupnorm_fold_linear", "layernorm", "row_stats", "layernorm_fp8", "quantize_fp8", "gemm", "geglu", "ff_fused", "tblock_fused", "alloc_vt", "gemm_split", "key_norm_max", "attention",
        "temporal_attention", "small_kv_attention", "add_row_bias", "gather_latents", "cfg_combine", "pack_rows", "combine_units", "overlap_ddim_step",
        "ncfhw_to_nhwc", "nhwc_to_ncfhw", "vae_postprocess")
 

@@ -91,32 +91,6 @@ def test_fullsize_16_frame_forward_vs_reference_golden(full):
     assert r <= 3e-2 and c >= 0.999, (r, c)
 
 
-def test_fullsize_16_frame_forward_with_the_fused_groupnorm_conv_kernel(full, monkeypatch):
-    """The same forward with every 64x64- / 32x32-level resnet convolution on vx_conv3x3_gn (GroupNorm + SiLU applied in
-    the convolution's A path, csrc/vx_conv3.hip; off by default because it is not faster): same golden, same bounds, and
-    the block-path table must show that the kernel actually ran."""
-    from v_express_amd import ReferenceAttentionControl, ops
-    monkeypatch.setattr(ops, "CONV3_GN", [True])
-    ops.BLOCK_PATHS.clear()
-    pipe, inp, g = full["pipe"], full["inp"], full["gold"]
-    unet, refnet = pipe.denoising_unet, pipe.reference_net
-    writer = ReferenceAttentionControl(refnet, do_classifier_free_guidance=True, mode="write", fusion_blocks="full")
-    reader = ReferenceAttentionControl(unet, do_classifier_free_guidance=True, mode="read", fusion_blocks="full",
-                                       reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD)
-    refnet(inp["ref_latents"], timestep=0, encoder_hidden_states=torch.zeros(1, 1, 768), return_dict=False)
-    reader.update(writer, True)
-    x = inp["latents"].repeat(2, 1, 1, 1, 1)
-    ehs = inp["audio_embeddings"].reshape(-1, 5, 768)
-    got = unet(x, 999, encoder_hidden_states=ehs, kps_features=inp["kps_features"], return_dict=False)[0]
-    reader.clear()
-    writer.clear()
-    r, c = rel_l2(got, g["pred_step0"]), cosine(got, g["pred_step0"])
-    used = [k for k, v in ops.block_paths().items() if k.startswith("resnet_conv3x3") and "vx_conv3x3_gn" in v]
-    print(f"[fullsize f=16 forward, vx_conv3x3_gn on {len(used)} conv geometries] relL2={r:.4g} cosine={c:.6f}")
-    assert len(used) >= 4, ops.block_paths()
-    assert torch.isfinite(got).all() and r <= 3e-2 and c >= 0.999, (r, c)
-
-
 LOOP_STEPS = ((0, "latents_step0"), (4, "latents_step4"), (12, "latents_step12"), (24, "latents"))
 LOOP_BOUNDS_BF16 = {0: 3e-3, 4: 1e-2, 12: 2e-2, 24: 3e-2}      # relative L2 of the latents after step i + 1
 LOOP_BOUNDS_FP8 = {0: 5e-3, 4: 2e-2, 12: 4e-2, 24: 6e-2}

@@ -613,22 +613,23 @@ def test_gemm_fp8_store_and_split(ops, m, n, k):
 
 def test_gemm_fp8_ring_vs_classic_tiles(ops):
     """The persistent ring kernel's fp8 instantiation (opt-in: it spills and measures slower than the classic fp8 tiles;
-    enabled here, for this comparison only, through vx_gemm_set_fp8_ring so that every model-level fp8 test runs the
-    product default) against the classic fp8 tiles and the float64 reference of the dequantised operands."""
+    requested per call here - ops.FP8_RING -> vx_gemm_params.ring_hint = 3, ABI 14 - so that every model-level fp8 test
+    runs the product default) against the classic fp8 tiles and the float64 reference of the dequantised operands."""
     from v_express_amd import lib as L
     m, n, k = 256 * 200, 640, 640
     a8, w8 = ops.quantize_fp8(rnd(m, k, seed=1)), ops.fp8_weight(rnd(n, k, scale=k ** -0.5, seed=2))
     bias, res = rnd(n, seed=3, dtype=torch.float32), rnd(m, n, seed=4)
     ref = _deq(a8.q, a8.scale).double() @ _deq(w8.w8, w8.scale).double().t() + bias.double()
     outs = {}
+    saved = ops.FP8_RING[0]
     try:
         for mode in (2, 0):
-            L.check(L.lib.vx_gemm_set_fp8_ring(1 if mode else 0), "fp8 ring")
+            ops.FP8_RING[0] = bool(mode)
             with ops.GemmProfile() as prof:
                 outs[mode] = (ops.gemm(a8, w8, bias), ops.gemm(a8, w8, bias, residual=res, alpha=0.5))
             assert _ring_used(prof) == bool(mode), prof.records[0][3]
     finally:
-        L.check(L.lib.vx_gemm_set_fp8_ring(0), "fp8 ring")
+        ops.FP8_RING[0] = saved
     for mode, (plain, with_res) in outs.items():
         check(plain, ref.float(), f"fp8 gemm ring mode {mode}")
         check(with_res, (res.double() + 0.5 * ref).float(), f"fp8 gemm + residual, ring mode {mode}")
@@ -1037,107 +1038,49 @@ def test_gemm_ring_coop_split_refusals(ops):
     p2, _ = ops._base_params(a[:, :2496].contiguous(), w[:, :2496].contiguous(), None)      # 39 chunks
     p2.epi, p2.out, p2.ldc, p2.alpha = L.VX_EPI_STORE, o.data_ptr(), 1280, 1.0
     assert ops._lib.vx_gemm_ring_coop_ok(p2) == 0
-    p2.ring_hint, p2.splitk = 2, 2
+    p2.ring_hint, p2.splitk, p2.coop_epoch = 2, 2, 1
     ws = torch.zeros(int(ops._lib.vx_gemm_splitk_ws_bytes(8192, 1280, 2)), device="cuda", dtype=torch.uint8)
     p2.splitk_ws = ws.data_ptr()
     with pytest.raises(L.VxError):
         L.check(ops._lib.vx_gemm(p2, ops._stream()), "vx_gemm")
-    p.ring_hint, p.splitk = 2, 2                       # no workspace
+    p.ring_hint, p.splitk, p.coop_epoch = 2, 2, 1      # no workspace
+    with pytest.raises(L.VxError):
+        L.check(ops._lib.vx_gemm(p, ops._stream()), "vx_gemm")
+    p.splitk_ws, p.coop_epoch = ws.data_ptr(), 0       # a workspace, but no epoch (ABI 14: 1 <= coop_epoch < 2^27)
     with pytest.raises(L.VxError):
         L.check(ops._lib.vx_gemm(p, ops._stream()), "vx_gemm")
 
 
-# ------------------------------------------------------------------------------------------ conv3x3 with GroupNorm + SiLU in its A path
-def _conv3_case(ops, frames, H, W, c1, c2, n, res, rowb, seed=0):
-    hw = H * W
-    x1 = rnd(frames, hw, c1, seed=seed) * 1.3 + 0.2
-    x2 = rnd(frames, hw, c2, seed=seed + 1) * 0.7 - 0.1 if c2 else None
-    cin = c1 + c2
-    wt = rnd(n, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=seed + 2)
-    w2d = wt.permute(0, 2, 3, 1).reshape(n, -1).contiguous()
-    bias = rnd(n, seed=seed + 3, dtype=torch.float32)
-    gamma, beta = 1 + 0.2 * rnd(cin, seed=seed + 4, dtype=torch.float32), 0.3 * rnd(cin, seed=seed + 5, dtype=torch.float32)
-    r = rnd(frames * hw, n, seed=seed + 6) if res else None
-    rowbias = rnd(frames, n, seed=seed + 7, dtype=torch.float32) if rowb else None
-    return dict(x1=x1, x2=x2, wt=wt, w2d=w2d, bias=bias, gamma=gamma, beta=beta, r=r, rowbias=rowbias, hw=hw)
-
-
-def _conv3_two_launches(ops, c, frames, H, W, groups, gn):
-    """the path vx_conv3x3_gn replaces: GroupNorm apply into the zero-bordered image + the pad-0 implicit-GEMM convolution"""
-    hw = H * W
-    nrm = ops.groupnorm(c["x1"], c["gamma"], c["beta"], frames=frames, hw=hw, groups=groups, eps=1e-5, silu=True,
-                        x2=c["x2"], pad_hw=(H, W))
-    g3 = ops.ConvGeom(frames, H + 2, W + 2, 3, 3, 1, 0)
-    with ops.frame_rows(hw, items=1):
-        return ops.gemm(nrm.view(frames * (H + 2) * (W + 2), -1), c["w2d"], c["bias"], geom=g3, rowbias=c["rowbias"],
-                        rows_per_group=hw if c["rowbias"] is not None else 0, residual=c["r"], gn=gn)
-
-
-@pytest.mark.parametrize("frames,H,W,c1,c2,n,res,rowb", [
-    (2, 8, 32, 64, 0, 320, False, False),          # one tile per frame: halo rows above AND below the image
-    (3, 16, 32, 32, 96, 320, True, False),         # two sources (chunk 0 from x1, 1..3 from x2), top and bottom tiles
-    (2, 8, 64, 128, 0, 640, False, True),          # W = 64, two column tiles, time-embedding rows
-    (4, 64, 64, 320, 0, 320, False, True),         # conv1 of a 64x64-level resnet (modules/resnet.py:220-223)
-    (4, 64, 64, 320, 0, 320, True, False),         # conv2 (+ shortcut / residual, :235-251)
-    (2, 64, 64, 320, 320, 320, False, True),       # up-block resnet: skip concat (modules/unet_3d_blocks.py:694,831)
-    (6, 32, 32, 640, 0, 640, True, False),         # 32x32 level
-    (2, 32, 32, 640, 320, 640, False, True),       # 32x32 level, 960-channel concat
-])
-def test_conv3_gn_matches_groupnorm_plus_conv(ops, frames, H, W, c1, c2, n, res, rowb):
-    """vx_conv3x3_gn = InflatedGroupNorm -> SiLU -> InflatedConv3d of ResnetBlock3D (modules/resnet.py:220-223, :235-244) in
-    one pass: against float32 F.conv2d(F.silu(F.group_norm(.))) (kernel tolerance), against the two launches it replaces
-    (same bf16 A operand by construction: only the fp32 summation order of the K loop differs), the GroupNorm partial
-    sums it leaves against float64 sums of the stored tensor, and a launch over ONE frame against its rows of the batched
-    launch (bit-identical: batch invariance)."""
-    groups, hw = 32, H * W
-    c = _conv3_case(ops, frames, H, W, c1, c2, n, res, rowb)
-    assert ops.conv3_gn_supported(H, W, c1 + c2, n, c1)
-    kw = dict(frames=frames, H=H, W=W, groups=groups, eps=1e-5, x2=c["x2"], rowbias=c["rowbias"],
-              rows_per_group=hw if rowb else 0, residual=c["r"])
-    got = ops.conv3_gn(c["x1"], c["gamma"], c["beta"], c["w2d"], c["bias"], gn=(groups, hw), **kw)
-    x = c["x1"].float() if c["x2"] is None else torch.cat([c["x1"].float(), c["x2"].float()], dim=-1)
-    img = x.view(frames, H, W, -1).permute(0, 3, 1, 2)
-    nrm = F.silu(F.group_norm(img, groups, c["gamma"], c["beta"], 1e-5)).to(BF).float()     # the kernel rounds the A operand to bf16
-    ref = F.conv2d(nrm, c["wt"].float(), c["bias"], padding=1).permute(0, 2, 3, 1).reshape(frames * hw, n)
-    if rowb:
-        ref = ref + c["rowbias"].repeat_interleave(hw, 0)
-    if res:
-        ref = ref + c["r"].float()
-    check(got, ref, f"conv3_gn {frames}x{H}x{W} {c1}+{c2}->{n}")
-    two = _conv3_two_launches(ops, c, frames, H, W, groups, None)
-    diff = (got.float() - two.float()).abs().max().item()
-    frac = (got != two).float().mean().item()
-    print(f"[conv3_gn {frames}x{H}x{W} {c1}+{c2}->{n}] vs the two launches: max|diff| {diff:.4g}, differing elements {100 * frac:.3g} %")
-    assert diff <= 2 ** -6 * two.float().abs().max().item() and frac < 0.05, (diff, frac)
-    _gn_check(ops, got, frames, hw, groups, "conv3_gn")
-    one = ops.conv3_gn(c["x1"][:1].contiguous(), c["gamma"], c["beta"], c["w2d"], c["bias"], gn=(groups, hw),
-                       **dict(kw, frames=1, x2=None if c["x2"] is None else c["x2"][:1].contiguous(),
-                              rowbias=None if not rowb else c["rowbias"][:1], residual=None if not res else c["r"][:hw]))
-    assert torch.equal(one, got[:hw]) and torch.equal(ops.gn_of(one).ws, ops.gn_of(got).ws[:1])
-
-
-def test_conv3_gn_scale_shift_table_and_refusals(ops):
-    """vx_groupnorm_scale_shift against float64 (gamma rstd, beta - mean gamma rstd) from the statistics pass's partial
-    sums; geometries the kernel does not take are refused by the library (VX_ERR_UNSUPPORTED), never run wrongly."""
+def test_gemm_ring_coop_split_survives_stale_rendezvous_words(ops):
+    """with reset-to-zero flag words one stale word (a reader that gave up on its bounded poll, an aborted
+    launch) made every later launch of the process add accumulators that were not written yet.  ABI 14: the words carry the
+    launch's epoch and are never reset - a workspace whose words hold ANY older state gives the same bits as a fresh one."""
     from v_express_amd import lib as L
-    frames, hw, cch, groups = 3, 1024, 640, 32
-    x = rnd(frames, hw, cch) * 2 + 0.5
-    gamma, beta = 1 + 0.2 * rnd(cch, seed=3, dtype=torch.float32), 0.3 * rnd(cch, seed=4, dtype=torch.float32)
-    ws, slices = ops.groupnorm_stats(x, frames=frames, hw=hw, groups=groups)
-    ab = ops.groupnorm_scale_shift(ws, slices, gamma, beta, frames=frames, hw=hw, groups=groups, eps=1e-5)
-    xg = x.double().view(frames, hw, groups, -1)
-    mean, var = xg.mean(dim=(1, 3)), xg.var(dim=(1, 3), unbiased=False)
-    rstd = torch.rsqrt(var + 1e-5).repeat_interleave(cch // groups, dim=1)
-    sc = gamma.double()[None] * rstd
-    sh = beta.double()[None] - mean.repeat_interleave(cch // groups, dim=1) * sc
-    assert ab.shape == (frames, 1024, 2) and torch.equal(ab[:, cch:], torch.zeros_like(ab[:, cch:]))
-    assert torch.allclose(ab[:, :cch, 0].double(), sc, rtol=2e-6, atol=1e-6)
-    assert torch.allclose(ab[:, :cch, 1].double(), sh, rtol=2e-5, atol=2e-6)
-    assert not ops.conv3_gn_supported(96, 96, 320, 320) and not ops.conv3_gn_supported(64, 64, 1280, 320)
-    p = ops._conv3_params(rnd(2, 48 * 48, 320), None, 2, 48, 48, 320)
-    assert ops._lib.vx_conv3x3_gn_supported(p) == 0
-    with pytest.raises(L.VxError):
-        L.check(ops._lib.vx_conv3x3_gn(p, ops._stream()), "vx_conv3x3_gn")
+    m, n, k = 8192, 1280, 8192
+    a, w = rnd(m, k), rnd(n, k, scale=k ** -0.5, seed=1)
+    bias = rnd(n, seed=2, dtype=torch.float32)
+    nbytes = int(ops._lib.vx_gemm_splitk_ws_bytes(m, n, 2))
+
+    def run(ws, epoch):
+        o = torch.empty((m, n), device="cuda", dtype=BF)
+        p, _ = ops._base_params(a, w, None)
+        p.epi, p.out, p.ldc, p.alpha, p.bias = L.VX_EPI_STORE, o.data_ptr(), n, 1.0, bias.data_ptr()
+        p.ring_hint, p.splitk, p.splitk_ws, p.coop_epoch = 2, 2, ws.data_ptr(), epoch
+        L.check(ops._lib.vx_gemm(p, ops._stream()), "vx_gemm")
+        return o
+    fresh = torch.zeros(nbytes, device="cuda", dtype=torch.uint8)
+    ref = run(fresh, 1)
+    check(ref, a.float() @ w.float().t() + bias, "cooperative split, fresh workspace")
+    assert torch.equal(run(fresh, 2), ref) and torch.equal(run(fresh, 3), ref)
+    # every word of the flag area left at an older epoch: "claimed" (word 0) and "ready" (word 1) of launches 5 / 6, and the
+    # exchange area full of garbage - what aborted launches could leave at worst
+    dirty = torch.zeros(nbytes, device="cuda", dtype=torch.uint8)
+    flags = dirty[m * n * 4:].view(torch.int32)
+    assert flags.numel() == (m // 256) * (n // 320) * 8 * 2
+    dirty[:m * n * 4].view(torch.float32).fill_(float("nan"))
+    flags[0::2] = 5
+    flags[1::2] = (6 << 4) | 3
+    assert torch.equal(run(dirty, 7), ref) and torch.equal(run(dirty, 8), ref)
 
 
 @pytest.mark.parametrize("m", [128 * 3, 128 * 600])

@@ -352,13 +352,14 @@ def test_full_size_forward_ring_vs_classic_and_batch_invariance():
         out = unet.forward_tokens(ops.ncfhw_to_nhwc(xx, 8), 519, ee.to(torch.bfloat16).reshape(-1, 768).contiguous(),
                                   ops.ncfhw_to_nhwc(kk, c0), b=b, f=F, H=h, W=w, batch_rows=rows)
         return out.view(b, F * h * w, -1)[..., :4].clone()
+    saved = ops.RING_MODE[0]                 # (a per-call choice since ABI 14: ops turns the knob into ring_hint values)
     try:
-        L.check(L.lib.vx_gemm_set_ring_mode(2))
+        ops.RING_MODE[0] = 2
         ring = fwd(x, ehs, kps)
-        L.check(L.lib.vx_gemm_set_ring_mode(0))
+        ops.RING_MODE[0] = 0
         classic = fwd(x, ehs, kps)
     finally:
-        L.lib.vx_gemm_set_ring_mode(2)
+        ops.RING_MODE[0] = saved
     assert torch.isfinite(ring).all() and torch.isfinite(classic).all()
     assert rel_l2(ring, classic) <= 3e-2 and cosine(ring, classic) >= 0.999, (rel_l2(ring, classic), cosine(ring, classic))
     again = fwd(x, ehs, kps)

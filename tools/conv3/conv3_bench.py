@@ -2,7 +2,7 @@
 GroupNorm apply pass into the zero-bordered image + the persistent ring kernel's pad-0 convolution - on the resnet
 convolution shapes of a CFG UNet3D forward at 512x512 (32 frames), statistics given by the producer in both cases:
 
-    python tools/conv3_bench.py [reps]
+    python tools/conv3/conv3_bench.py [reps]      (after tools/conv3/build_conv3_variants.sh)
 
 Prints us per call of: gn_apply, ring conv, their sum | scale_shift table, conv3_gn, their sum | ratio, and the max
 difference between the two results in bf16 ulps of the largest output."""
@@ -11,7 +11,9 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
+sys.path.insert(0, "tools/conv3")
 from v_express_amd import ops  # noqa: E402
+import conv3_ops as c3  # noqa: E402
 
 SHAPES = [  # name, frames, H, W, c1, c2, n, residual
     ("L0 conv 320>320 (conv1)", 32, 64, 64, 320, 0, 320, False),
@@ -67,11 +69,11 @@ def main():
                 buf["two"] = ops.gemm(buf["n"].view(frames * (H + 2) * (W + 2), -1), w, bias, geom=g3, residual=resid, gn=(groups, hw))
 
         def table():
-            buf["ab"] = ops.groupnorm_scale_shift(ws, slices, gamma, beta, frames=frames, hw=hw, groups=groups, eps=1e-5)
+            buf["ab"] = c3.groupnorm_scale_shift(ws, slices, gamma, beta, frames=frames, hw=hw, groups=groups, eps=1e-5)
 
         def conv3():
-            p = ops._conv3_params(x1, x2, frames, H, W, n)
-            wp = ops.conv3_weight(w)
+            p = c3._conv3_params(x1, x2, frames, H, W, n)
+            wp = c3.conv3_weight(w)
             out = buf.setdefault("out", torch.empty((frames * hw, n), device="cuda", dtype=torch.bfloat16))
             gws = buf.setdefault("gws", torch.empty((frames, hw // 128, groups, 2), device="cuda"))
             p.w_perm, p.ab, p.silu, p.bias = wp.data_ptr(), buf["ab"].data_ptr(), 1, bias.data_ptr()
@@ -79,7 +81,7 @@ def main():
             if resid is not None:
                 p.residual, p.ldr = resid.data_ptr(), n
             p.gn_ws, p.gn_groups, p.gn_hw = gws.data_ptr(), groups, hw
-            ops.L.check(ops._lib.vx_conv3x3_gn(ops.C.byref(p), ops._stream()), "vx_conv3x3_gn")
+            ops.L.check(c3._c3().vx_conv3x3_gn(ops.C.byref(p), ops._stream()), "vx_conv3x3_gn")
         t_a, t_r = timed(gn_apply, reps), timed(ring, reps)
         t_t, t_c = timed(table, reps), timed(conv3, reps)
         d = (buf["out"].float() - buf["two"].float()).abs().max().item()

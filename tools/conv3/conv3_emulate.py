@@ -1,4 +1,4 @@
-"""Lane-level emulation of csrc/vx_conv3.hip (the 3x3 convolution with GroupNorm + SiLU applied in its A-staging path):
+"""Lane-level emulation of tools/conv3/vx_conv3.hip (the 3x3 convolution with GroupNorm + SiLU applied in its A-staging path):
 the SAME index formulas as the kernel - plane copies (copy slot -> halo row / columns, slot swizzle on the source side),
 the in-place normalisation of the units a thread copied (validity of the halo row, table index), the weight copies and
 their XOR swizzle, the K order (32-channel chunk major, taps innermost, two tap-steps per K-tile), the period of nine

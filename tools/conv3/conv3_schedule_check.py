@@ -1,4 +1,4 @@
-"""Happens-before check of the copy / wait / barrier protocol of csrc/vx_conv3.hip (timing only; the address arithmetic is
+"""Happens-before check of the copy / wait / barrier protocol of tools/conv3/vx_conv3.hip (timing only; the address arithmetic is
 tools/conv3_emulate.py's job).
 
 The kernel's workgroup = two wave rows that execute the SAME slot sequence, row 1 one slot behind row 0, with one
@@ -22,7 +22,7 @@ import re
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(os.path.dirname(HERE), "v-express_amd", "csrc", "vx_conv3.hip")
+SRC = os.path.join(HERE, "vx_conv3.hip")
 
 
 def kernel_immediates():

@@ -12,7 +12,9 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
+sys.path.insert(0, "tools/conv3")
 from v_express_amd import ops  # noqa: E402
+import conv3_ops as c3  # noqa: E402
 
 
 def main():
@@ -27,11 +29,11 @@ def main():
     bias, gamma, beta = r(n, dtype=torch.float32), 1 + 0.1 * r(c, dtype=torch.float32), 0.1 * r(c, dtype=torch.float32)
     res = r(frames * hw, n)
     buf = torch.zeros(2 * 513, device="cuda", dtype=torch.int64)
-    fn = ops._lib.vx_conv3_set_trace
+    fn = c3._c3().vx_conv3_set_trace
     fn.argtypes = [ctypes.c_void_p]
     for _ in range(3):
         assert fn(ctypes.c_void_p(buf.data_ptr())) == 0
-        ops.conv3_gn(x, gamma, beta, w, bias, frames=frames, H=H, W=W, groups=groups, eps=1e-5, residual=res, gn=(groups, hw))
+        c3.conv3_gn(x, gamma, beta, w, bias, frames=frames, H=H, W=W, groups=groups, eps=1e-5, residual=res, gn=(groups, hw))
     torch.cuda.synchronize()
     t = buf.cpu().view(2, 513)
     for row in (0, 1):

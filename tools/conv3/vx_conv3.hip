@@ -38,9 +38,10 @@
 //     lane by lane (both CPU tests);
 //   * past the end of its sequence a block keeps issuing copies from clamped (valid) sources into buffers nobody reads:
 //     the immediates stay compile-time constants; the kernel drains them before it exits.
-#include "vx_common.h"
-#include "vx_gemm_common.h"
+#include "../../v-express_amd/csrc/vx_common.h"
+#include "../../v-express_amd/csrc/vx_gemm_common.h"
 #include "../../include/vexpress_hip.h"
+#include "vx_conv3.h"
 
 #include <stdio.h>
 #include <stdlib.h>

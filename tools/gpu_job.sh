@@ -15,6 +15,10 @@
 #   profile  <tag>                                  rocprofv3 --kernel-trace --stats of one bench clip -> <tag>_trace_summary.txt
 #   pmc      <tag>                                  HBM-side traffic per kernel (separate --pmc passes) -> <tag>_pmc_traffic.{json,txt}
 #   final    <tag>                                  the round's validation: box, tests (all), smoke, bench, profile, pmc, bench again
+#   scale8   <tag>                                  multi-GPU pre-flight + scaling runs (needs >= 2 GPUs): a 60 s two-rank RCCL probe
+#                                                   (tools/rccl_probe.py: init, sub-groups, all-gather, all-to-all, sharded loop vs
+#                                                   sequential, bit for bit) FIRST, then bench.py --gpus 1 2 4 8 at F = 124 with
+#                                                   per-rank / per-collective timing; stops at the first failure with the step named
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp PYTHONPATH=$PWD:$PYTHONPATH
@@ -43,7 +47,8 @@ tests)
 smoke)
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/${T}_smoke.log 2>&1; tail -2 $OUT/${T}_smoke.log ;;
 bench)
-  timeout 900 python bench.py --gemm-shapes $OUT/${T}_gemm_by_shape.txt "$@" > $OUT/${T}_bench.json 2> $OUT/${T}_bench.err
+  timeout 900 python bench.py --gemm-shapes $OUT/${T}_gemm_by_shape.txt --detail $OUT/${T}_bench_detail.json "$@" > $OUT/${T}_bench.json 2> $OUT/${T}_bench.err
+  python -c "import sys; n = len(open('$OUT/${T}_bench.json').read().strip().splitlines()[-1]); print('bench line bytes:', n); sys.exit(0 if n < 4096 else 1)"
   fps_of < $OUT/${T}_bench.json ;;
 ab)
   VAR=$1; A=$2; B=$3; REPS=${4:-2}; shift 4 2>/dev/null || shift $#
@@ -81,6 +86,23 @@ final)
   bash tools/gpu_job.sh profile $T
   bash tools/gpu_job.sh pmc $T
   timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${T}_bench2.json 2>> $OUT/${T}_bench.err ;;
+scale8)
+  NG=$(python -c "import torch; print(torch.cuda.device_count())")
+  echo "visible GPUs: $NG" | tee $OUT/${T}_scale8.log
+  if [ "$NG" -lt 2 ]; then echo "scale8 needs >= 2 GPUs (RCCL refuses two ranks on one device)" | tee -a $OUT/${T}_scale8.log; exit 3; fi
+  export HSA_ENABLE_IPC_MODE_LEGACY=0
+  timeout 60 python tools/rccl_probe.py --gpus 2 > $OUT/${T}_rccl_probe_2.json 2> $OUT/${T}_rccl_probe_2.err
+  rc=$?; echo "rccl_probe --gpus 2: exit $rc (124 = hung: the last 'step:' line of ${T}_rccl_probe_2.err names the call)" | tee -a $OUT/${T}_scale8.log
+  tail -3 $OUT/${T}_rccl_probe_2.err | tee -a $OUT/${T}_scale8.log
+  [ $rc -ne 0 ] && exit $rc
+  if [ "$NG" -ge 8 ]; then timeout 120 python tools/rccl_probe.py --gpus 8 > $OUT/${T}_rccl_probe_8.json 2> $OUT/${T}_rccl_probe_8.err
+    echo "rccl_probe --gpus 8: exit $?" | tee -a $OUT/${T}_scale8.log; fi
+  for n in 1 2 4 8; do
+    [ "$n" -gt "$NG" ] && break
+    timeout 900 python bench.py --gpus $n --frames 124 --steps 2 --warmup 1 --no-cpu-baseline --detail $OUT/${T}_scale_${n}_detail.json \
+      > $OUT/${T}_scale_${n}.json 2> $OUT/${T}_scale_${n}.err
+    echo "N=$n: exit $? $(fps_of < $OUT/${T}_scale_${n}.json)" | tee -a $OUT/${T}_scale8.log
+  done ;;
 *)
-  echo "usage: gpu_job.sh box|tests|smoke|bench|ab|ablib|configs|profile|pmc|final <tag> [...]"; exit 2 ;;
+  echo "usage: gpu_job.sh box|tests|smoke|bench|ab|ablib|configs|profile|pmc|final|scale8 <tag> [...]"; exit 2 ;;
 esac

@@ -25,22 +25,17 @@ def _resnet_block(P, x, frames, H, W, *, groups, eps, temb=None, rows_per_group=
     temb: fp32 [b, Cout] view = time_emb_proj(silu(emb)) rows (resnet.py:225-233)."""
     hw = H * W
     c1 = x.shape[-1]
-    c_in = c1 + (skip.shape[-1] if skip is not None else 0)
     cout = P.conv1.w.shape[0]
     g3 = ConvGeom(frames, H + 2, W + 2, 3, 3, 1, 0)
     hp = (H + 2) * (W + 2)
-    if ops.conv3_gn_applies(frames, H, W, c_in, cout, c1):
-        # norm1 -> SiLU -> conv1 in one pass over the raw x (| skip): the statistics alone are computed (the producer's
-        # own when it left them), the normalisation happens in the convolution's LDS tile (csrc/vx_conv3.hip)
-        h = ops.conv3_gn(x, P.norm1.g, P.norm1.b, P.conv1.w, P.conv1.b, frames=frames, H=H, W=W, groups=groups, eps=eps,
-                         x2=skip, rowbias=temb, rows_per_group=rows_per_group, gn=(groups, hw))
-    else:
-        # GroupNorm writes into a zero-bordered (H+2)x(W+2) image, so the 3x3 convs are pad-0 convs (vx_gemm fast path)
-        n = ops.groupnorm(x, P.norm1.g, P.norm1.b, frames=frames, hw=hw, groups=groups, eps=eps, silu=True, x2=skip,
-                          pad_hw=(H, W))
-        # conv1's epilogue leaves norm2's partial sums on h (ops.gemm(gn=...)): norm2 is an apply pass only
-        h = ops.gemm(n.view(frames * hp, -1), P.conv1.w, P.conv1.b, geom=g3, rowbias=temb, rows_per_group=rows_per_group,
-                     gn=(groups, hw))
+    # GroupNorm writes into a zero-bordered (H+2)x(W+2) image, so the 3x3 convs are pad-0 convs (vx_gemm fast path).
+    # (The one-pass form - GroupNorm + SiLU applied in the convolution's A path - was built and measured in round 5:
+    # correct, 0.8 % slower; it lives in tools/conv3/ with its emulator, not in the shipped ABI: LABNOTES 12.3.)
+    n = ops.groupnorm(x, P.norm1.g, P.norm1.b, frames=frames, hw=hw, groups=groups, eps=eps, silu=True, x2=skip,
+                      pad_hw=(H, W))
+    # conv1's epilogue leaves norm2's partial sums on h (ops.gemm(gn=...)): norm2 is an apply pass only
+    h = ops.gemm(n.view(frames * hp, -1), P.conv1.w, P.conv1.b, geom=g3, rowbias=temb, rows_per_group=rows_per_group,
+                 gn=(groups, hw))
     if P.shortcut is not None:
         sc = ops.gemm(x.view(frames * hw, c1), P.shortcut.w, P.shortcut.b,
                       a2=None if skip is None else skip.view(frames * hw, -1))
@@ -49,13 +44,9 @@ def _resnet_block(P, x, frames, H, W, *, groups, eps, temb=None, rows_per_group=
             raise ValueError("concat input needs a conv_shortcut")
         sc = x.view(frames * hw, c1)
     # every resnet output is read by a GroupNorm next (Transformer3DModel.norm or the motion module's norm)
-    if ops.conv3_gn_applies(frames, H, W, cout, cout):
-        out = ops.conv3_gn(ops.keep_gn(h.view(frames, hw, cout), h), P.norm2.g, P.norm2.b, P.conv2.w, P.conv2.b,
-                           frames=frames, H=H, W=W, groups=groups, eps=eps, residual=sc, gn=(groups, hw))
-    else:
-        n2 = ops.groupnorm(ops.keep_gn(h.view(frames, hw, cout), h), P.norm2.g, P.norm2.b, frames=frames, hw=hw,
-                           groups=groups, eps=eps, silu=True, pad_hw=(H, W))
-        out = ops.gemm(n2.view(frames * hp, cout), P.conv2.w, P.conv2.b, geom=g3, residual=sc, gn=(groups, hw))
+    n2 = ops.groupnorm(ops.keep_gn(h.view(frames, hw, cout), h), P.norm2.g, P.norm2.b, frames=frames, hw=hw,
+                       groups=groups, eps=eps, silu=True, pad_hw=(H, W))
+    out = ops.gemm(n2.view(frames * hp, cout), P.conv2.w, P.conv2.b, geom=g3, residual=sc, gn=(groups, hw))
     return ops.keep_gn(out.view(frames, hw, cout), out)
 
 

@@ -977,6 +977,10 @@ static int vx_gemm_dispatch(const vx_gemm_params& p, hipStream_t stream) {
     VX_REQUIRE(p.out != nullptr && (p.ldc % 8) == 0, "vx_gemm: STORE needs out and ldc%%8==0");
     VX_REQUIRE(p.residual == nullptr || (p.ldr % 8) == 0, "vx_gemm: ldr%%8");
     VX_REQUIRE(p.rowbias == nullptr || p.rows_per_group > 0, "vx_gemm: rows_per_group");
+    if (p.ring_hint == 2 && (p.coop_epoch < 1 || p.coop_epoch >= (1 << 27))) {
+      vx_set_error("vx_gemm: ring_hint = 2 needs 1 <= coop_epoch < 2^27 (the workspace's launch counter), got %d", p.coop_epoch);
+      return VX_ERR_INVALID;
+    }
     if (vx_gemm_ring_eligible(p)) return vx_gemm_ring_launch(p, stream);
     if (p.ring_hint == 2) {
       vx_set_error("vx_gemm: ring_hint = 2 (cooperative two-way K split on the persistent kernel) needs splitk == 2, a zeroed "

@@ -182,11 +182,13 @@ __device__ __forceinline__ uint32_t sk_xcc_id() {
 // SK (round 5; STORE, bf16 operands, no LayerNorm fold / row statistics): cooperative two-way K split for launches with
 // fewer 256 x 320 tiles than CUs (the 16x16 level: 8192 x 1280 = 128 tiles).  A work item = (tile, K half): items 2t and
 // 2t + 1 sit next to each other in the walk, i.e. on the same XCD in the same round.  Per WAVE (the STORE / GNS epilogues
-// are wave-local): lane 0 counts the wave's arrival at flag word [t][wave][0]; the FIRST of the two partner waves writes its
-// 160 accumulators per lane to splitk_ws (40 KB per wave, lane-linear float4), releases flag word [1] and goes on to its
-// next item - it never waits, so no co-residency of the two blocks is assumed; the SECOND waits for [1] (its partner is by
-// construction already past its K loop), adds the partner's accumulators to its own (a + b: the same bits whichever half
-// arrives first), zeroes both words for the next launch and runs the normal epilogue.  The K halves are whole channel
+// are wave-local): lane 0 claims flag word [t][wave][0] with an atomic exchange of the launch's epoch (p.coop_epoch); the
+// FIRST of the two partner waves (it reads another value back) writes its 160 accumulators per lane to splitk_ws (40 KB per
+// wave, lane-linear float4), releases flag word [1] = (epoch, XCC id) and goes on to its next item - it never waits, so no
+// co-residency of the two blocks is assumed; the SECOND (it reads the epoch back) waits for [1] to carry the epoch (its
+// partner is by construction already past its K loop), adds the partner's accumulators to its own (a + b: the same bits
+// whichever half arrives first) and runs the normal epilogue.  The words are never reset (round 6): whatever an aborted or
+// timed-out launch leaves behind belongs to an older epoch and is ignored.  The K halves are whole channel
 // chunks ((c1 + c2) / 64 even), each walked taps-innermost like the unsplit loop.
 template <int EPI, bool RES, bool F8 = false, bool STATS = false, bool LNF = false, bool GNS = false, bool SK = false>
 __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params p) {
@@ -547,46 +549,48 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
       // rendezvous of the two K halves of this tile, per wave (see the kernel's head comment); the partner's accumulators
       // are added in the bias pass below (a separate "acc += partner" pass here makes hipcc spill 100-200 registers)
       int* fl = (int*)((char*)p.splitk_ws + (size_t)total_tiles * (R_BM * R_BN * 4)) + (cmp_tile * 8 + wave) * 2;
-      int arrival = 0;
-      if (lane == 0) arrival = __hip_atomic_fetch_add(fl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      arrival = __builtin_amdgcn_readfirstlane(arrival);
-      if (arrival == 0) {
+      // fl[0] = epoch of the launch whose first partner wave claimed the slot, fl[1] = (epoch << 4 | writer's XCC id) once its
+      // accumulators are in memory.  Nothing is reset: a later launch waits for ITS epoch (ABI 14; tools/coop_protocol_check.py)
+      const int epoch = p.coop_epoch;
+      int claimed = 0;
+      if (lane == 0) claimed = __hip_atomic_exchange(fl, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      claimed = __builtin_amdgcn_readfirstlane(claimed);
+      if (claimed != epoch) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int j = 0; j < 5; ++j) sk_store16(wsr, wsl, wsb + (i * 5 + j) * 1024, acc[i][j]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-through stores have reached L2 / memory
-        if (lane == 0) __hip_atomic_store(fl + 1, (int)(1u + sk_xcc_id()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0)
+          __hip_atomic_store(fl + 1, (int)(((uint32_t)epoch << 4) | sk_xcc_id()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cmp_lid += stride;
         continue;                                  // (the epilogue below has no barriers: waves may skip it one by one)
       }
-      uint32_t pollv, polls, polln;
+      uint32_t pollv, polls, polln, polle;
       {
-        // wait for flag word [1] (agent-scope loads, every lane the same word).  Bounded (~2^20 polls): a lost partner must
-        // show up as a wrong result in the tests, never as a hung GPU.  An asm loop on purpose: with a C++ loop here the
-        // 160 accumulators are "live through a loop" for the register allocator, which then spills ~100-200 of them (and
-        // puts scratch reloads into the K loop).
+        // wait for flag word [1] to carry this launch's epoch (agent-scope loads, every lane the same word).  Bounded (~2^20
+        // polls): a lost partner must show up as a wrong result in the tests, never as a hung GPU.  An asm loop on purpose: with
+        // a C++ loop here the 160 accumulators are "live through a loop" for the register allocator, which then spills ~100-200
+        // of them (and puts scratch reloads into the K loop).
         asm volatile("s_mov_b32 %2, 0\n"
                      "1:\n\t"
-                     "global_load_dword %0, %3, %4 offset:4 sc1\n\t"
+                     "global_load_dword %0, %4, %5 offset:4 sc1\n\t"
                      "s_waitcnt vmcnt(0)\n\t"
                      "v_readfirstlane_b32 %1, %0\n\t"
-                     "s_cmp_lg_u32 %1, 0\n\t"
+                     "s_lshr_b32 %3, %1, 4\n\t"
+                     "s_cmp_eq_u32 %3, %6\n\t"
                      "s_cbranch_scc1 2f\n\t"
                      "s_sleep 2\n\t"
                      "s_add_u32 %2, %2, 1\n\t"
                      "s_cmp_lt_u32 %2, 0x100000\n\t"
                      "s_cbranch_scc1 1b\n"
                      "2:"
-                     : "=&v"(pollv), "=&s"(polls), "=&s"(polln)
-                     : "v"(0u), "s"(fl)
+                     : "=&v"(pollv), "=&s"(polls), "=&s"(polln), "=&s"(polle)
+                     : "v"(0u), "s"(fl), "s"(epoch)
                      : "memory", "scc");
       }
-      if (polls != 1u + sk_xcc_id()) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // writer on another XCD (or lost)
-      if (lane == 0) {
-        __hip_atomic_store(fl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(fl + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if ((polls & 15u) != sk_xcc_id() || polle != (uint32_t)epoch)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // writer on another XCD (or lost)
     }
     const int tile_m = cmp_tile / n_tiles, tile_n = cmp_tile - tile_m * n_tiles;
     const int row_base = tile_m * R_BM + 128 * grp + lrow;
@@ -954,53 +958,18 @@ extern "C" int vx_gemm_ring_set_trace(void* dev_buf) {
 }
 #endif
 
-static int g_ring_mode = -1;   // VX_GEMM_RING: 0 off, 1 short K only, 2 (default) every eligible shape
-
-static int g_fp8_ring = -1;    // VX_FP8_RING / vx_gemm_set_fp8_ring: fp8 operands on the ring kernel (opt-in, see below)
-
-extern "C" int vx_gemm_set_fp8_ring(int on) {
-  if (on < -1 || on > 1) {
-    vx_set_error("vx_gemm_set_fp8_ring: %d outside [-1, 1]", on);
-    return VX_ERR_INVALID;
-  }
-  g_fp8_ring = on;
-  return VX_OK;
-}
-
-extern "C" int vx_gemm_set_ring_mode(int mode) {
-  if (mode < 0 || mode > 2) {
-    vx_set_error("vx_gemm_set_ring_mode: mode %d outside [0, 2]", mode);
-    return VX_ERR_INVALID;
-  }
-  g_ring_mode = mode;
-  return VX_OK;
-}
-
-static int ring_mode() {
-  int& mode = g_ring_mode;
-  if (mode < 0) {
-    const char* e = getenv("VX_GEMM_RING");
-    mode = (e && !strcmp(e, "0")) ? 0 : ((e && !strcmp(e, "1")) ? 1 : 2);
-  }
-  return mode;
-}
-
-extern "C" int vx_gemm_get_ring_mode(void) { return ring_mode(); }
-
 bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
-  const int mode = ring_mode();
-  if (!mode || p.ring_hint < 0) return false;
+  // The kernel choice is a per-call fact (ABI 14): ring_hint < 0 = never; there is no process-wide mode any more (the
+  // A/B knobs VX_GEMM_RING / VX_FP8_RING live in the Python layer, which turns them into ring_hint values).
+  if (p.ring_hint < 0) return false;
   if (p.a_fp8) {
     // fp8 operands on the ring kernel: correct (tests/test_gpu_kernels.py::test_gemm_fp8_ring_vs_classic_tiles), but
     // its 8-register MFMA operand tuples push the 256-VGPR budget over (67-72 spilled registers in the K loop) and it
     // measures SLOWER than the classic fp8 tiles (287 vs 207 us at 294912 x 320 x 384; 768^2 clip 3.59 vs 3.92
-    // frames/s, profiles/r02d_*): off unless VX_FP8_RING=1 / vx_gemm_set_fp8_ring(1)
-    int& on = g_fp8_ring;
-    if (on < 0) {
-      const char* e = getenv("VX_FP8_RING");
-      on = e && !strcmp(e, "1");
-    }
-    if (!on || p.epi != VX_EPI_STORE || (p.k % 128) != 0 || p.kh != 1 || p.kw != 1 || p.a2 != nullptr) return false;
+    // frames/s, profiles/r02d_*): only on the explicit per-call request ring_hint == 3
+    if (p.ring_hint != 3 || p.epi != VX_EPI_STORE || (p.k % 128) != 0 || p.kh != 1 || p.kw != 1 || p.a2 != nullptr) return false;
+  } else if (p.ring_hint == 3) {
+    return false;
   }
   // ring_hint == 2: the cooperative two-way K split (gemm_ring_kernel<..., SK>; splitk == 2 + a ZEROED workspace of
   // vx_gemm_splitk_ws_bytes(m, n, 2) bytes).  Any other split-K request belongs to the classic tiles.
@@ -1032,8 +1001,8 @@ bool vx_gemm_ring_eligible(const vx_gemm_params& p) {
   // long K loops: an LDS-DMA copy issued beside the partner wave's MFMAs costs 2-3x one issued in a burst
   // (profiles/r01d_ring_ablation.txt).  Inside the model the ring kernel wins on every eligible shape (tap-innermost
   // K order: 89 % vs 57 % L2 hit rate, 6x less fabric traffic; next tile prefetched under the epilogue): 11.01 vs
-  // 10.64 frames/s.  VX_GEMM_RING=1 restricts it to K <= 1280, =0 disables it.
-  return mode == 2 || p.k <= 1280;
+  // 10.64 frames/s.
+  return true;
 }
 
 template <int EPI, bool RES, bool F8 = false, bool STATS = false, bool LNF = false, bool GNS = false, bool SK = false>

@@ -39,21 +39,6 @@ class TBlockParams(C.Structure):
     ]
 
 
-class Conv3Params(C.Structure):
-    """Mirror of `vx_conv3_params` (include/vexpress_hip.h)."""
-    _fields_ = [
-        ("x1", C.c_void_p), ("x2", C.c_void_p),
-        ("c1", C.c_int32), ("c2", C.c_int32), ("ldx1", C.c_int32), ("ldx2", C.c_int32),
-        ("frames", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
-        ("w_perm", C.c_void_p), ("n", C.c_int32),
-        ("ab", C.c_void_p), ("ab_ld", C.c_int32), ("silu", C.c_int32),
-        ("bias", C.c_void_p), ("rowbias", C.c_void_p), ("rowbias_ld", C.c_int32), ("rows_per_group", C.c_int32),
-        ("residual", C.c_void_p), ("ldr", C.c_int32),
-        ("out", C.c_void_p), ("ldc", C.c_int32),
-        ("gn_ws", C.c_void_p), ("gn_groups", C.c_int32), ("gn_hw", C.c_int32),
-    ]
-
-
 class GemmParams(C.Structure):
     """Mirror of `vx_gemm_params` (include/vexpress_hip.h).""" 
     _fields_ = [
@@ -83,6 +68,7 @@ class GemmParams(C.Structure):
         ("w_group_rows", C.c_int32),
         ("gn_ws", C.c_void_p), ("gn_groups", C.c_int32), ("gn_hw", C.c_int32),
         ("row_stats_parts", C.c_int32), ("ln_stats_parts", C.c_int32), ("ln_eps", C.c_float),
+        ("coop_epoch", C.c_int32),
     ]
 
 
@@ -134,9 +120,6 @@ def _load():
     lib.vx_ff_fused.argtypes = [C.POINTER(FfParams), vp]
     lib.vx_ff_pack_weights.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     lib.vx_tblock_fused.argtypes = [C.POINTER(TBlockParams), vp]
-    lib.vx_conv3x3_gn.argtypes = [C.POINTER(Conv3Params), vp]
-    lib.vx_conv3x3_gn_supported.argtypes = [C.POINTER(Conv3Params)]
-    lib.vx_groupnorm_scale_shift.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp, i32, vp, i32, vp]
     lib.vx_tblock_pack.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.vx_tblock_packed_bytes.argtypes = [i32]
     lib.vx_tblock_packed_bytes.restype = i64
@@ -160,8 +143,6 @@ def _load():
     lib.vx_ncfhw_to_nhwc.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     lib.vx_nhwc_to_ncfhw.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
     lib.vx_vae_postprocess.argtypes = [vp, i32, i32, i32, i32, vp, vp]
-    lib.vx_gemm_set_ring_mode.argtypes = [i32]
-    lib.vx_gemm_set_fp8_ring.argtypes = [i32]
     lib.vx_median3d.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
     lib.vx_wave_conv1d.argtypes = [vp, i32, vp, i32, i32, i32, vp, vp]
     for name in declared_symbols():
@@ -170,7 +151,7 @@ def _load():
                         "vx_gemm_splitk_ws_bytes", "vx_gemm_last_kernel", "vx_last_kernel", "vx_build_id",
                         "vx_tblock_packed_bytes"):
             fn.restype = i32
-    if lib.vx_abi_version() != 13:
+    if lib.vx_abi_version() != 14:
         raise ImportError("libvexpress_hip.so ABI version mismatch")
     return lib
 
@@ -208,7 +189,8 @@ def _build_identity():
     if os.environ.get("VX_LIBRARY"):
         # an explicitly chosen A/B build (tools/build_*_variants.sh link the product's stamped vx_api.o): never the product
         return "variant:" + os.path.basename(LIB_PATH)
-    if src == "unstamped":
+    if src == "unstamped" or len(src) != 16 or any(ch not in "0123456789abcdef" for ch in src):
+        # (an empty or malformed stamp - tools/lib_id.py failed inside make - is "unstamped" too, never "stale": ADVICE r05)
         return "unstamped:" + os.path.basename(LIB_PATH)
     disk = source_id()
     if disk is not None and disk != src:

@@ -509,7 +509,8 @@ def clear_caches():
     _FP8_W.clear()
     _FF_PACKED.clear()
     _TB_PACKED.clear()
-    _C3_W.clear()
+    _COOP_WS.clear()
+    _COOP_OK.clear()
 
 
 _ITEMS = [None]
@@ -532,10 +533,25 @@ class frame_rows:
         _FRAME_ROWS[0], _ITEMS[0] = self.prev
 
 
+# A/B knobs of the kernel choice.  They live HERE (ABI 14): the library has no process-wide mode any more, every vx_gemm call
+# carries its own choice in vx_gemm_params.ring_hint, so two pipelines in one process cannot race on a switch.
+#   RING_MODE (VX_GEMM_RING): 2 = the persistent ring-staged kernel for every eligible problem (product), 1 = only K <= 1280,
+#   0 = never (results then differ only by fp32 summation order: the ring kernel walks conv taps innermost)
+#   FP8_RING (VX_FP8_RING=1): fp8 operands on the persistent kernel (ring_hint = 3; measures slower than the classic fp8 tiles)
+RING_MODE = [int(os.environ.get("VX_GEMM_RING", "2")) if os.environ.get("VX_GEMM_RING", "2") in ("0", "1", "2") else 2]
+FP8_RING = [os.environ.get("VX_FP8_RING") == "1"]
+
+
+def _ring_off(k):
+    return RING_MODE[0] == 0 or (RING_MODE[0] == 1 and k > 1280)
+
+
 def _ring_hint(p):
     """vx_gemm_params.ring_hint from batch-independent facts: rows of ONE batch item (a 16-frame CFG half) and N.
     The ring kernel is chosen when a nominal CFG-pair launch (2 items) would have >= 192 tiles of 256 x 320 and an
     item is a whole number of 256-row tiles; without the frame_rows context the library decides by the launch size."""
+    if _ring_off(p.k):
+        return -1
     items = _ITEMS[0]
     if items is None or items <= 0 or p.m % items:
         return 0
@@ -556,7 +572,7 @@ def qk_on_ring(m, c):
     if not QK_RING[0] or items is None or items <= 0 or m % items or (2 * c) % 320 or c % 64:
         return False
     rows_item = m // items
-    return rows_item % 256 == 0 and (2 * rows_item // 256) * (2 * c // 320) >= 192 and _lib.vx_gemm_get_ring_mode() != 0
+    return rows_item % 256 == 0 and (2 * rows_item // 256) * (2 * c // 320) >= 192 and not _ring_off(c)
 
 
 def _splitk(p, geom, device, plain):
@@ -587,7 +603,17 @@ def _splitk(p, geom, device, plain):
 # the 128 x 160 tiles (A/B knob); COOP_MIN_K: shortest K that takes the split.
 RING_COOP = [os.environ.get("VX_RING_COOP", "1") != "0"]
 COOP_MIN_K = [int(os.environ.get("VX_RING_COOP_MIN_K", "8192"))]
-_COOP_WS = {}
+_COOP_WS = {}            # (device, stream, bytes) -> [zeroed workspace, epoch of its last launch]
+_COOP_OK = {}            # epilogue / geometry signature -> vx_gemm_ring_coop_ok (asked of the library once per signature)
+_COOP_EPOCH_MAX = (1 << 27) - 1
+
+
+def _coop_signature(p, rows_item):
+    """Every fact the decision reads (launches that share (rows_item, n, k) but differ in the epilogue decided
+    differently under one log key): the shape, the K chunking, the epilogue's operands and strides."""
+    return (rows_item, p.m, p.n, p.k, p.c1, p.c2, p.kh, p.kw, p.stride, p.lda1, p.lda2, p.ldc, p.ldr, bool(p.residual),
+            bool(p.ln_stats), bool(p.row_stats_out), p.row_stats_parts, p.w_group_rows, bool(p.rowbias), p.rowbias_ld,
+            p.rows_per_group, p.epi, p.out_f32, p.act)
 
 
 def ring_coop_applies(p):
@@ -596,7 +622,7 @@ def ring_coop_applies(p):
     Only where `_ring_hint` said "not the ring kernel" because a CFG pair has too few tiles: rows of an item a multiple of
     256, 96 <= tiles of the nominal pair < 192, K >= COOP_MIN_K; the kernel's own limits are asked of the library."""
     items = _ITEMS[0]
-    if items is None or items <= 0 or p.m % items:
+    if items is None or items <= 0 or p.m % items or _ring_off(p.k):
         return False
     rows_item = p.m // items
     if rows_item % 256 or p.n % 320:
@@ -604,23 +630,33 @@ def ring_coop_applies(p):
     tiles_pair = (2 * rows_item // 256) * (p.n // 320)
     if not 96 <= tiles_pair < 192:
         return False
+    sig = _coop_signature(p, rows_item)
+    lib_ok = _COOP_OK.get(sig)
+    if lib_ok is None and RING_COOP[0] and p.k >= COOP_MIN_K[0]:
+        lib_ok = _COOP_OK[sig] = bool(_lib.vx_gemm_ring_coop_ok(C.byref(p)))
     why = ("VX_RING_COOP=0" if not RING_COOP[0] else f"K below {COOP_MIN_K[0]}: break-even" if p.k < COOP_MIN_K[0] else
-           "" if _lib.vx_gemm_ring_coop_ok(C.byref(p)) else "the kernel's limits (epilogue / odd number of 64-channel chunks)")
-    # logged once per (rows of an item, N, K) like the one-launch blocks' decisions (bench.py: block_paths)
-    return _note_path("gemm_too_few_tiles", (("rows_item", rows_item), ("n", p.n), ("k", p.k)), not why,
+           "" if lib_ok else "the kernel's limits (epilogue / odd number of 64-channel chunks)")
+    # logged once per deciding signature like the one-launch blocks' decisions (bench.py: block_paths)
+    epi = ("+res" if p.residual else "") + ("+ln" if p.ln_stats else "") + ("+rowstats" if p.row_stats_out else "")
+    return _note_path("gemm_too_few_tiles", (("rows_item", rows_item), ("n", p.n), ("k", p.k), ("chunks", (p.c1 + p.c2) // 64),
+                                             ("epilogue", epi or "plain")), not why,
                       "persistent kernel, cooperative two-way K split" if not why else "128 x 160 tiles", why)
 
 
 def _ring_coop(p, device):
-    """Switch p over to the cooperative split (ring_hint = 2, splitk = 2, a zeroed workspace) when `ring_coop_applies`."""
+    """Switch p over to the cooperative split (ring_hint = 2, splitk = 2, the workspace and its next epoch) when
+    `ring_coop_applies`.  The rendezvous flags carry the launch's EPOCH (vx_gemm_params.coop_epoch, ABI 14) and are never
+    reset: a launch that lost a partner (bounded poll) or was aborted leaves nothing a later launch can mistake for its own
+    (with reset-to-zero flags one stale word poisoned every later launch of the process)."""
     if not ring_coop_applies(p):
         return False
     nbytes = int(_lib.vx_gemm_splitk_ws_bytes(p.m, p.n, 2))
     key = (device, _stream_key(device), nbytes)
-    ws = _COOP_WS.get(key)
-    if ws is None:
-        ws = _COOP_WS[key] = torch.zeros(nbytes, device=device, dtype=torch.uint8)   # flag words start (and stay) zero
-    p.splitk, p.splitk_ws, p.ring_hint = 2, ws.data_ptr(), 2
+    ent = _COOP_WS.get(key)
+    if ent is None or ent[1] >= _COOP_EPOCH_MAX:
+        ent = _COOP_WS[key] = [torch.zeros(nbytes, device=device, dtype=torch.uint8), 0]   # epoch 0 = "never written"
+    ent[1] += 1
+    p.splitk, p.splitk_ws, p.ring_hint, p.coop_epoch = 2, ent[0].data_ptr(), 2, ent[1]
     return True
 
 
@@ -669,6 +705,8 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
         if ln is None:
             _splitk(p, geom, a.device, plain)
         p.ring_hint = _ring_hint(p)
+    elif FP8_RING[0]:
+        p.ring_hint = 3
     _set_ln(p, ln)
     if stats_out is not None:
         if stats_out.dtype != torch.float32 or not stats_out.is_contiguous() or out_f32 or \
@@ -927,12 +965,13 @@ def gn_fold_applies(m, hw, c, n):
     `_ring_hint`), a 256-row tile never straddles a frame, and the per-frame weight copies (frames x n x c) are cheaper
     to write than the normalised tensor (2 x m x c): c = 320 in practice (the 64x64 and 96x96 levels)."""
     items = _ITEMS[0]
-    geom = (("c", c), ("n", n), ("hw", hw))
+    # (every deciding fact is in the key: the rows of ONE item included - ADVICE r05)
+    geom = (("c", c), ("n", n), ("hw", hw), ("rows_item", m // items if items and items > 0 and m % items == 0 else None))
     folded, applied = "GroupNorm folded into per-frame weights (no normalised tensor)", "GroupNorm apply pass + GEMM"
     if not GN_FOLD[0] or items is None or items <= 0 or m % items or hw % 256 or n % 320 or c % 64:
         return _note_path("groupnorm_proj_in", geom, False, applied, "fold off or geometry not whole 256 x 320 tiles per frame")
-    if _lib.vx_gemm_get_ring_mode() == 0 or (c > 1280 and _lib.vx_gemm_get_ring_mode() == 1):
-        # the persistent kernel is switched off (A/B knob vx_gemm_set_ring_mode)
+    if _ring_off(c):
+        # the persistent kernel is switched off (A/B knob ops.RING_MODE)
         return _note_path("groupnorm_proj_in", geom, False, applied, "persistent kernel switched off")
     rows_item = m // items
     ok = rows_item % 256 == 0 and (2 * rows_item // 256) * (n // 320) >= 192 and n * 2 <= hw
@@ -973,117 +1012,6 @@ def groupnorm_fold_linear(ws, gamma, w, bias_beta, *, frames, hw, groups, eps, s
                                           _ptr(w), _ptr(bias_beta), n, _ptr(w_f), _ptr(b_f), _stream()),
             "vx_groupnorm_fold_linear")
     return w_f, b_f
-
-
-# GroupNorm + SiLU + 3x3 convolution of a resnet block as ONE pass over the raw tensor (csrc/vx_conv3.hip, round 5): the
-# normalised, zero-bordered copy that groupnorm(pad_hw=...) + gemm(3x3) went through is never written, and a tile's
-# activations cross the CU's L1 once per 32-channel chunk instead of nine times.  Correct (kernel, model and full-size
-# parity) but NOT faster than the two launches it replaces: 250 - 260 us against 220 + 34 us at the 64x64 level, whole path
-# -0.8 ... -1.5 % in same-box A/B (profiles/r05b ... r05g: the in-LDS normalisation lengthens the L slots of four of every
-# nine K-tiles by what the apply pass cost, and moved into the M slots its v_exp / v_rcp do not hide under the same
-# wave's MFMAs).  OFF by default; VX_CONV3_GN=1 turns it on.
-CONV3_GN = [os.environ.get("VX_CONV3_GN", "0") == "1"]
-_C3_W = {}
-C3_AB_LD = 1024
-
-
-def conv3_weight(w):
-    """[N, 9 C] conv weight with K = (ky, kx, c) -> the kernel's K order (32-channel chunk, tap, 32); cached per tensor."""
-    key = (w.data_ptr(), tuple(w.shape))
-    hit = _C3_W.get(key)
-    if hit is None:
-        n, k = w.shape
-        c = k // 9
-        wp = w.view(n, 9, c // 32, 32).permute(0, 2, 1, 3).reshape(n, k).contiguous()
-        hit = _C3_W[key] = (w, wp)                     # keep `w` alive: the key is its address
-    return hit[1]
-
-
-def _conv3_params(x1, x2, frames, H, W, n):
-    p = L.Conv3Params()
-    p.x1, p.c1, p.ldx1 = x1.data_ptr(), x1.shape[-1], x1.stride(-2)
-    if x2 is not None:
-        p.x2, p.c2, p.ldx2 = x2.data_ptr(), x2.shape[-1], x2.stride(-2)
-    p.frames, p.h, p.w, p.n, p.ab_ld = frames, H, W, n, C3_AB_LD
-    return p
-
-
-def conv3_gn_supported(H, W, c_in, n, c1=None):
-    """Geometries vx_conv3x3_gn takes (vx_conv3x3_gn_supported): W = 64 or 32 with whole 256-pixel tiles per frame, source
-    channel counts multiples of 32 summing to a multiple of 64 (<= 1024), output channels a multiple of 320."""
-    c1 = c_in if c1 is None else c1
-    return (W in (64, 32) and (H * W) % 256 == 0 and c1 % 32 == 0 and (c_in - c1) % 32 == 0 and c_in % 64 == 0
-            and c_in <= C3_AB_LD and n % 320 == 0)
-
-
-def conv3_gn_applies(frames, H, W, c_in, n, c1=None):
-    """Whether a resnet convolution runs on the fused GroupNorm + SiLU + 3x3 convolution kernel: the switch is on and the
-    geometry is supported - a function of the per-frame geometry and the channel counts only, never of the number of
-    frames in the launch."""
-    ok = CONV3_GN[0] and conv3_gn_supported(H, W, c_in, n, c1)
-    why = "" if ok else ("off by default (not faster than the two launches: VX_CONV3_GN=1 turns it on)" if not CONV3_GN[0] else
-                         "needs image width 64 or 32 (whole 256-pixel tiles), channel counts in 32s / 64s up to 1024, "
-                         "output channels in 320s")
-    return _note_path("resnet_conv3x3", (("h", H), ("w", W), ("c_in", c_in), ("n", n)), ok,
-                      "GroupNorm + SiLU applied in the convolution's A path (vx_conv3x3_gn)" if ok else
-                      "GroupNorm apply pass into a zero-bordered image + implicit-GEMM convolution", why)
-
-
-def groupnorm_scale_shift(ws, slices, gamma, beta, *, frames, hw, groups, eps):
-    """float32 [frames, 1024, 2] = (scale, shift) per frame and channel from GroupNorm partial sums (vx_groupnorm_scale_shift)."""
-    c = gamma.numel()
-    ab = torch.empty((frames, C3_AB_LD, 2), device=ws.device, dtype=torch.float32)
-    L.check(_lib.vx_groupnorm_scale_shift(_ptr(ws), int(slices), frames, hw, groups, float(eps), _ptr(gamma), _ptr(beta), c,
-                                          _ptr(ab), C3_AB_LD, _stream()), "vx_groupnorm_scale_shift")
-    return ab
-
-
-def conv3_gn(x1, gamma, beta, w, bias, *, frames, H, W, groups, eps, x2=None, silu=True, rowbias=None, rows_per_group=0,
-             residual=None, gn=None):
-    """out = residual + conv3x3_pad1(act(GroupNorm(x1 | x2))) + bias + rowbias, act = SiLU (silu=True): ResnetBlock3D's
-    norm -> SiLU -> conv (modules/resnet.py:220-223, :235-244) without the normalised intermediate.
-    x1: [frames, H*W, C1] (+ x2: [frames, H*W, C2], the skip concat); w: [N, 9 (C1 + C2)] with K = (ky, kx, c).
-    The statistics come from the producer of x1 when it left them (`gn_of`), else from vx_groupnorm_stats.
-    gn=(groups, hw): as in `gemm` - the epilogue leaves the next GroupNorm's partial sums on the returned tensor."""
-    _chk_bf16(x1, "x1")
-    if not x1.is_contiguous() or (x2 is not None and not x2.is_contiguous()):
-        raise ValueError("conv3_gn inputs must be contiguous")
-    hw = H * W
-    n = w.shape[0]
-    ws, slices = groupnorm_stats(x1, frames=frames, hw=hw, groups=groups, x2=x2)
-    ab = groupnorm_scale_shift(ws, slices, gamma, beta, frames=frames, hw=hw, groups=groups, eps=eps)
-    p = _conv3_params(x1, x2, frames, H, W, n)
-    wp = conv3_weight(w)
-    p.w_perm, p.ab, p.silu = wp.data_ptr(), ab.data_ptr(), int(bool(silu))
-    if bias is not None:
-        if bias.dtype != torch.float32:
-            raise TypeError("bias must be float32")
-        p.bias = bias.data_ptr()
-    if rowbias is not None:
-        if rowbias.dtype != torch.float32 or rowbias.stride(-1) != 1:
-            raise TypeError("rowbias must be float32 with contiguous columns")
-        p.rowbias, p.rowbias_ld, p.rows_per_group = rowbias.data_ptr(), rowbias.stride(0), rows_per_group
-    out = torch.empty((frames * hw, n), device=x1.device, dtype=BF16)
-    p.out, p.ldc = out.data_ptr(), n
-    if residual is not None:
-        _chk_bf16(residual, "residual")
-        p.residual, p.ldr = residual.data_ptr(), _row_stride(residual)[0]
-    gst = None
-    if gn is not None and GN_FUSED[0]:
-        g_groups, g_hw = gn
-        cg = n // g_groups if g_groups else 0
-        if g_groups > 0 and n % g_groups == 0 and (frames * hw) % g_hw == 0 and g_hw % 128 == 0 and cg and 80 % cg == 0:
-            slabs = g_hw // 128
-            gst = GnStats(torch.empty((frames * hw // g_hw, slabs, g_groups, 2), device=x1.device, dtype=torch.float32),
-                          slabs, g_groups, frames * hw // g_hw, g_hw, n)
-            p.gn_ws, p.gn_groups, p.gn_hw = gst.ws.data_ptr(), int(g_groups), int(g_hw)
-    cin = p.c1 + p.c2
-    # reads the raw rows once, the weights once, writes the output once (+ residual); 2 m n 9 cin FLOP
-    with _hbm_op("conv3_gn", 2 * (frames * hw * (cin + n * (2 if residual is not None else 1)) + n * 9 * cin),
-                 flops=2.0 * frames * hw * n * 9 * cin):
-        L.check(_lib.vx_conv3x3_gn(C.byref(p), _stream()), "vx_conv3x3_gn")
-    _set_gn(out, gst)
-    return out
 
 
 def layernorm(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_entries=1, out=None):
