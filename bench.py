@@ -32,7 +32,8 @@ block paths, the CPU workers) goes to the side file named by its `detail` key (`
                 AttnProcessor2_0 runs it) on the host cores, USING THE BOX: N worker processes pinned to disjoint sets of 8
                 physical cores (frames are independent), each one frame pair - a CFG UNet3D forward at 512^2 with a 2-frame
                 window (warmed at a quarter of the pixels) + one frame of VAE decode - extrapolated linearly (x8 frame pairs
-                x25 steps + x16 frames of decode per clip; N clips side by side); `cores` = N x 8, hard 40 s bound.  The
+                x25 steps + x16 frames of decode per clip; N clips side by side); `cores` = N x 8; the weights are built once
+                and shared copy-on-write by the forked workers; hard 30 s bound (workers report how far they got).  The
                 reference-module figure of SURVEY.md E6 (dev container) is in the side file beside it.
 """
 import argparse
@@ -67,7 +68,7 @@ def flop_per_frame(num_frames, windows, steps, scale, ctx=16):
 
 def _lib_sha():
     from v_express_amd import lib
-    return lib.LIB_SHA256
+    return lib.LIB_SHA256 + (":f16" if lib.ELEM[0] is torch.float16 else "")      # (committed profiles are of the bf16 build)
 
 
 def _symbol_forms(symbol):
@@ -153,6 +154,27 @@ def _core_cpus():
     return allowed[:max(1, len(allowed) // 2)] if len(allowed) >= 16 else allowed, len(allowed)
 
 
+def _cpu_quota():
+    """CPUs' worth of run time the container may use per unit of wall time (cgroup CFS quota), or None when unlimited.  The
+    GPU boxes show 256 logical CPUs and a quota of 16 (cpu.max = "1600000 100000", profiles/r06c_cpu_box_probe.txt): every
+    busy thread beyond 16 is throttled, which is why 128 threads were SLOWER than 16 in rounds 3-5 and why 16 pinned
+    8-thread workers did not get through a quarter-size warm-up in 30 s (r06b)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                                  # cgroup v2
+            q, per = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:                     # cgroup v1
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 CPU_WORKER_THREADS = 8     # threads per worker process = the core count the dev-container Tier-A figure was taken on
 
 
@@ -177,16 +199,18 @@ def _reader_banks_for(cfg, h, OU):
     return OU.reader_banks(banks)
 
 
-def cpu_worker(size, cpus, threads):
-    """One worker of the CPU leg (its own process, `python bench.py --cpu-worker`): pinned to `cpus`, `threads` intra-op
-    threads, the fp32 oracle (`oracle/`, a port of the reference path; attention through F.scaled_dot_product_attention as
-    AttnProcessor2_0 runs it) on ONE frame pair: CFG UNet3D forward at size x size with a 2-frame window - warmed by the same
-    forward at a quarter of the pixels (weights paged in, thread team and primitive caches up) - and one frame of VAE decode
-    (warmed the same way).  Prints one JSON line."""
+def cpu_leg(size, seconds_budget, max_workers=16):
+    """The CPU leg's own process (`python bench.py --cpu-leg`: no GPU state, nothing multi-threaded before the forks).  Builds
+    the fp32 weights ONCE on one thread (timing-only pool values), then forks N workers that share them copy-on-write; worker
+    i pins itself to its CPU_WORKER_THREADS physical cores (os.sched_setaffinity), starts its own thread team and runs the
+    fp32 oracle (`oracle/`, a port of the reference path; attention through F.scaled_dot_product_attention as
+    AttnProcessor2_0 runs it) on ONE frame pair: a CFG UNet3D forward at size x size with a 2-frame window - warmed by the
+    same forward at a quarter of the pixels - and one frame of VAE decode (warmed the same way).  Workers report every stage
+    through a pipe, so a worker killed at the deadline still says how far it got.  Prints one JSON object."""
+    import select
+    import signal
     t_all = time.time()
-    if cpus and hasattr(os, "sched_setaffinity"):
-        os.sched_setaffinity(0, cpus)
-    torch.set_num_threads(threads)
+    torch.set_num_threads(1)
     import oracle
     from oracle import leaf as OLF
     from oracle import unet as OU
@@ -195,90 +219,141 @@ def cpu_worker(size, cpus, threads):
     OLF.USE_SDPA[0] = True
     cfg, ocfg = synth.UNetConfig(), oracle.UNetConfig()
     f = 2
-    t0 = time.time()
     sd3 = synth.unet3d_state_dict(cfg, timing_only=True)
     sdv = synth.vae_decoder_state_dict(synth.VaeConfig(), timing_only=True)
-    weights_s = time.time() - t0
+    weights_s = time.time() - t_all
+    cores, logical = _core_cpus()
+    quota = _cpu_quota()
+    usable = len(cores) if quota is None else max(1, min(len(cores), int(quota)))     # what the container may keep busy
+    T = min(CPU_WORKER_THREADS, usable)
+    n = max(1, min(usable // T, max_workers))
 
-    def fwd(h):
-        inp = synth.synthetic_inputs(cfg, f, h, h)
-        rb = _reader_banks_for(cfg, h, OU)
-        x = inp["latents"].repeat(2, 1, 1, 1, 1)
-        ehs = inp["audio_embeddings"].reshape(-1, 5, 768)
-        t0 = time.time()
-        OU.unet3d_forward(sd3, ocfg, x, 519, ehs, inp["kps_features"], rb, 0.95, 3.0)
-        return time.time() - t0, inp
+    def worker(i, wfd):
+        def say(**kw):
+            os.write(wfd, (json.dumps(dict(worker=i, **kw)) + "\n").encode())
+        cpus = cores[i * T:(i + 1) * T]
+        if hasattr(os, "sched_setaffinity"):
+            os.sched_setaffinity(0, cpus)
+        torch.set_num_threads(T)
 
-    with torch.no_grad():
-        warm_s, _ = fwd(size // 16)
-        unet_s, inp = fwd(size // 8)
-        z = inp["latents"][0, :, :1].permute(1, 0, 2, 3).contiguous()
-        OV.vae_decode(sdv, oracle.VaeConfig(), z[:, :, :size // 16, :size // 16].contiguous())     # warm
-        t0 = time.time()
-        OV.vae_decode(sdv, oracle.VaeConfig(), z)
-        vae_s = time.time() - t0
-    print(json.dumps(dict(unet_forward_s=unet_s, vae_frame_s=vae_s, warm_s=warm_s, weights_s=weights_s, frames=f,
-                          threads=threads, cpus=list(cpus or []), total_s=time.time() - t_all)))
+        def fwd(h):
+            inp = synth.synthetic_inputs(cfg, f, h, h)
+            rb = _reader_banks_for(cfg, h, OU)
+            x = inp["latents"].repeat(2, 1, 1, 1, 1)
+            ehs = inp["audio_embeddings"].reshape(-1, 5, 768)
+            t0 = time.time()
+            OU.unet3d_forward(sd3, ocfg, x, 519, ehs, inp["kps_features"], rb, 0.95, 3.0)
+            return time.time() - t0, inp
+        with torch.no_grad():
+            warm_s, _ = fwd(size // 16)
+            say(stage="warm", warm_s=warm_s)
+            unet_s, inp = fwd(size // 8)
+            say(stage="unet", unet_forward_s=unet_s)
+            z = inp["latents"][0, :, :1].permute(1, 0, 2, 3).contiguous()
+            OV.vae_decode(sdv, oracle.VaeConfig(), z[:, :, :size // 16, :size // 16].contiguous())     # warm
+            t0 = time.time()
+            OV.vae_decode(sdv, oracle.VaeConfig(), z)
+            say(stage="done", vae_frame_s=time.time() - t0, cpus=cpus)
+
+    pids, fds = {}, {}
+    for i in range(n):
+        r, w = os.pipe()
+        pid = os.fork()
+        if pid == 0:
+            os.close(r)
+            code = 0
+            try:
+                worker(i, w)
+            except BaseException as e:                                  # noqa: BLE001 - reported, the child must not return
+                os.write(w, (json.dumps(dict(worker=i, stage="error", error=repr(e)[:200])) + "\n").encode())
+                code = 1
+            os._exit(code)
+        os.close(w)
+        pids[i], fds[r] = pid, i
+    state = {i: dict(stage="started") for i in range(n)}
+    buf = {r: b"" for r in fds}
+    deadline = t_all + seconds_budget
+    open_fds = set(fds)
+    while open_fds and time.time() < deadline:
+        ready, _, _ = select.select(list(open_fds), [], [], max(0.05, min(1.0, deadline - time.time())))
+        for r in ready:
+            chunk = os.read(r, 65536)
+            if not chunk:
+                open_fds.discard(r)
+                continue
+            buf[r] += chunk
+            while b"\n" in buf[r]:
+                line, buf[r] = buf[r].split(b"\n", 1)
+                msg = json.loads(line)
+                state[msg.pop("worker")].update(msg)
+    killed = 0
+    for i, pid in pids.items():
+        if state[i].get("stage") not in ("done", "error"):
+            try:
+                os.kill(pid, signal.SIGKILL)
+                killed += 1
+            except ProcessLookupError:
+                pass
+        try:
+            os.waitpid(pid, 0)
+        except ChildProcessError:
+            pass
+    print(json.dumps(dict(workers=[dict(worker=i, **state[i]) for i in range(n)], killed=killed, started=n, threads=T,
+                          weights_s=weights_s, physical_cores=len(cores), host_cpus=logical, cpu_quota=quota, frames=f,
+                          leg_process_s=time.time() - t_all)))
 
 
 def cpu_baseline(size, seconds_budget, max_workers=16):
-    """The reference path's port (`oracle/`) on the host cores, using the box: N independent worker
-    processes, each pinned to its own CPU_WORKER_THREADS physical cores (os.sched_setaffinity; frames of a window are
-    independent work, so N frame pairs run side by side), every worker one frame pair - see cpu_worker.  Whole-box figure:
-    N workers finish N x 2 frame-forwards in the mean worker time, so a 16-frame clip of 25 steps + decode takes
-    clip_s = mean(unet_s) x 8 x 25 + mean(vae_s) x 16 per worker and the box delivers N clips in that time.  Hard bound:
-    workers still running `seconds_budget` + 10 s after the start are killed and the leg reports what finished."""
+    """The reference path's port (`oracle/`) on the host cores, using the box: cpu_leg in its own
+    process - N forked workers pinned to disjoint sets of CPU_WORKER_THREADS physical cores (frames of a window are independent
+    work, so N frame pairs run side by side), every worker one frame pair.  Whole-box figure: N workers finish N x 2
+    frame-forwards in the mean worker time, so a 16-frame clip of 25 steps + decode takes clip_s = mean(unet_s) x 8 x 25 +
+    mean(vae_s) x 16 per worker and the box delivers N clips in that time.  Hard bound: the leg kills its workers
+    `seconds_budget` after its own start and reports how far each one got."""
     import subprocess
     t_all = time.time()
-    cores, logical = _core_cpus()
-    T = min(CPU_WORKER_THREADS, len(cores))
-    n = max(1, min(len(cores) // T, max_workers))
-    try:                                   # ~7 GB per worker (fp32 weights + activations): stay under half the free memory
-        with open("/proc/meminfo") as fm:
-            avail_kb = next(int(ln.split()[1]) for ln in fm if ln.startswith("MemAvailable"))
-        n = max(1, min(n, int(avail_kb / 1e6 / 2 / 7)))
-    except (OSError, StopIteration, ValueError):
-        pass
-    env = dict(os.environ, OMP_NUM_THREADS=str(T), MKL_NUM_THREADS=str(T), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    procs = []
-    for i in range(n):
-        cpus = cores[i * T:(i + 1) * T]
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "--size", str(size),
-                                       "--cpu-list", ",".join(map(str, cpus)), "--cpu-threads", str(T)],
-                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env))
-    deadline = t_all + seconds_budget + 10
-    done, killed = [], 0
-    for pr in procs:
-        try:
-            out, _ = pr.communicate(timeout=max(0.1, deadline - time.time()))
-            rows = [ln for ln in out.splitlines() if ln.startswith("{")]
-            if pr.returncode == 0 and rows:
-                done.append(json.loads(rows[-1]))
-        except subprocess.TimeoutExpired:
-            pr.kill()
-            pr.communicate()
-            killed += 1
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("OMP_NUM_THREADS", None)
+    res = None
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", "--size", str(size), "--cpu-budget",
+                            str(seconds_budget), "--cpu-max-workers", str(max_workers)], capture_output=True, text=True,
+                           timeout=seconds_budget + 30, env=env)
+        rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        res = json.loads(rows[-1]) if rows else None
+        err = r.stderr[-300:]
+    except subprocess.TimeoutExpired:
+        err = "the CPU leg's process did not return"
     leg_s = time.time() - t_all
+    if res is None:
+        return dict(value=None, unit="frames/s", cores=0, kind="port", sample=f"oracle fp32 CPU leg failed: {err}", cpu_leg_s=leg_s)
+    T, n = res["threads"], res["started"]
+    done = [w for w in res["workers"] if w.get("stage") == "done"]
+    common = dict(unit="frames/s", kind="port", threads_per_process=T, workers=res["workers"], workers_killed=res["killed"],
+                  workers_started=n, weights_s=res["weights_s"], physical_cores=res["physical_cores"],
+                  host_cpus=res["host_cpus"], cpu_quota=res.get("cpu_quota"), cpu_leg_s=leg_s,
+                  reference_modules_dev_container=dict(
+                      value=16.0 / (25 * 78.1 + 16 * 5.5), cores=8, unet_forward_s=78.1, unet_core_seconds_per_frame=78.1 * 8 / 16,
+                      note="SURVEY.md E6: the reference's own modules (fp32, f=16 CFG forward) on the 8 cores of the dev "
+                           "container, measured once during the survey; not re-measured on the GPU box"))
     if not done:
-        return dict(value=None, unit="frames/s", cores=n * T, kind="port", processes=n, threads_per_process=T,
-                    sample=f"oracle fp32 CPU leg: no worker of {n} finished within {seconds_budget + 10} s", cpu_leg_s=leg_s)
-    f = done[0]["frames"]
+        stages = sorted({w.get("stage", "?") for w in res["workers"]})
+        return dict(value=None, cores=n * T, processes=n,
+                    sample=f"oracle fp32 CPU leg: no worker of {n} finished within {seconds_budget} s (stages reached: {stages})",
+                    **common)
+    f = res["frames"]
     unet_s = sum(d["unet_forward_s"] for d in done) / len(done)
     vae_s = sum(d["vae_frame_s"] for d in done) / len(done)
     clip_s = unet_s * (16 / f) * 25 + vae_s * 16
     nd = len(done)
-    return dict(value=nd * 16.0 / clip_s, unit="frames/s", cores=nd * T, kind="port", processes=nd, threads_per_process=T,
-                sample=(f"oracle/ (fp32 port of the reference path, SDPA attention) in {nd} pinned processes x {T} threads, "
+    lim = (f" (the container's CPU quota: {res['cpu_quota']:g} of {res['host_cpus']} visible CPUs)"
+           if res.get("cpu_quota") else "")
+    return dict(value=nd * 16.0 / clip_s, cores=nd * T, processes=nd,
+                sample=(f"oracle/ (fp32 port of the reference path, SDPA attention) in {nd} pinned processes x {T} threads{lim}, "
                         f"each: CFG UNet3D forward {size}x{size} f={f} ({unet_s:.1f} s mean, warmed at quarter size) + 1 frame "
                         f"VAE decode ({vae_s:.1f} s); per process x{16 // f} frame pairs x25 steps + x16 frames = {clip_s:.0f} s "
                         f"per 16-frame clip, {nd} clips side by side"),
-                unet_forward_s=unet_s, vae_frame_s=vae_s, workers=done, workers_killed=killed, workers_started=n,
-                physical_cores=len(cores), host_cpus=logical,
-                unet_core_seconds_per_frame=unet_s * T / f, cpu_leg_s=leg_s,
-                reference_modules_dev_container=dict(
-                    value=16.0 / (25 * 78.1 + 16 * 5.5), cores=8, unet_forward_s=78.1, unet_core_seconds_per_frame=78.1 * 8 / 16,
-                    note="SURVEY.md E6: the reference's own modules (fp32, f=16 CFG forward) on the 8 cores of the dev "
-                         "container, measured once during the survey; not re-measured on the GPU box"))
+                unet_forward_s=unet_s, vae_frame_s=vae_s, unet_core_seconds_per_frame=unet_s * T / f, **common)
 
 
 def kernel_rate(v):
@@ -361,7 +436,7 @@ def compact_line(result, detail_path=None):
     cb = result.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "processes", "threads_per_process",
-                                          "unet_core_seconds_per_frame", "cpu_leg_s"))
+                                          "cpu_quota", "host_cpus", "unet_core_seconds_per_frame", "cpu_leg_s"))
         line["speedup_vs_cpu"] = result.get("speedup_vs_cpu")
     if result.get("n_gpus", 1) > 1:
         pr = result.get("per_rank")
@@ -399,18 +474,21 @@ def main():
                     help="N>1: skip rank 0's single-GPU run of the same clip after the timed region")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[4]: attention q/k/v/out projections on the fp8 (e4m3) MFMA GEMM")
+    ap.add_argument("--dtype", choices=("bf16", "fp16"), default="bf16",
+                    help="16-bit element type of the whole path: bf16 (BASELINE configs[1]) or fp16, the reference's own default "
+                         "(inference.py:44) - the IEEE-half build of the kernel library, same kernels, same MFMA rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)     # one worker of the CPU leg (cpu_worker)
-    ap.add_argument("--cpu-list", default="", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-threads", type=int, default=CPU_WORKER_THREADS, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-leg", action="store_true", help=argparse.SUPPRESS)        # the CPU leg's own process (cpu_leg)
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-max-workers", type=int, default=16, help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-shapes", default="", help="write the per-shape vx_gemm timing table of the roofline leg here")
     ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
                     help="side file for the full tables (ranking, per-kernel, HBM kernels, block paths, CPU-leg probes)")
     args = ap.parse_args()
 
-    if args.cpu_worker:
-        cpu_worker(args.size, [int(c) for c in args.cpu_list.split(",") if c], args.cpu_threads)
+    if args.cpu_leg:
+        cpu_leg(args.size, args.cpu_budget, args.cpu_max_workers)
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -447,9 +525,13 @@ def main():
             dist.init_process_group(backend)
 
     import v_express_amd as vx
-    from v_express_amd import ops, synth
+    from v_express_amd import lib as vxlib, ops, synth
     from v_express_amd.context import uniform
 
+    elem = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    vxlib.ELEM[0] = elem                        # a bench process runs ONE element type: every ops call below uses its library
+    if elem is torch.float16:
+        vxlib.lib_f16()
     cfg, vcfg = synth.UNetConfig(), synth.VaeConfig()
     ctx, ovl = args.context_frames, args.context_overlap
     if args.frames:
@@ -463,16 +545,15 @@ def main():
     scaling = "weak" if (world > 1 and args.scaling == "weak" and not args.frames) else "strong"
     h = w = args.size // 8
     t_build = time.time()
-    unet = vx.UNet3DConditionModel(cfg).to(dev)
-    refnet = vx.UNet2DConditionModel(cfg).to(dev)
-    vae = vx.AutoencoderKLDecoder(vcfg).to(dev)
-    unet.load_state_dict(synth.unet3d_state_dict(cfg, seed=42, device=dev, dtype=torch.bfloat16, draw_on_device=True))
+    unet = vx.UNet3DConditionModel(cfg).to(dev).to(elem)
+    refnet = vx.UNet2DConditionModel(cfg).to(dev).to(elem)
+    vae = vx.AutoencoderKLDecoder(vcfg).to(dev).to(elem)
+    unet.load_state_dict(synth.unet3d_state_dict(cfg, seed=42, device=dev, dtype=elem, draw_on_device=True))
     unet.release_raw_weights()
     unet.fp8_projections = bool(args.fp8)
-    refnet.load_state_dict(synth.refnet_state_dict(cfg, seed=43, device=dev, dtype=torch.bfloat16, draw_on_device=True))
+    refnet.load_state_dict(synth.refnet_state_dict(cfg, seed=43, device=dev, dtype=elem, draw_on_device=True))
     refnet.release_raw_weights()
-    vae.load_state_dict(synth.vae_decoder_state_dict(vcfg, seed=44, device=dev, dtype=torch.bfloat16,
-                                                     draw_on_device=True))
+    vae.load_state_dict(synth.vae_decoder_state_dict(vcfg, seed=44, device=dev, dtype=elem, draw_on_device=True))
     vae._prepared()
     sched = vx.DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
                              steps_offset=1, prediction_type="v_prediction", rescale_betas_zero_snr=True,
@@ -501,7 +582,7 @@ def main():
                            closed_loop=False))
     c0 = cfg.block_out_channels[0]
     kps_tokens = ops.ncfhw_to_nhwc(inp["kps_features"], c0).view(2, F, h * w, c0)
-    audio = inp["audio_embeddings"].to(torch.bfloat16).contiguous()
+    audio = inp["audio_embeddings"].to(elem).contiguous()
 
     def one_clip():
         lat = inp["latents"].clone()
@@ -544,7 +625,7 @@ def main():
         "metric": f"decoded frames/sec at {args.size}x{args.size}, {args.ddim_steps} DDIM steps", "value": fps, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
-        "vs_baseline": None, "dtype": "fp8-proj/bf16" if args.fp8 else "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": ("fp8-proj/" if args.fp8 else "") + args.dtype, "data": "synthetic",
         "config": {"workload": (f"{args.size}x{args.size}, {F} frames ({len(windows)} window(s) of {ctx}, overlap {ovl}), "
                                 f"{args.ddim_steps} DDIM steps, CFG 3.5, random-init UNet3D + ReferenceNet banks + "
                                 "sd-vae-ft-mse decode"),

@@ -4,8 +4,11 @@
  * PyTorch aten ops.  Each entry point below replaces the aten call sites named in
  * its comment (paths relative to the reference root).  Conventions:
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocates all buffers, incl. workspaces);
- *   - activations are bfloat16, channels-last tokens:  [(b f), H*W, C]  ==  NHWC per frame;
- *   - norm affine parameters, biases and statistics are float32; weights are bfloat16 [N, K], K contiguous,
+ *   - activations are 16-bit, channels-last tokens:  [(b f), H*W, C]  ==  NHWC per frame.  The element type is a
+ *     property of the LIBRARY (vx_element_type()): libvexpress_hip.so computes on bfloat16, libvexpress_hip_f16.so - the same
+ *     sources compiled with -DVX_ELEM_F16, the same ABI - on IEEE half, the reference's default `--dtype fp16`
+ *     (inference.py:44,150-151); both accumulate in float32.  "bf16" in the comments below = "the library's element";
+ *   - norm affine parameters, biases and statistics are float32; weights are 16-bit elements [N, K], K contiguous,
  *     conv weights pre-laid-out as [Cout][ky][kx][Cin];
  *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*); no host threads, no
  *     device-wide synchronisation, no global mutable state except the last-error string;
@@ -27,6 +30,8 @@ int vx_abi_version(void);
  * csrc/Makefile ("unstamped|" for a library built any other way).  The Python binding compares the hash with the sources
  * on disk (v_express_amd.lib.source_id): measurements under profiles/ are keyed by it. */
 const char* vx_build_id(void);
+/* "bf16" or "f16": the 16-bit element type this binary stores activations / weights in and feeds the MFMAs with (ABI 14) */
+const char* vx_element_type(void);
 /* device properties snapshot: out[0]=CU count, out[1]=LDS bytes per block, out[2]=wavefront size, out[3]=clock kHz */
 int vx_device_info(int device, int* out4);
 

@@ -90,18 +90,10 @@ def unet_and_reference_net_from_files(tmp_path, layout, device):
         writer.clear()
     assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0
     assert torch.equal(outs[0], outs[1]), "the file-loaded UNet3D / ReferenceNet differ from the load_state_dict ones"
-    # the reference's default dtype (inference.py:44): accepted as an I/O dtype with a warning, bf16 compute
-    with pytest.warns(UserWarning) if not module_base._FP16_WARNED[0] else contextlib.nullcontext():
-        r16 = checkpoints.load_reference_net(str(tmp_path / "config.json"), str(tmp_path / "reference_net.bin"),
-                                             dtype=torch.float16, device=device)
-    assert r16.dtype == torch.float16
-    os.environ["VX_STRICT_FP16"] = "1"
-    try:
-        with pytest.raises(NotImplementedError):
-            checkpoints.load_reference_net(str(tmp_path / "config.json"), str(tmp_path / "reference_net.bin"),
-                                           dtype=torch.float16, device=device)
-    finally:
-        del os.environ["VX_STRICT_FP16"]
+    # the reference's default dtype (inference.py:44): a compute dtype since round 6 (the IEEE-half build of the library)
+    r16 = checkpoints.load_reference_net(str(tmp_path / "config.json"), str(tmp_path / "reference_net.bin"),
+                                         dtype=torch.float16, device=device)
+    assert r16.dtype == torch.float16 and r16._elem == torch.float16
 
 
 def vae_guider_and_audio_projection_from_files(tmp_path, device):

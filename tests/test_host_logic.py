@@ -554,35 +554,67 @@ def test_bench_refuses_a_world_size_that_differs_from_gpus(tmp_path):
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr), r.stdout[-500:] + r.stderr[-500:]
 
 
-def test_float16_is_an_io_dtype_and_device_spellings_compare_equal(monkeypatch):
-    """Round-3 boundary items (reference inference.py:44,150-151: `--dtype fp16` is the default and every model gets
-    `.to(dtype=dtype, device=device)`): float16 is accepted as an I/O dtype with ONE warning per process, `.half()` too,
-    VX_STRICT_FP16=1 restores the NotImplementedError; 'cuda' and 'cuda:<current>' are the same device for `.to()`."""
-    import warnings
+def test_float16_is_a_compute_dtype_and_device_spellings_compare_equal():
+    """Reference inference.py:44,150-151: `--dtype fp16` is the default and every model gets `.to(dtype=dtype, device=device)`.
+    Round 6: float16 is a COMPUTE dtype - a float16 model runs the IEEE-half build of the kernel library
+    (libvexpress_hip_f16.so: same sources, -DVX_ELEM_F16, same ABI), a bfloat16 / float32 model the bfloat16 one; every model
+    entry point is wrapped to run under its element type; changing the element type after the device layouts were built
+    rebuilds them from the source tensors (or fails loudly when those were released); 'cuda' and 'cuda:<current>' are the
+    same device for `.to()`."""
+    import ctypes
     import v_express_amd as vx
-    from v_express_amd import module_base as MB
-    monkeypatch.setattr(MB, "_FP16_WARNED", [False])
+    from v_express_amd import lib as L, module_base as MB, ops
     cfgd = dict(block_out_channels=[64, 128, 256, 256], attention_head_dim=8, cross_attention_dim=768)
     unet = vx.UNet3DConditionModel.from_config_2d(cfgd, dict(use_motion_module=True))
-    with pytest.warns(UserWarning, match="bfloat16"):
-        unet.to(dtype=torch.float16, device="cpu")
-    assert unet.dtype == torch.float16
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")                    # the second request must stay silent
-        unet.half()
-        vx.UNet2DConditionModel.from_config(cfgd).to(torch.float16)
-    monkeypatch.setenv("VX_STRICT_FP16", "1")
-    with pytest.raises(NotImplementedError):
-        unet.to(torch.float16)
-    monkeypatch.delenv("VX_STRICT_FP16")
+    assert unet.dtype == torch.bfloat16 and unet._elem == torch.bfloat16
+    unet.to(dtype=torch.float16, device="cpu")
+    assert unet.dtype == torch.float16 and unet._elem == torch.float16
+    assert unet.half()._elem == torch.float16 and unet.to(torch.float32)._elem == torch.bfloat16      # fp32: I/O dtype only
+    assert vx.UNet2DConditionModel.from_config(cfgd).to(torch.float16)._elem == torch.float16
     with pytest.raises(TypeError):
         unet.to(torch.float64)
+    # both libraries load, export every declared symbol, agree on the ABI and on the sources they were built from
+    l16 = L.lib_f16()
+    assert l16.vx_element_type() == b"f16" and L.lib.vx_element_type() == b"bf16"
+    assert l16.vx_abi_version() == L.lib.vx_abi_version() == 14 and l16.vx_build_id() == L.lib.vx_build_id()
+    assert all(hasattr(l16, sym) for sym in L.declared_symbols())
+    # the element type in force selects library and allocation dtype, and nests
+    assert L.current() is L.lib and ops.BF16 is torch.bfloat16
+    with L.element_type(torch.float16):
+        assert L.current() is l16 and ops.BF16 is torch.float16 and ops._lib.vx_element_type() == b"f16"
+        with L.element_type(torch.bfloat16):
+            assert L.current() is L.lib
+        assert L.current() is l16
+    assert L.current() is L.lib
+    with pytest.raises(TypeError):
+        L.element_type(torch.float32)
+    # model entry points run under the model's element type (wrapped once per class)
+    seen = []
+
+    class Probe(MB.DeviceModule):
+        def forward(self):
+            seen.append(L.ELEM[0])
+            return self._prepared()
+
+        def _prepared(self):
+            seen.append(L.ELEM[0])
+    pr = Probe().to(torch.float16)
+    pr.forward()
+    assert seen == [torch.float16, torch.float16] and L.ELEM[0] is torch.bfloat16
+    pr._P = object()
+    pr.to(torch.bfloat16)
+    assert pr._P is None                                  # element type changed: layouts rebuilt at the next call
+    pr._released = True
+    with pytest.raises(RuntimeError):
+        pr.to(torch.float16)                              # ... which needs the source tensors
     assert MB._norm_device("cuda") == MB._norm_device("cuda:0") == MB._norm_device(0) == torch.device("cuda", 0)
+    unet = vx.UNet3DConditionModel.from_config_2d(cfgd, dict(use_motion_module=True))
     unet.to("cuda")
     unet._released = True                                 # after release_raw_weights() a real move must fail ...
     unet.to("cuda:0")                                     # ... the other spelling of the same GPU must not
     with pytest.raises(RuntimeError):
         unet.to("cpu")
+    del ctypes
 
 
 def test_gelu_tail_polynomial_of_the_kernels_matches_erf_gelu():

@@ -7,6 +7,7 @@
 #
 #   box      <tag>                                  GPU / host identity of the box (clocks, CU count, cores)
 #   tests    <tag> [-k expression] [file ...]       pytest -m gpu of the given files (default: all of tests/), summary kept
+#   tests16  <tag> [-k expression]                  tests/test_gpu_kernels.py with VX_TEST_ELEM=f16 (IEEE-half library) + tests/test_gpu_f16.py
 #   smoke    <tag>                                  __graft_entry__.smoke()
 #   bench    <tag> [bench.py flags ...]             one bench line -> <tag>_bench.json (+ per-shape GEMM table)
 #   ab       <tag> <ENVVAR> <a> <b> [reps] [bench flags ...]   same-box A/B of an environment knob, interleaved reps
@@ -44,6 +45,13 @@ tests)
   echo "pytest exit $?" >> $OUT/${T}_pytest_gpu.log
   grep -E "^\[|passed|failed|rror|assert|pytest exit" $OUT/${T}_pytest_gpu.log | tail -60 > $OUT/${T}_pytest_gpu_summary.log
   tail -4 $OUT/${T}_pytest_gpu_summary.log ;;
+tests16)
+  # the whole kernel test file against the IEEE-half build (libvexpress_hip_f16.so), tolerances 8x tighter + the always-on f16 cases
+  K=""; if [ "$1" = "-k" ]; then K="$2"; shift 2; fi
+  VX_TEST_ELEM=f16 timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_f16.py -m gpu -q -s --tb=short -p no:cacheprovider ${K:+-k "$K"} > $OUT/${T}_pytest_f16.log 2>&1
+  echo "pytest exit $?" >> $OUT/${T}_pytest_f16.log
+  grep -E "^\[|passed|failed|rror|assert|pytest exit" $OUT/${T}_pytest_f16.log | tail -80 > $OUT/${T}_pytest_f16_summary.log
+  tail -4 $OUT/${T}_pytest_f16_summary.log ;;
 smoke)
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/${T}_smoke.log 2>&1; tail -2 $OUT/${T}_smoke.log ;;
 bench)

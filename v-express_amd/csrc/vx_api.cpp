@@ -38,6 +38,13 @@ extern "C" int vx_abi_version(void) { return VX_ABI_VERSION; }
 #endif
 extern "C" const char* vx_build_id(void) { return VX_BUILD_SRC_ID "|" VX_BUILD_DEFS; }
 
+// the 16-bit element type this binary computes on (vx_common.h: one set of sources, two libraries)
+#ifdef VX_ELEM_F16
+extern "C" const char* vx_element_type(void) { return "f16"; }
+#else
+extern "C" const char* vx_element_type(void) { return "bf16"; }
+#endif
+
 extern "C" int vx_device_info(int device, int* out4) {
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
       }
       ss = wave_xor_sum(ss, 16);
       ss = wave_xor_sum(ss, 32);
-      mfix[qt] = p.c * sqrtf(ss) * p.kmax[kvb * p.heads + h];
+      mfix[qt] = p.c * sqrtf(ss) * p.kmax[kvb * p.heads + h] - VX_P_HEADROOM;
     }
   }
 
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
     vlds[s] = vs + v_lds_off(row, j);
     if (!vval[s] && row < DT * 16)
       *reinterpret_cast<uint4*>(vlds[s]) = (ONES && row == p.d)
-                                               ? make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u)
+                                               ? make_uint4(VX_E16_ONE2, VX_E16_ONE2, VX_E16_ONE2, VX_E16_ONE2)
                                                : make_uint4(0, 0, 0, 0);
   }
   const uint32_t kstep = 64u * (uint32_t)p.ldk;   // elements per key tile
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const AttnParams p) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       const float l = row_sum(qt);
-      bad |= (q0 + 16 * qt + i < p.n_q) && !(l >= 7.8886e-31f);   // 2^-100; also catches NaN
+      bad |= (q0 + 16 * qt + i < p.n_q) && !(l >= VX_P_MIN_ROWSUM(p.n_kv));   // (bf16: 2^-100); also catches NaN
     }
     if (__syncthreads_or(bad)) {   // block-uniform (the K / V^T staging is shared by the 4 waves): exact recompute
 #pragma unroll

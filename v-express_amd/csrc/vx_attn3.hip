@@ -69,12 +69,6 @@ __device__ __forceinline__ int a3_pi32(int r) {
 template <bool QK32>
 __device__ __forceinline__ int a3_pi(int r) { return QK32 ? a3_pi32(r) : a3_pi16(r); }
 
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0,
-                                                 0);
-}
-
 template <int NBUF, bool PIPE, bool UNIT, bool QK32 = false>   // UNIT: p.c == 1 (K already carries scale * log2 e)
 __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Params p) {
   static_assert(!PIPE || NBUF == 3, "the pipelined loop needs three stages");
@@ -97,12 +91,12 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
 
   // ---- constants in LDS: the ones / zero planes (K column d = 40 and d >= 48) and V^T rows 40..47 of every stage
   for (int idx = tid; idx < 128; idx += 256) {
-    *reinterpret_cast<uint4*>(smem + ONES + idx * 16) = idx < 64 ? make_uint4(0x3f80u, 0, 0, 0) : make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(smem + ONES + idx * 16) = idx < 64 ? make_uint4(VX_E16_ONE, 0, 0, 0) : make_uint4(0, 0, 0, 0);
   }
   for (int idx = tid; idx < NBUF * 64; idx += 256) {
     const int st = idx >> 6, r = 40 + ((idx >> 3) & 7), j = idx & 7;
     *reinterpret_cast<uint4*>(smem + st * A3_STAGE + A3_V + r * 128 + j * 16) =
-        r == 40 ? make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u) : make_uint4(0, 0, 0, 0);
+        r == 40 ? make_uint4(VX_E16_ONE2, VX_E16_ONE2, VX_E16_ONE2, VX_E16_ONE2) : make_uint4(0, 0, 0, 0);
   }
 
   // ---- DMA pieces of this wave: piece pw = wave + 4 s (s = 0..2, pw < 10); 0..3 = K chunks 0..3 of rows 16 pw..,
@@ -193,7 +187,7 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
     }
     ss = wave_xor_sum(ss, 16);
     ss = wave_xor_sum(ss, 32);
-    mfix[qt] = sqrtf(ss) * p.kmax[kvb * p.heads + h];
+    mfix[qt] = sqrtf(ss) * p.kmax[kvb * p.heads + h] - (UNIT ? VX_P_HEADROOM : VX_P_HEADROOM / p.c);
   }
   auto set_shift = [&](const float (&m)[A3_QT]) {
 #pragma unroll
@@ -222,7 +216,7 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
       qf32[st] = v;
     }
     ss = wave_xor_sum(ss, 32);
-    mfix32 = sqrtf(ss) * p.kmax[kvb * p.heads + h];
+    mfix32 = sqrtf(ss) * p.kmax[kvb * p.heads + h] - (UNIT ? VX_P_HEADROOM : VX_P_HEADROOM / p.c);
   }
   auto set_shift32 = [&](float m) {
     if (hi == 1) qf32[2] = make_uint4((uint32_t)f32_to_bf16(-m), 0, 0, 0);
@@ -467,7 +461,7 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void attn3_kernel(const Attn3Par
 #pragma unroll
   for (int qt = 0; qt < A3_QT; ++qt) {
     const float l = row_sum(qt);
-    bad |= (q0 + 16 * qt + i < p.n_q) && !(l >= 7.8886e-31f);   // 2^-100; also catches NaN
+    bad |= (q0 + 16 * qt + i < p.n_q) && !(l >= VX_P_MIN_ROWSUM(p.n_kv));   // (bf16: 2^-100); also catches NaN
   }
   if (__syncthreads_or(bad)) {   // block-uniform (the stages are shared by the 4 waves)
     const float zero[A3_QT] = {0.f, 0.f};

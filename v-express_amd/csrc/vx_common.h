@@ -5,9 +5,48 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef uint16_t bf16_t;   // raw bfloat16 bits
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+// ---- element type of the build.  ONE set of sources, two libraries: libvexpress_hip.so computes on bfloat16 storage,
+// libvexpress_hip_f16.so (-DVX_ELEM_F16) on IEEE half - the reference's own default (inference.py:44,150-151 `--dtype fp16`);
+// both accumulate in fp32.  `bf16_t` = the raw 16 bits of an element of the build (the name predates the second library);
+// every conversion, literal and matrix instruction that depends on the format goes through the helpers below.
+typedef uint16_t bf16_t;
+#ifdef VX_ELEM_F16
+#define VX_ELEM_NAME "f16"
+typedef _Float16 vx_e16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 vx_e16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 vx_e16x2_t __attribute__((ext_vector_type(2)));
+#define VX_E16_ONE 0x3c00u          // 1.0
+#define VX_E16_ONE2 0x3c003c00u
+#define VX_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define VX_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define VX_MFMA_16x16x16 __builtin_amdgcn_mfma_f32_16x16x16f16
+#else
+#define VX_ELEM_NAME "bf16"
+typedef __bf16 vx_e16x8_t __attribute__((ext_vector_type(8)));
+typedef short vx_e16x4_t __attribute__((ext_vector_type(4)));     // (the 16x16x16 bf16_1k builtin takes shorts)
+typedef __bf16 vx_e16x2_t __attribute__((ext_vector_type(2)));
+#define VX_E16_ONE 0x3f80u
+#define VX_E16_ONE2 0x3f803f80u
+#define VX_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define VX_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define VX_MFMA_16x16x16 __builtin_amdgcn_mfma_f32_16x16x16bf16_1k
+#endif
+typedef vx_e16x8_t bf16x8_t;
+// Bounded softmax (vx_attention_bounded: the shift is the Cauchy-Schwarz bound m >= max_j s_ij instead of the row maximum, so
+// every p = 2^(s - m) <= 1 and rows far under their bound are small numbers).  bfloat16 carries p down to 2^-126; IEEE half
+// does not: its build lowers the shift by VX_P_HEADROOM log2 units (p <= 2^14 < 65504; the factor is per row and cancels in
+// the normalisation) and sends a row to the exact recompute (true row maximum as the shift) as soon as rounding / flushing
+// its probabilities below half's normal range could cost more than half's own epsilon: absolute error <= n_kv 2^-25 against
+// a row sum l, i.e. l < n_kv 2^-14.  (bf16 build: l < 2^-100, as before.)
+#ifdef VX_ELEM_F16
+#define VX_P_HEADROOM 14.0f
+#define VX_P_MIN_ROWSUM(n_kv) ((float)(n_kv) * 6.103515625e-5f)
+#else
+#define VX_P_HEADROOM 0.0f
+#define VX_P_MIN_ROWSUM(n_kv) 7.8886e-31f   // 2^-100
+#endif
 
 #define VX_OK 0
 #define VX_ERR_INVALID (-1)
@@ -29,6 +68,15 @@ extern thread_local const char* g_vx_last_kernel;
     }                                           \
   } while (0)
 
+typedef float vx_f32x2_t __attribute__((ext_vector_type(2)));
+#ifdef VX_ELEM_F16
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// round-to-nearest-even (v_cvt_f16_f32), NaN preserved, |f| > 65504 -> inf
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+// the two elements of a packed pair (v_cvt_f32_f16, the high half through SDWA)
+__device__ __forceinline__ float e16_lo(uint32_t u) { return (float)__builtin_bit_cast(vx_e16x2_t, u)[0]; }
+__device__ __forceinline__ float e16_hi(uint32_t u) { return (float)__builtin_bit_cast(vx_e16x2_t, u)[1]; }
+#else
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even, NaN preserved
@@ -38,20 +86,21 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+__device__ __forceinline__ float e16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float e16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+#endif
 
-// two floats -> packed bf16 pair with one v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved)
-typedef __bf16 vx_bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float vx_f32x2_t __attribute__((ext_vector_type(2)));
+// two floats -> packed element pair with one v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 (round-to-nearest-even, NaN preserved)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   vx_f32x2_t v = {lo, hi};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vx_bf16x2_t));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vx_e16x2_t));
 }
 
 __device__ __forceinline__ void unpack_bf16x8(const uint4& v, float* f) {
-  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  f[0] = e16_lo(v.x); f[1] = e16_hi(v.x);
+  f[2] = e16_lo(v.y); f[3] = e16_hi(v.y);
+  f[4] = e16_lo(v.z); f[5] = e16_hi(v.z);
+  f[6] = e16_lo(v.w); f[7] = e16_hi(v.w);
 }
 
 __device__ __forceinline__ uint4 pack_bf16x8(const float* f) {
@@ -143,8 +192,10 @@ __device__ __forceinline__ float gelu_as_f(float x) { return 0.5f * x * (1.0f + 
 #endif
 
 __device__ __forceinline__ f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
-                                                 c, 0, 0, 0);
+  return VX_MFMA_16x16x32(__builtin_bit_cast(vx_e16x8_t, a), __builtin_bit_cast(vx_e16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
+  return VX_MFMA_32x32x16(__builtin_bit_cast(vx_e16x8_t, a), __builtin_bit_cast(vx_e16x8_t, b), c, 0, 0, 0);
 }
 
 __device__ __forceinline__ float wave_xor_max(float v, int mask) { return fmaxf(v, __shfl_xor(v, mask, 64)); }

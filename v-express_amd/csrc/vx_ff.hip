@@ -350,10 +350,10 @@ __global__ __launch_bounds__(64 * (16 / MI), MI == 4 ? 1 : 2) void ff_fused_kern
       for (int i = 0; i < SMI; ++i) {
         const size_t row = (size_t)(m0 + 16 * i + lrow);
         const uint2 r2 = rv[i][j];
-        const float v0 = Y[i][j][0] + b4.x + __uint_as_float(r2.x << 16);
-        const float v1 = Y[i][j][1] + b4.y + __uint_as_float(r2.x & 0xffff0000u);
-        const float v2 = Y[i][j][2] + b4.z + __uint_as_float(r2.y << 16);
-        const float v3 = Y[i][j][3] + b4.w + __uint_as_float(r2.y & 0xffff0000u);
+        const float v0 = Y[i][j][0] + b4.x + e16_lo(r2.x);
+        const float v1 = Y[i][j][1] + b4.y + e16_hi(r2.x);
+        const float v2 = Y[i][j][2] + b4.z + e16_lo(r2.y);
+        const float v3 = Y[i][j][3] + b4.w + e16_hi(r2.y);
         *reinterpret_cast<uint2*>(out + row * p.ldo + col) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
       }
     }

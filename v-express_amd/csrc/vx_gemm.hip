@@ -436,14 +436,14 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N, 2) void gemm_kernel(const v
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= alpha;
-          v[0] += __uint_as_float(rv[j].x << 16); v[1] += __uint_as_float(rv[j].x & 0xffff0000u);
-          v[2] += __uint_as_float(rv[j].y << 16); v[3] += __uint_as_float(rv[j].y & 0xffff0000u);
+          v[0] += e16_lo(rv[j].x); v[1] += e16_hi(rv[j].x);
+          v[2] += e16_lo(rv[j].y); v[3] += e16_hi(rv[j].y);
           if constexpr (GNS) {
             // whole tiles, bf16 output (vx_gemm_gn_slabs): statistics of the STORED values, as a read-back would see them
             const uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             *reinterpret_cast<uint2*>((bf16_t*)p.out + (size_t)m * p.ldc + ncol[j]) = pk;
-            const float g[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
-                                __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
+            const float g[4] = {e16_lo(pk.x), e16_hi(pk.x),
+                                e16_lo(pk.y), e16_hi(pk.y)};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               gcs[(j0 + j) * 4 + e] += g[e];
@@ -652,8 +652,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vx_gemm_params
     for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
     if (p.residual != nullptr) {
       const uint2 r2 = *reinterpret_cast<const uint2*>((const bf16_t*)p.residual + (size_t)m * p.ldr + n);
-      v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
-      v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+      v[0] += e16_lo(r2.x); v[1] += e16_hi(r2.x);
+      v[2] += e16_lo(r2.y); v[3] += e16_hi(r2.y);
     }
     if (p.out_f32) {
       *reinterpret_cast<float4*>((float*)p.out + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);

@@ -742,8 +742,8 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
             v[r] *= alpha;
           }
           if (RES && !RABL(64)) {
-            v[0] += __uint_as_float(rv[k].x << 16); v[1] += __uint_as_float(rv[k].x & 0xffff0000u);
-            v[2] += __uint_as_float(rv[k].y << 16); v[3] += __uint_as_float(rv[k].y & 0xffff0000u);
+            v[0] += e16_lo(rv[k].x); v[1] += e16_hi(rv[k].x);
+            v[2] += e16_lo(rv[k].y); v[3] += e16_hi(rv[k].y);
           }
           if (RABL(32)) {
             asm volatile("" ::"v"(v[0]), "v"(v[3]));
@@ -752,16 +752,16 @@ __global__ __launch_bounds__(R_NT, 2) void gemm_ring_kernel(const vx_gemm_params
           const uint2 pk2 = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
           ring_store8(outb, out_off(k), pk2);
           if constexpr (GNS) {
-            const float g0 = __uint_as_float(pk2.x << 16), g1 = __uint_as_float(pk2.x & 0xffff0000u);
-            const float g2 = __uint_as_float(pk2.y << 16), g3 = __uint_as_float(pk2.y & 0xffff0000u);
+            const float g0 = e16_lo(pk2.x), g1 = e16_hi(pk2.x);
+            const float g2 = e16_lo(pk2.y), g3 = e16_hi(pk2.y);
             gcs[16] += g0; gcs[17] += g1; gcs[18] += g2; gcs[19] += g3;
             gcq[16] = fmaf(g0, g0, gcq[16]); gcq[17] = fmaf(g1, g1, gcq[17]);
             gcq[18] = fmaf(g2, g2, gcq[18]); gcq[19] = fmaf(g3, g3, gcq[19]);
           }
           if constexpr (STATS) {
             // statistics of the STORED (bf16-rounded) values, as vx_row_stats would read them back
-            const float r0 = __uint_as_float(pk2.x << 16), r1 = __uint_as_float(pk2.x & 0xffff0000u);
-            const float r2 = __uint_as_float(pk2.y << 16), r3 = __uint_as_float(pk2.y & 0xffff0000u);
+            const float r0 = e16_lo(pk2.x), r1 = e16_hi(pk2.x);
+            const float r2 = e16_lo(pk2.y), r3 = e16_hi(pk2.y);
             st_s += (r0 + r1) + (r2 + r3);
             st_q = fmaf(r0, r0, st_q); st_q = fmaf(r1, r1, st_q); st_q = fmaf(r2, r2, st_q); st_q = fmaf(r3, r3, st_q);
             // last item of row block i: add up the four lanes (lq = 0..3) that share the row.  permlane16_swap(s, q)

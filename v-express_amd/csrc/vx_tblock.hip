@@ -82,9 +82,9 @@ struct TbGeo {
 #define VX_TB_PF 2
 #endif
 
-typedef short tb_s4 __attribute__((ext_vector_type(4)));
+typedef vx_e16x4_t tb_s4;
 __device__ __forceinline__ f32x4_t mfma16k(const uint2& a, const uint2& b, f32x4_t c) {   // 16 x 16 x 16
-  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(tb_s4, a), __builtin_bit_cast(tb_s4, b), c, 0, 0, 0);
+  return VX_MFMA_16x16x16(__builtin_bit_cast(tb_s4, a), __builtin_bit_cast(tb_s4, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ uint4 tb_frag(const char* p) {
   if (TABL(64)) return make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
@@ -554,15 +554,15 @@ __global__ __launch_bounds__(64 * TB_NW, TB_NW == 8 ? 2 : 1) void tblock_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint2 r2 = rv[i][j];
-          const float v0 = Y[i][jb + j][0] + b4.x + __uint_as_float(r2.x << 16);
-          const float v1 = Y[i][jb + j][1] + b4.y + __uint_as_float(r2.x & 0xffff0000u);
-          const float v2 = Y[i][jb + j][2] + b4.z + __uint_as_float(r2.y << 16);
-          const float v3 = Y[i][jb + j][3] + b4.w + __uint_as_float(r2.y & 0xffff0000u);
+          const float v0 = Y[i][jb + j][0] + b4.x + e16_lo(r2.x);
+          const float v1 = Y[i][jb + j][1] + b4.y + e16_hi(r2.x);
+          const float v2 = Y[i][jb + j][2] + b4.z + e16_lo(r2.y);
+          const float v3 = Y[i][jb + j][3] + b4.w + e16_hi(r2.y);
           const uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
           if (estore[i]) *reinterpret_cast<uint2*>(out + erow[i] + col) = pk;
           if (p.stats_out != nullptr) {        // of the STORED values, as vx_row_stats would read them back
-            const float r0 = __uint_as_float(pk.x << 16), r1 = __uint_as_float(pk.x & 0xffff0000u);
-            const float r2_ = __uint_as_float(pk.y << 16), r3 = __uint_as_float(pk.y & 0xffff0000u);
+            const float r0 = e16_lo(pk.x), r1 = e16_hi(pk.x);
+            const float r2_ = e16_lo(pk.y), r3 = e16_hi(pk.y);
             so_s[i] += (r0 + r1) + (r2_ + r3);
             so_q[i] = fmaf(r0, r0, so_q[i]); so_q[i] = fmaf(r1, r1, so_q[i]);
             so_q[i] = fmaf(r2_, r2_, so_q[i]); so_q[i] = fmaf(r3, r3, so_q[i]);

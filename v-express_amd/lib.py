@@ -90,14 +90,15 @@ def build(force=False):
     return LIB_PATH
 
 
-def _load():
-    if not os.path.exists(LIB_PATH):
-        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+def _load(path=None, element="bf16"):
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(or `make -C v-express_amd/csrc`).  There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     if missing:
-        raise ImportError(f"{LIB_PATH} does not export {missing}; rebuild it")
+        raise ImportError(f"{path} does not export {missing}; rebuild it")
     i32, f32, vp, i64 = C.c_int32, C.c_float, C.c_void_p, C.c_int64
     lib.vx_last_error_string.restype = C.c_char_p
     lib.vx_abi_version.restype = i32
@@ -108,6 +109,7 @@ def _load():
     lib.vx_gemm_last_kernel.restype = C.c_char_p
     lib.vx_last_kernel.restype = C.c_char_p
     lib.vx_build_id.restype = C.c_char_p
+    lib.vx_element_type.restype = C.c_char_p
     lib.vx_gemm_splitk_ws_bytes.argtypes = [i32, i32, i32]
     lib.vx_gemm_splitk_ws_bytes.restype = i64
     lib.vx_gemm_ring_coop_ok.argtypes = [C.POINTER(GemmParams)]
@@ -149,14 +151,62 @@ def _load():
         fn = getattr(lib, name)
         if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name",
                         "vx_gemm_splitk_ws_bytes", "vx_gemm_last_kernel", "vx_last_kernel", "vx_build_id",
-                        "vx_tblock_packed_bytes"):
+                        "vx_tblock_packed_bytes", "vx_element_type"):
             fn.restype = i32
     if lib.vx_abi_version() != 14:
-        raise ImportError("libvexpress_hip.so ABI version mismatch")
+        raise ImportError(f"{os.path.basename(path)} ABI version mismatch")
+    if lib.vx_element_type().decode() != element:
+        raise ImportError(f"{path} computes on {lib.vx_element_type().decode()} elements, expected {element}")
     return lib
 
 
 lib = _load()
+
+# ---- the element type of the running computation.  libvexpress_hip.so computes on bfloat16 storage, libvexpress_hip_f16.so
+# (the same sources, -DVX_ELEM_F16, the same ABI) on IEEE half - the reference's default `--dtype fp16`
+# (inference.py:44,150-151).  Which one a call goes to is decided by the MODEL's dtype: every model entry point runs inside
+# `with element_type(model element)` (module_base.DeviceModule), ops.py allocates in ELEM[0] and calls `current()`.
+import torch  # noqa: E402
+
+LIB16_PATH = os.environ.get("VX_LIBRARY_F16") or os.path.join(_HERE, "libvexpress_hip_f16.so")
+ELEM = [torch.bfloat16]
+_LIB16 = [None]
+
+
+def lib_f16():
+    """The IEEE-half build, loaded on first use (a missing / stale / mismatching library is an ImportError, like the bf16 one)."""
+    if _LIB16[0] is None:
+        l16 = _load(LIB16_PATH, "f16")
+        if not os.environ.get("VX_LIBRARY_F16") and not os.environ.get("VX_LIBRARY"):
+            a, b = l16.vx_build_id().decode(), lib.vx_build_id().decode()
+            if a != b:
+                raise ImportError(f"{LIB16_PATH} ({a}) and {LIB_PATH} ({b}) were built from different sources: rebuild both")
+        _LIB16[0] = l16
+    return _LIB16[0]
+
+
+def current():
+    """The library of the element type in force (ELEM[0])."""
+    return lib if ELEM[0] is torch.bfloat16 else lib_f16()
+
+
+class element_type:
+    """`with element_type(torch.float16):` - calls and allocations of ops.py inside the block use the IEEE-half library."""
+
+    def __init__(self, dtype):
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise TypeError(f"the kernels compute on bfloat16 or float16 elements, not {dtype}")
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = ELEM[0]
+        ELEM[0] = self.dtype
+        if self.dtype is torch.float16:
+            lib_f16()
+        return self
+
+    def __exit__(self, *a):
+        ELEM[0] = self.prev
 
 
 def source_id():
@@ -215,5 +265,5 @@ class VxError(RuntimeError):
 
 def check(rc, what=""):
     if rc != 0:
-        msg = lib.vx_last_error_string().decode("utf-8", "replace")
+        msg = current().vx_last_error_string().decode("utf-8", "replace")
         raise VxError(f"libvexpress_hip {what} failed (rc={rc}): {msg}")

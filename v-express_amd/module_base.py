@@ -3,33 +3,36 @@ kernel-specific device layouts).  What the reference's call sites use is here: `
 `.dtype`, `.eval()`, `.requires_grad_()`, `load_state_dict(sd, strict)`, `state_dict()`, `parameters()`
 (inference.py:77-129,150-163; pipelines/v_express_pipeline.py:345).
 
-Compute dtype: the gfx950 kernels store activations and weights in bf16 and accumulate in fp32 (MFMA
-v_mfma_f32_16x16x32_bf16).  `torch.float16` - the reference's default (`inference.py:44,150-151`) - and
-`torch.float32` are accepted as I/O dtypes: `.dtype` reports them and model outputs follow the caller's input dtype
-like the reference's, but every kernel computes in bf16 storage / fp32 accumulation (same MFMA rate as an f16 path,
-wider exponent range).  Asking for float16 emits ONE warning per process that says so; set VX_STRICT_FP16=1 to get the
-round-2 behaviour (NotImplementedError) back when a silent change of the compute dtype is not acceptable.
+Compute dtype = the model's dtype, as in the reference: `torch.bfloat16` runs libvexpress_hip.so (bf16 storage, fp32
+accumulation, v_mfma_f32_16x16x32_bf16), `torch.float16` - the reference's default, `inference.py:44,150-151` - runs
+libvexpress_hip_f16.so, the same kernel sources compiled for IEEE half (v_mfma_f32_16x16x32_f16: same MFMA rate, 11 instead
+of 8 mantissa bits, 5 instead of 8 exponent bits).  `torch.float32` is an I/O dtype only (bf16 elements underneath).  Every
+model entry point runs inside `lib.element_type(self._elem)`; the device layouts of the weights are (re)built in that
+element type, from the source-layout tensors, whenever it changes.
 """
-import os
-import warnings
 from types import SimpleNamespace
 
 import torch
 
-_NO_FP16 = ("v_express_amd computes in bfloat16 (bf16 storage, fp32 accumulation on the gfx950 matrix cores); a float16 "
-            "compute path is not implemented.  Use torch.bfloat16 (reference CLI: --dtype bf16).")
-_FP16_WARNED = [False]
+from . import lib as L
+
+# entry points of the model classes that launch kernels or build device layouts: wrapped (once per subclass) so that they
+# run under the model's element type
+_ELEM_METHODS = ("forward", "forward_tokens", "__call__", "_prepared", "_prepared_encoder", "decode", "decode_tokens",
+                 "decode_video", "encode", "time_rows", "release_raw_weights")
 
 
-def _fp16_io():
-    """torch.float16 requested: bf16 compute behind a float16 I/O surface (one warning), or an error in strict mode."""
-    if os.environ.get("VX_STRICT_FP16", "0") == "1":
-        raise NotImplementedError(_NO_FP16)
-    if not _FP16_WARNED[0]:
-        _FP16_WARNED[0] = True
-        warnings.warn("v_express_amd: torch.float16 is accepted as an I/O dtype only - the gfx950 kernels compute in "
-                      "bfloat16 storage with fp32 accumulation (VX_STRICT_FP16=1 turns this into an error)",
-                      stacklevel=3)
+def _in_element_type(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def run(self, *args, **kwargs):
+        if L.ELEM[0] is self._elem:
+            return fn(self, *args, **kwargs)
+        with L.element_type(self._elem):
+            return fn(self, *args, **kwargs)
+    run._vx_elem_wrapped = True
+    return run
 
 
 def _norm_device(device):
@@ -46,6 +49,13 @@ class DeviceModule:
     """Base of every model class.  Subclasses keep raw (reference-layout) tensors in `_raw` and build their device
     layouts lazily in `_prepared()`; `expected_keys()` (name -> shape) enables strict loading where it is defined."""
 
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        for name in _ELEM_METHODS:
+            fn = cls.__dict__.get(name)
+            if callable(fn) and not getattr(fn, "_vx_elem_wrapped", False):
+                setattr(cls, name, _in_element_type(fn))
+
     def __init__(self):
         self._device = torch.device("cpu")
         self._dtype = torch.bfloat16
@@ -61,6 +71,11 @@ class DeviceModule:
     def dtype(self):
         return self._dtype
 
+    @property
+    def _elem(self):
+        """The 16-bit element type the kernels compute on for this model (float32 models: bfloat16 underneath)."""
+        return torch.float16 if self._dtype == torch.float16 else torch.bfloat16
+
     def _invalidate(self):
         self._P = None
 
@@ -70,11 +85,16 @@ class DeviceModule:
             if isinstance(a, bool) or a is None:          # non_blocking= / copy= flags of torch's signature
                 continue
             if isinstance(a, torch.dtype):
-                if a == torch.float16:
-                    _fp16_io()
                 if a not in (torch.bfloat16, torch.float32, torch.float16):
                     raise TypeError(f"unsupported dtype {a}")
+                before = self._elem
                 self._dtype = a
+                if self._elem != before and (self._P is not None or self._released):
+                    # the device layouts hold elements of the other type: rebuild them from the source-layout tensors
+                    if self._released:
+                        raise RuntimeError("release_raw_weights() dropped the source-layout weights; this model can no "
+                                           "longer change its element type - load the state dict again first")
+                    self._invalidate()
             elif isinstance(a, (torch.device, str, int)):
                 device = _norm_device(a)
         if device != _norm_device(self._device):

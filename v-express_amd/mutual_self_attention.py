@@ -14,6 +14,7 @@ for which attention returns exactly `to_out.bias`; that row is recorded as None 
 import torch
 
 from . import blocks as B
+from . import lib as L
 
 
 class ReferenceAttentionControl:
@@ -46,6 +47,13 @@ class ReferenceAttentionControl:
         reader, wbanks = self.unet, writer.unet.banks
         if not wbanks:
             raise RuntimeError("writer has no banks: run the ReferenceNet forward before update()")
+        if writer.unet._elem != reader._elem:
+            raise TypeError(f"ReferenceNet ({writer.unet.dtype}) and denoising UNet ({reader.dtype}) compute on different "
+                            "16-bit element types: give both models the same dtype (inference.py:150-161 does)")
+        with L.element_type(reader._elem):                      # the bank K / V projections run in the reader's element type
+            self._update(reader, wbanks, do_classifier_free_guidance, do_unconditional_forward)
+
+    def _update(self, reader, wbanks, do_classifier_free_guidance, do_unconditional_forward):
         P = reader._prepared()
         heads = reader.cfg.heads
         banks = {}

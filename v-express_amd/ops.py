@@ -12,8 +12,21 @@ import torch
 
 from . import lib as L
 
-BF16 = torch.bfloat16
-_lib = L.lib
+class _CurrentLib:
+    """`_lib.vx_*` resolves to the library of the element type in force (lib.ELEM: bfloat16 or IEEE half; lib.element_type)."""
+
+    def __getattr__(self, name):
+        return getattr(L.current(), name)
+
+
+_lib = _CurrentLib()
+
+
+def __getattr__(name):
+    # `ops.BF16` = the element dtype in force (the name predates the IEEE-half library: torch.bfloat16 or torch.float16)
+    if name == "BF16":
+        return L.ELEM[0]
+    raise AttributeError(name)
 
 
 def _stream():
@@ -203,7 +216,7 @@ def _ptr(t):
 
 
 def _chk_bf16(t, name):
-    if t.dtype != BF16 or not t.is_cuda:
+    if t.dtype != L.ELEM[0] or not t.is_cuda:
         raise TypeError(f"{name}: expected a CUDA bf16 tensor, got {t.dtype} on {t.device}")
 
 
@@ -685,7 +698,7 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
         p.w_group_rows = w_group_rows
     n = p.n
     if out is None:
-        out = torch.empty((geom.m, n), device=a.device, dtype=torch.float32 if out_f32 else BF16)
+        out = torch.empty((geom.m, n), device=a.device, dtype=torch.float32 if out_f32 else L.ELEM[0])
     ldc, orows = _row_stride(out)
     if orows != geom.m or out.shape[-1] != n:
         raise ValueError("bad output shape")
@@ -744,7 +757,7 @@ def geglu(a, w_interleaved, bias_interleaved, out=None, ln=None):
     """FeedForward first half: h * gelu(g) with value/gate weight rows interleaved in blocks of 8 (ln: as in gemm)."""
     p, geom = _base_params(a, w_interleaved, None)
     if out is None:
-        out = torch.empty((geom.m, p.n // 2), device=a.device, dtype=BF16)
+        out = torch.empty((geom.m, p.n // 2), device=a.device, dtype=L.ELEM[0])
     p.epi = L.VX_EPI_GEGLU
     p.bias = bias_interleaved.data_ptr() if bias_interleaved is not None else None
     p.out, p.ldc = out.data_ptr(), _row_stride(out)[0]
@@ -839,8 +852,8 @@ def tblock_fused(h, wqkv_folded, bqkv, colsum, pe_rows, wo, bo, *, b, f, hw, hea
     hit = _TB_PACKED.get(key)
     if hit is None:
         dev = h.device
-        wqkv_t = torch.empty(int(_lib.vx_tblock_packed_bytes(f)) // 2, device=dev, dtype=BF16)
-        wo_t = torch.empty(204800 // 2, device=dev, dtype=BF16)
+        wqkv_t = torch.empty(int(_lib.vx_tblock_packed_bytes(f)) // 2, device=dev, dtype=L.ELEM[0])
+        wo_t = torch.empty(204800 // 2, device=dev, dtype=L.ELEM[0])
         cs = torch.empty(1024, device=dev, dtype=torch.float32)
         L.check(_lib.vx_tblock_pack(_ptr(wqkv_folded), _ptr(bqkv) if bqkv is not None else None, _ptr(colsum),
                                     _ptr(pe_rows) if pe_rows is not None else None,
@@ -893,8 +906,8 @@ def alloc_vt(seqs, heads, head_dim, n, device):
     """V^T buffer [seqs, heads, head_dim, pitch]; zero-filled when the pitch pads the key axis."""
     pitch = vt_pitch(n)
     if pitch != n:
-        return torch.zeros((seqs, heads, head_dim, pitch), device=device, dtype=BF16)
-    return torch.empty((seqs, heads, head_dim, pitch), device=device, dtype=BF16)
+        return torch.zeros((seqs, heads, head_dim, pitch), device=device, dtype=L.ELEM[0])
+    return torch.empty((seqs, heads, head_dim, pitch), device=device, dtype=L.ELEM[0])
 
 
 def _gn_slices(hw):
@@ -914,7 +927,7 @@ def padded_buffer(device, frames, H, W, c):
     key = (device, _stream_key(device), frames, H, W, c)
     buf = _PADDED.get(key)
     if buf is None:
-        buf = torch.zeros((frames, (H + 2) * (W + 2), c), device=device, dtype=BF16)
+        buf = torch.zeros((frames, (H + 2) * (W + 2), c), device=device, dtype=L.ELEM[0])
         _PADDED[key] = buf
     return buf
 
@@ -937,7 +950,7 @@ def groupnorm(x1, gamma, beta, *, frames, hw, groups, eps, silu, x2=None, out=No
         out = padded_buffer(x1.device, frames, H, W, c1 + c2)
         width, pad = W, 1
     elif out is None:
-        out = torch.empty((frames, hw, c1 + c2), device=x1.device, dtype=BF16)
+        out = torch.empty((frames, hw, c1 + c2), device=x1.device, dtype=L.ELEM[0])
     slices = _gn_slices(hw)
     st = gn_of(x1) if x2 is None else None
     elems = frames * hw * (c1 + c2)
@@ -1006,7 +1019,7 @@ def groupnorm_fold_linear(ws, gamma, w, bias_beta, *, frames, hw, groups, eps, s
     n, c = w.shape
     if bias_beta.dtype != torch.float32 or gamma.dtype != torch.float32 or not w.is_contiguous():
         raise TypeError("groupnorm_fold_linear: float32 gamma / bias_beta, contiguous bf16 weight expected")
-    w_f = torch.empty((frames, n, c), device=w.device, dtype=BF16)
+    w_f = torch.empty((frames, n, c), device=w.device, dtype=L.ELEM[0])
     b_f = torch.empty((frames, n), device=w.device, dtype=torch.float32)
     L.check(_lib.vx_groupnorm_fold_linear(_ptr(ws), frames, hw, slices or _gn_slices(hw), groups, float(eps), _ptr(gamma), c,
                                           _ptr(w), _ptr(bias_beta), n, _ptr(w_f), _ptr(b_f), _stream()),
@@ -1019,7 +1032,7 @@ def layernorm(x, gamma, beta, eps=1e-5, *, add=None, add_rows_per_entry=1, add_e
     ldx, rows = _row_stride(x)
     c = x.shape[-1]
     if out is None:
-        out = torch.empty((rows, c), device=x.device, dtype=BF16)
+        out = torch.empty((rows, c), device=x.device, dtype=L.ELEM[0])
     with _hbm_op("layernorm", 4 * rows * c):
         L.check(_lib.vx_layernorm(_ptr(x), ldx, rows, c, float(eps), _ptr(gamma), _ptr(beta), _ptr(add),
                                   add_rows_per_entry, add_entries, _ptr(out), _row_stride(out)[0], _stream()),
@@ -1049,7 +1062,7 @@ def attention(q, k, vt, *, batch, heads, n_q, n_kv, head_dim, q_per_kv=1, out=No
     ldq, _ = _row_stride(q)
     ldk, _ = _row_stride(k)
     if out is None:
-        out = torch.empty((batch * n_q, heads * head_dim), device=q.device, dtype=BF16)
+        out = torch.empty((batch * n_q, heads * head_dim), device=q.device, dtype=L.ELEM[0])
     scale = 0.0 if k_prescaled else head_dim ** -0.5
     # algorithmic work: QK^T + PV = 4 n_q n_kv d FLOP per (batch, head) at the TRUE head dim (zero padding is not counted);
     # q and the output once, K and V^T once per kv batch
@@ -1078,7 +1091,7 @@ def temporal_attention(qkv, *, b, f, hw, heads, head_dim, out=None):
     if rows != b * f * hw:
         raise ValueError("qkv rows != b*f*hw")
     if out is None:
-        out = torch.empty((rows, heads * head_dim), device=qkv.device, dtype=BF16)
+        out = torch.empty((rows, heads * head_dim), device=qkv.device, dtype=L.ELEM[0])
     # reads q | k | v, writes out (bf16); 4 f f d FLOP per (batch, pixel, head)
     with _hbm_op("temporal_attention", 2 * rows * 4 * heads * head_dim, flops=4.0 * rows * f * heads * head_dim):
         L.check(_lib.vx_temporal_attention(_ptr(qkv), ld, _ptr(out), _row_stride(out)[0], b, f, hw, heads, head_dim,
@@ -1092,7 +1105,7 @@ def small_kv_attention(q, kv, *, batch, n_q, n_kv, heads, head_dim, out=None):
     ldkv, _ = _row_stride(kv)
     c = heads * head_dim
     if out is None:
-        out = torch.empty((batch * n_q, c), device=q.device, dtype=BF16)
+        out = torch.empty((batch * n_q, c), device=q.device, dtype=L.ELEM[0])
     with _hbm_op("small_kv_attention", 2 * (2 * batch * n_q * c + 2 * batch * n_kv * c)):   # q + out, K | V
         L.check(_lib.vx_small_kv_attention(_ptr(q), ldq, _ptr(kv), ldkv, c, _ptr(out), _row_stride(out)[0], batch, n_q,
                                            n_kv, heads, head_dim, head_dim ** -0.5, _stream()),
@@ -1111,7 +1124,7 @@ def gather_latents(latents, frame_ids, reps, c_pad=8):
     """latents fp32 [1, C, F, h, w], frame_ids int32 [f] (device) -> bf16 [reps*f, h*w, c_pad]."""
     _, c, F, h, w = latents.shape
     f = frame_ids.numel()
-    out = torch.empty((reps * f, h * w, c_pad), device=latents.device, dtype=BF16)
+    out = torch.empty((reps * f, h * w, c_pad), device=latents.device, dtype=L.ELEM[0])
     L.check(_lib.vx_gather_latents(_ptr(latents), c, F, h * w, _ptr(frame_ids), f, reps, c_pad, _ptr(out),
                                    _stream()), "vx_gather_latents")
     return out
@@ -1156,7 +1169,7 @@ def ncfhw_to_nhwc(x, c_pad=None):
     b, c, f, h, w = x.shape
     c_pad = c_pad or (c + 7) // 8 * 8
     x = x.contiguous().float()
-    out = torch.empty((b * f, h * w, c_pad), device=x.device, dtype=BF16)
+    out = torch.empty((b * f, h * w, c_pad), device=x.device, dtype=L.ELEM[0])
     L.check(_lib.vx_ncfhw_to_nhwc(_ptr(x), b, c, f, h * w, c_pad, _ptr(out), _stream()), "vx_ncfhw_to_nhwc")
     return out
 
@@ -1187,7 +1200,7 @@ def wave_conv1d(wave, wt, stride):
     t_out = (wave.numel() - taps) // stride + 1
     if t_out < 1:
         raise ValueError(f"wave_conv1d: {wave.numel()} samples are shorter than one {taps}-tap window")
-    out = torch.empty((t_out, c), device=wave.device, dtype=BF16)
+    out = torch.empty((t_out, c), device=wave.device, dtype=L.ELEM[0])
     L.check(_lib.vx_wave_conv1d(_ptr(wave), wave.numel(), _ptr(wt), c, taps, stride, _ptr(out), _stream()),
             "vx_wave_conv1d")
     return out

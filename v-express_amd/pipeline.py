@@ -23,11 +23,24 @@ import os
 
 import torch
 
+from . import lib as L
 from . import ops
 from .context import get_context_scheduler, overlap_plan
 from .distributed import (DistContext, MixedUnitSchedule, UnitSchedule, choose_frame_shards, choose_mixed_shards,
                           split_frames)
 from .mutual_self_attention import ReferenceAttentionControl
+
+
+def _in_unet_element_type(fn):
+    """Pipeline entry points launch kernels themselves (gather / combine / DDIM, layout changes): they run under the
+    denoising UNet's 16-bit element type (lib.element_type: bfloat16, or IEEE half for a float16 model)."""
+    import functools
+
+    @functools.wraps(fn)
+    def run(self, *args, **kwargs):
+        with L.element_type(self.denoising_unet._elem):
+            return fn(self, *args, **kwargs)
+    return run
 
 
 class VExpressPipeline:
@@ -89,6 +102,7 @@ class VExpressPipeline:
             t = torch.from_numpy(arr / 255.0).permute(2, 0, 1)[None]
         return 2.0 * t - 1.0 if normalize else t
 
+    @_in_unet_element_type
     def prepare_reference_latent(self, reference_image, height, width):
         """pipelines/v_express_pipeline.py:343-348: VAE-encode the reference image (posterior mean) * 0.18215.  Runs on
         the HIP VAE encoder when `vae` is a v_express_amd.AutoencoderKL (encoder weights loaded)."""
@@ -99,6 +113,7 @@ class VExpressPipeline:
         x = self._preprocess_image(reference_image, height, width, normalize=True)
         return self.vae.encode(x).latent_dist.mean * 0.18215
 
+    @_in_unet_element_type
     def prepare_kps_tokens(self, kps_images, height, width, do_classifier_free_guidance):
         """prepare_kps_feature (:350-372) on the device, returning the token layout the loop consumes:
         bf16 `[2, F, hw, C0]` (row 0 = the all-zero unconditional half).  Needs a v_express_amd.VKpsGuider."""
@@ -113,6 +128,7 @@ class VExpressPipeline:
             tok = torch.cat([torch.zeros_like(tok), tok], dim=0)
         return tok
 
+    @_in_unet_element_type
     def prepare_kps_feature(self, kps_images, height, width, do_classifier_free_guidance):
         """pipelines/v_express_pipeline.py:350-372 with the reference's return layout `[2, C, F, h, w]` float32."""
         if self.v_kps_guider is None:
@@ -131,6 +147,7 @@ class VExpressPipeline:
             feat = torch.cat([torch.zeros_like(feat), feat], dim=0)
         return feat
 
+    @_in_unet_element_type
     def prepare_audio_embeddings(self, audio_waveform, video_length, num_pad_audio_frames,
                                  do_classifier_free_guidance):
         """pipelines/v_express_pipeline.py:374-407.  `audio_processor` / `audio_encoder` are v_express_amd's
@@ -166,6 +183,7 @@ class VExpressPipeline:
         return latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
 
     # ------------------------------------------------------------------ the hot loop
+    @_in_unet_element_type
     def denoise(self, latents, kps_tokens, audio, timesteps, windows, guidance_scale, callback=None,
                 callback_steps=1):
         """pipelines/v_express_pipeline.py:526-583.  latents fp32 [1,4,F,h,w] (device, updated in place);
@@ -294,6 +312,7 @@ class VExpressPipeline:
         return latents
 
     @torch.no_grad()
+    @_in_unet_element_type
     def decode_latents(self, latents, chunk=8):
         """pipelines/v_express_pipeline.py:152-166; frames are split evenly over the ranks when distributed."""
         dc = self.dist
@@ -313,6 +332,7 @@ class VExpressPipeline:
 
     # ------------------------------------------------------------------ reference call surface
     @torch.no_grad()
+    @_in_unet_element_type
     def __call__(self, reference_image, kps_images, audio_waveform, width, height, video_length,
                  num_inference_steps, guidance_scale, strength=1., num_images_per_prompt=1, eta: float = 0.0,
                  generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None,

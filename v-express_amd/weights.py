@@ -12,7 +12,16 @@ diffusers AutoencoderKL — SURVEY.md Appendix C).  Re-layouts done once at load
 """
 import torch
 
-BF16 = torch.bfloat16
+from . import lib as L
+
+
+
+def __getattr__(name):
+    # `weights.BF16` = the element dtype in force when a model prepares its device layouts (lib.element_type: torch.bfloat16,
+    # or torch.float16 for a model in the reference's default --dtype fp16)
+    if name == "BF16":
+        return L.ELEM[0]
+    raise AttributeError(name)
 
 
 class Prepared(dict):
@@ -43,11 +52,11 @@ def prep_conv(sd, p, device, cin_pad=None, cout_pad=None):
     b = torch.zeros(cout_p, device=device, dtype=torch.float32)
     if (p + ".bias") in sd:
         b[:cout] = sd[p + ".bias"].detach().to(device=device, dtype=torch.float32)
-    return Prepared(w=wp.reshape(cout_p, kh * kw * cin_p).to(BF16).contiguous(), b=b, k=kh, cout=cout)
+    return Prepared(w=wp.reshape(cout_p, kh * kw * cin_p).to(L.ELEM[0]).contiguous(), b=b, k=kh, cout=cout)
 
 
 def prep_linear(sd, p, device):
-    w = _dev(sd[p + ".weight"], device, BF16)
+    w = _dev(sd[p + ".weight"], device, L.ELEM[0])
     if w.dim() == 4:     # 1x1 conv stored as [Cout, Cin, 1, 1]
         w = w.reshape(w.shape[0], w.shape[1]).contiguous()
     b = _dev(sd[p + ".bias"], device, torch.float32) if (p + ".bias") in sd else None
@@ -68,7 +77,7 @@ def _cat_w(sd, keys, device, scales=None):
         w = sd[k].detach().to(device=device, dtype=torch.float32)
         if scales is not None and scales[i] != 1.0:
             w = w * scales[i]
-        parts.append(w.to(BF16))
+        parts.append(w.to(L.ELEM[0]))
     return torch.cat(parts, dim=0).contiguous()
 
 
@@ -98,7 +107,7 @@ def fold_layernorm(w_src, bias, gamma, beta, device, row_scale=None, interleave=
         w32 = w32 * row_scale.to(device=device, dtype=torch.float32)[:, None]
     g = gamma.detach().to(device=device, dtype=torch.float32)
     bt = beta.detach().to(device=device, dtype=torch.float32)
-    w = (w32 * g[None, :]).to(BF16)
+    w = (w32 * g[None, :]).to(L.ELEM[0])
     colsum = w.float().sum(dim=1)
     b = w32 @ bt
     if bias is not None:
@@ -118,7 +127,7 @@ def fold_groupnorm(w_src, bias, gamma, beta, device):
     bb = w32 @ beta.detach().to(device=device, dtype=torch.float32)
     if bias is not None:
         bb = bb + bias.detach().to(device=device, dtype=torch.float32)
-    return Prepared(w=w32.to(BF16).contiguous(), g=gamma.detach().to(device=device, dtype=torch.float32).contiguous(),
+    return Prepared(w=w32.to(L.ELEM[0]).contiguous(), g=gamma.detach().to(device=device, dtype=torch.float32).contiguous(),
                     bb=bb.contiguous())
 
 
@@ -152,8 +161,8 @@ def prep_cross_attn(sd, p, device, heads=None):
     """Attention whose K/V come from another sequence: Q alone, fused KV, out projection.  heads: as prep_self_attn
     (the fused K | V weight only; `wk` stays unscaled)."""
     scales = None if heads is None else [key_fold(sd[p + ".to_k.weight"].shape[0], heads), 1.0]
-    return Prepared(wq=_dev(sd[p + ".to_q.weight"], device, BF16),
-                    wk=_dev(sd[p + ".to_k.weight"], device, BF16),
+    return Prepared(wq=_dev(sd[p + ".to_q.weight"], device, L.ELEM[0]),
+                    wk=_dev(sd[p + ".to_k.weight"], device, L.ELEM[0]),
                     wkv=_cat_w(sd, [p + ".to_k.weight", p + ".to_v.weight"], device, scales),
                     out=prep_linear(sd, p + ".to_out.0", device), k_prescaled=heads is not None)
 
@@ -172,7 +181,7 @@ def geglu_interleave(t):
 
 
 def prep_ff(sd, p, device):
-    w1 = sd[p + ".net.0.proj.weight"].detach().to(device=device, dtype=BF16)
+    w1 = sd[p + ".net.0.proj.weight"].detach().to(device=device, dtype=L.ELEM[0])
     b1 = sd[p + ".net.0.proj.bias"].detach().to(device=device, dtype=torch.float32)
     return Prepared(w1=geglu_interleave(w1), b1=geglu_interleave(b1), out=prep_linear(sd, p + ".net.2", device))
 
@@ -234,7 +243,7 @@ def prep_motion(sd, p, device):
         # row-bias: (LN(x) + pe[f]) W^T = LN(x) W^T + pe[f] W^T, one float32 row per frame
         w, bq, _ = _qkv_rows(sd, a, device, None, ["to_q", "to_k", "to_v"])
         A["ln_qkv"] = fold_layernorm(w, bq, sd[f"{b}.norms.{i}.weight"], sd[f"{b}.norms.{i}.bias"], device)
-        A["pe_rows"] = (A.pe @ w.to(BF16).float().t()).contiguous()              # [max_len, 3C]
+        A["pe_rows"] = (A.pe @ w.to(L.ELEM[0]).float().t()).contiguous()              # [max_len, 3C]
         attn.append(A)
     P = Prepared(norm=prep_norm(sd, t + ".norm", device), proj_in=prep_linear(sd, t + ".proj_in", device),
                  proj_out=prep_linear(sd, t + ".proj_out", device), attn=attn,
