@@ -41,9 +41,9 @@ tests)
   K=""; if [ "$1" = "-k" ]; then K="$2"; shift 2; fi
   FILES="${*:-tests}"
   if [ -n "$K" ]; then timeout 1500 python -m pytest $FILES -m gpu -q -s --tb=short -p no:cacheprovider -k "$K" > $OUT/${T}_pytest_gpu.log 2>&1
-  else timeout 1500 python -m pytest $FILES -m gpu -q --tb=short -p no:cacheprovider > $OUT/${T}_pytest_gpu.log 2>&1; fi
+  else timeout 1500 python -m pytest $FILES -m gpu -q --tb=short -p no:cacheprovider --durations=25 > $OUT/${T}_pytest_gpu.log 2>&1; fi
   echo "pytest exit $?" >> $OUT/${T}_pytest_gpu.log
-  grep -E "^\[|passed|failed|rror|assert|pytest exit" $OUT/${T}_pytest_gpu.log | tail -60 > $OUT/${T}_pytest_gpu_summary.log
+  grep -E "^\[|passed|failed|rror|assert|pytest exit|s call|s setup" $OUT/${T}_pytest_gpu.log | tail -90 > $OUT/${T}_pytest_gpu_summary.log
   tail -4 $OUT/${T}_pytest_gpu_summary.log ;;
 tests16)
   # the whole kernel test file against the IEEE-half build (libvexpress_hip_f16.so), tolerances 8x tighter + the always-on f16 cases
@@ -88,6 +88,7 @@ pmc)
   bash tools/exp_pmc_bench.sh $T > $OUT/${T}_pmc.log 2>&1; tail -5 $OUT/pmc_${T}_passes.log ;;
 final)
   bash tools/gpu_job.sh box $T
+  cat /sys/fs/cgroup/cpu.max >> $OUT/${T}_box.log 2>&1
   bash tools/gpu_job.sh tests $T
   bash tools/gpu_job.sh smoke $T
   bash tools/gpu_job.sh bench $T

@@ -217,7 +217,7 @@ def _ptr(t):
 
 def _chk_bf16(t, name):
     if t.dtype != L.ELEM[0] or not t.is_cuda:
-        raise TypeError(f"{name}: expected a CUDA bf16 tensor, got {t.dtype} on {t.device}")
+        raise TypeError(f"{name}: expected a CUDA {L.ELEM[0]} tensor (the element type in force), got {t.dtype} on {t.device}")
 
 
 def _row_stride(t):
@@ -924,7 +924,7 @@ def padded_buffer(device, frames, H, W, c):
     """Persistent zero-bordered NHWC image [frames, (H+2)*(W+2), c] per shape.  Only `groupnorm(pad_hw=...)` writes
     into it (interior pixels only), so the border stays zero for the life of the process; the one buffer per shape
     is reused stream-ordered (the conv that reads it is enqueued before the next GroupNorm that refills it)."""
-    key = (device, _stream_key(device), frames, H, W, c)
+    key = (device, _stream_key(device), frames, H, W, c, L.ELEM[0])    # one image per element type (bf16 / half models in one process)
     buf = _PADDED.get(key)
     if buf is None:
         buf = torch.zeros((frames, (H + 2) * (W + 2), c), device=device, dtype=L.ELEM[0])

@@ -38,9 +38,19 @@ def _in_unet_element_type(fn):
 
     @functools.wraps(fn)
     def run(self, *args, **kwargs):
-        with L.element_type(self.denoising_unet._elem):
+        with L.element_type(_pipeline_element(self)):
             return fn(self, *args, **kwargs)
     return run
+
+
+def _pipeline_element(pipe):
+    """The denoising UNet's element type; a partial pipeline (the prologue helpers are callable on any object that
+    carries the components they use) falls back to the first component that has one, then to the type in force."""
+    for name in ("denoising_unet", "reference_net", "vae", "audio_projection", "audio_encoder", "v_kps_guider"):
+        elem = getattr(getattr(pipe, name, None), "_elem", None)
+        if elem is not None:
+            return elem
+    return L.ELEM[0]
 
 
 class VExpressPipeline:
