@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define VX_ABI_VERSION 14
+#define VX_ABI_VERSION 15
 
 const char* vx_last_error_string(void);
 int vx_abi_version(void);
@@ -248,6 +248,46 @@ int vx_tblock_pack(const void* wqkv, const float* bias, const float* colsum, con
                    const void* wo, void* wqkv_t, void* wo_t, float* colsum_p, int c, int heads, int f, void* stream);
 int vx_tblock_fused(const vx_tblock_params* p, void* stream);
 int64_t vx_tblock_packed_bytes(int f);
+
+/* ---- Audio cross-attention of a spatial transformer block in ONE launch (round 6, ABI 15) ------------------------------
+ * h <- h + alpha * to_out(softmax(q k^T / sqrt d) v),  q = to_q(LayerNorm(h)),  k | v = to_k | to_v of the frame's audio tokens:
+ * BasicTransformerBlock.attn2 as patched by modules/mutual_self_attention.py:227-244 (diffusers Attention + AttnProcessor2_0,
+ * hidden_states = norm2(h), encoder_hidden_states = audio tokens, the result weighted by audio_attention_weight and added to
+ * h).  A frame has FIVE audio tokens (AudioProjection num_queries, inference.py / modules/audio_projection.py), so per
+ * frame the block is two skinny products with frame-dependent operands that do not change over the DDIM steps:
+ *   S[m, (head, t)] = rstd_m (sum_c x[m, c] Kq_f[(head, t), c] - mean_m colsum_f[(head, t)]) + sbias_f[(head, t)],
+ *       Kq_f = log2(e) / sqrt(d) * K_f,head to_q_head  (to_q LayerNorm-folded like vx_gemm_params.ln_stats),
+ *   P = softmax over the 5 tokens of each head,   y[m, :] = x[m, :] + alpha (P VO_f^T + bias_o),   VO_f = to_out_head V_f,head^T.
+ * vx_audio_xattn_pack builds Kq_f / colsum / sbias / VO_f once per clip (kv: [frames * 5, ldkv] elements, K | V columns = the
+ * output of the to_k | to_v GEMM; wq: folded to_q weight [c, c] with bq its folded bias or NULL; wo: to_out weight [c, c]) into
+ * MFMA-fragment-major buffers of vx_audio_xattn_packed_bytes(c, frames) / 2 bytes each (+ float32 [frames][48] x 2);
+ * vx_audio_xattn streams the rows once: no [rows, c] query or attention-output tensor exists, FLOPs drop by c / 48 against the
+ * q / to_out projections it replaces.  8 heads, 5 tokens, c % 320 == 0, frames of rows_per_frame % 16 == 0 rows
+ * (vx_audio_xattn_supported); anything else keeps vx_gemm + vx_small_kv_attention + vx_gemm. */
+typedef struct {
+  const void* x;             /* elements [rows, ldx]: the residual stream h (read as the query source AND the residual) */
+  int32_t ldx;
+  void* out;                 /* elements [rows, ldo]; may be x (in place: a wave reads its rows before it writes them) */
+  int32_t ldo;
+  int32_t rows, c, rows_per_frame;   /* row r belongs to frame r / rows_per_frame of the packed operands */
+  const float* ln_stats;     /* LayerNorm statistics of x's rows: [rows][2] (mean, rstd) or [rows][4] two-part sums */
+  int32_t ln_stats_parts;    /* 0 / 2, as vx_gemm_params.ln_stats_parts */
+  float ln_eps;
+  const void* kq;            /* vx_audio_xattn_pack outputs */
+  const float* kq_colsum;
+  const float* kq_bias;
+  const void* vo;
+  const float* bias_o;       /* to_out bias [c] */
+  float alpha;               /* audio_attention_weight */
+  float* row_stats_out;      /* NULL, or the statistics of the STORED rows for the next LayerNorm fold (may alias ln_stats) */
+  int32_t row_stats_parts;   /* 0: (mean, rstd) [rows][2]; 2: two-part sums [rows][4] (vx_gemm_params.row_stats_parts) */
+  float row_stats_eps;
+} vx_axattn_params;
+int64_t vx_audio_xattn_packed_bytes(int c, int frames);
+int vx_audio_xattn_supported(int c, int heads, int n_ctx, int rows_per_frame);
+int vx_audio_xattn_pack(const void* kv, int ldkv, const void* wq, const float* bq, const void* wo, int c, int heads, int n_ctx,
+                        int frames, void* kq, float* kq_colsum, float* kq_bias, void* vo, void* stream);
+int vx_audio_xattn(const vx_axattn_params* p, void* stream);
 
 /* ---- GroupNorm (+SiLU), per-frame statistics, NHWC, optional dual (concat) source --------------------------
  * Replaces F.group_norm via InflatedGroupNorm (modules/resnet.py:20-28; :220-221,:235,:241), Transformer3DModel.norm

@@ -474,6 +474,66 @@ def test_small_kv_attention(ops, batch, n_q, n_kv, heads, d):
     check(out, ref, f"small-kv attention n_kv={n_kv} d={d}", rel=1e-2, mx=2 ** -6)
 
 
+@pytest.mark.parametrize("frames,hw,c,alpha", [(3, 64, 1280, 3.0), (2, 256, 1280, 3.0), (4, 1024, 640, 3.0), (16, 4096, 320, 3.0),
+                                               (1, 48, 320, 0.5)])
+def test_audio_xattn_one_launch(ops, frames, hw, c, alpha):
+    """vx_audio_xattn + vx_audio_xattn_pack (the audio cross-attention of a spatial transformer block as two 48-column products
+    with per-frame operands) against the fp32 statement of the block it replaces: modules/mutual_self_attention.py:227-244 ->
+    h + w * to_out(softmax(to_q(LN(h)) k^T / sqrt d) v), 8 heads, 5 audio tokens per frame.  Both statistics formats ([m, 2]
+    and the two-part [m, 4] of the 32x32 level), in place, the statistics of the written rows, 16- and 32-row waves; and a
+    launch over a subset of the frames is bit-identical to those rows of the full launch (batch invariance)."""
+    from v_express_amd import weights
+    heads, n_ctx, d = 8, 5, c // 8
+    m = frames * hw
+    assert ops.audio_xattn_applies(c, heads, n_ctx, hw)
+    g = torch.Generator().manual_seed(c + hw)
+    h = (torch.randn(m, c, generator=g) * 1.5 + 0.3).cuda().to(BF)
+    kv = (torch.randn(frames * n_ctx, 2 * c, generator=g) * 1.2).cuda().to(BF)
+    wq = torch.randn(c, c, generator=g) * c ** -0.5
+    wo = (torch.randn(c, c, generator=g) * c ** -0.5).cuda().to(BF)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+    bo = (torch.randn(c, generator=g) * 0.3).cuda()
+    Fq = weights.fold_layernorm(wq, None, gamma, beta, "cuda")
+    two = c == 640
+    st = torch.empty((m, 4 if two else 2), device="cuda", dtype=torch.float32)
+    ops.row_stats(h, 1e-5, out=st)
+    fold = ops.audio_xattn_pack(kv, Fq.w, Fq.b, wo, frames=frames, n_ctx=n_ctx, heads=heads)
+    st_out = torch.empty_like(st)
+    out = torch.empty_like(h)
+    ops.audio_xattn(h, st, fold, bo, alpha, rows_per_frame=hw, stats_out=st_out, out=out)
+    # fp32 reference on the same rounded inputs
+    x = h.float()
+    ln = F.layer_norm(x, (c,), gamma.cuda(), beta.cuda(), 1e-5)
+    q = (ln @ wq.cuda().t()).view(frames, hw, heads, d).transpose(1, 2)
+    k = kv[:, :c].float().view(frames, n_ctx, heads, d).transpose(1, 2)
+    v = kv[:, c:].float().view(frames, n_ctx, heads, d).transpose(1, 2)
+    a = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, dim=-1) @ v
+    ref = x + alpha * (a.transpose(1, 2).reshape(m, c) @ wo.float().t() + bo)
+    check(out, ref, f"audio_xattn c={c} hw={hw}", rel=8e-3, mx=2 ** -6)
+    # the block's own contribution, without the residual that dominates the norm above
+    check(out.float() - x, ref - x, f"audio_xattn increment c={c} hw={hw}", rel=2.5e-2, mx=2 ** -4)
+    # statistics of the STORED rows
+    o = out.float()
+    if two:
+        want = torch.stack([o[:, :c // 2].sum(1), o[:, :c // 2].pow(2).sum(1), o[:, c // 2:].sum(1), o[:, c // 2:].pow(2).sum(1)], 1)
+        assert torch.allclose(st_out, want, rtol=2e-4, atol=2e-2), (st_out - want).abs().max()
+    else:
+        mean, var = o.mean(1), o.var(1, unbiased=False)
+        assert torch.allclose(st_out[:, 0], mean, rtol=1e-4, atol=1e-4)
+        assert torch.allclose(st_out[:, 1], (var + 1e-5).rsqrt(), rtol=2e-3)
+    # in place, statistics written over the ones read
+    h2, st2 = h.clone(), st.clone()
+    ops.audio_xattn(h2, st2, fold, bo, alpha, rows_per_frame=hw, stats_out=st2)
+    assert torch.equal(h2, out) and torch.equal(st2, st_out)
+    # a subset of the frames: same bits
+    if frames > 1:
+        f0 = frames // 2
+        sub = ops.audio_xattn_pack(kv[f0 * n_ctx:], Fq.w, Fq.b, wo, frames=frames - f0, n_ctx=n_ctx, heads=heads)
+        o2 = torch.empty_like(h[f0 * hw:])
+        ops.audio_xattn(h[f0 * hw:], st[f0 * hw:].contiguous(), sub, bo, alpha, rows_per_frame=hw, out=o2)
+        assert torch.equal(o2, out[f0 * hw:])
+
+
 # ----------------------------------------------------------------------------------------------------- elementwise
 def test_add_row_bias(ops):
     x = rnd(50, 640)

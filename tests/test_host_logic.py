@@ -20,7 +20,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for n in names:
         assert hasattr(so, n), n
-    assert lib.lib.vx_abi_version() == 14
+    assert lib.lib.vx_abi_version() == 15
     # the binary says which sources it was compiled from (stamped by csrc/Makefile) and lib.py has compared that with the
     # sources on disk at import: a stale .so does not get this far
     src, _, defs = lib.lib.vx_build_id().decode().partition("|")
@@ -56,6 +56,29 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(vx_gemm_p
     G = lib.GemmParams
     assert got == [ctypes.sizeof(G), G.w.offset, G.alpha.offset, G.residual.offset, G.part_out.offset,
                    G.vt_pitch.offset, G.ring_hint.offset, G.ln_eps.offset, G.coop_epoch.offset]
+
+
+def test_axattn_params_struct_matches_header_layout():
+    """vx_axattn_params (ABI 15): the ctypes mirror against a C probe compiled from include/vexpress_hip.h; and the entry
+    point validates its arguments before any launch (no GPU needed)."""
+    import subprocess
+    import tempfile
+    from v_express_amd import lib
+    fields = ["ldx", "out", "rows", "rows_per_frame", "ln_stats", "ln_eps", "kq", "vo", "bias_o", "alpha", "row_stats_out",
+              "row_stats_parts", "row_stats_eps"]
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "vexpress_hip.h"\nint main(void){ printf("%zu", sizeof(vx_axattn_params));\n' +
+           "".join(f'printf(" %zu", offsetof(vx_axattn_params, {f}));\n' for f in fields) + 'printf("\\n"); return 0; }\n')
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "p.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.dirname(lib.HEADER), os.path.join(d, "p.c"), "-o", os.path.join(d, "p")])
+        got = list(map(int, subprocess.check_output([os.path.join(d, "p")]).split()))
+    A = lib.AxAttnParams
+    assert got == [ctypes.sizeof(A)] + [getattr(A, f).offset for f in fields]
+    assert lib.lib.vx_audio_xattn_supported(320, 8, 5, 4096) == 1 and lib.lib.vx_audio_xattn_supported(1280, 8, 5, 64) == 1
+    assert lib.lib.vx_audio_xattn_supported(320, 8, 4, 4096) == 0 and lib.lib.vx_audio_xattn_supported(64, 8, 5, 64) == 0
+    assert lib.lib.vx_audio_xattn_packed_bytes(320, 16) == 16 * 320 * 96
+    rc = lib.lib.vx_audio_xattn(ctypes.byref(A()), None)
+    assert rc < 0 and b"vx_audio_xattn" in lib.lib.vx_last_error_string()
 
 
 def test_windows_and_alignment_match_reference_context_py():
@@ -576,7 +599,7 @@ def test_float16_is_a_compute_dtype_and_device_spellings_compare_equal():
     # both libraries load, export every declared symbol, agree on the ABI and on the sources they were built from
     l16 = L.lib_f16()
     assert l16.vx_element_type() == b"f16" and L.lib.vx_element_type() == b"bf16"
-    assert l16.vx_abi_version() == L.lib.vx_abi_version() == 14 and l16.vx_build_id() == L.lib.vx_build_id()
+    assert l16.vx_abi_version() == L.lib.vx_abi_version() == 15 and l16.vx_build_id() == L.lib.vx_build_id()
     assert all(hasattr(l16, sym) for sym in L.declared_symbols())
     # the element type in force selects library and allocation dtype, and nests
     assert L.current() is L.lib and ops.BF16 is torch.bfloat16

@@ -171,6 +171,23 @@ def audio_kv(P, ehs):
     return ops.gemm(ehs, P.attn2.wkv)
 
 
+def _audio_fold(P, kv, f0, f1, n_ctx, heads):
+    """The vx_audio_xattn operands of frames f0 .. f1-1 of `kv`, built at first use and kept on the kv tensor object (which
+    the denoising loop holds for all DDIM steps of a window: unet_3d.precompute_audio_kv)."""
+    cache = getattr(kv, "_vx_audio_fold", None)
+    if cache is None:
+        cache = {}
+        try:
+            kv._vx_audio_fold = cache
+        except AttributeError:
+            pass
+    fold = cache.get((f0, f1))
+    if fold is None:
+        fold = cache[(f0, f1)] = ops.audio_xattn_pack(kv[f0 * n_ctx:f1 * n_ctx], P.ln_q2.w, P.ln_q2.b, P.attn2.out.w,
+                                                      frames=f1 - f0, n_ctx=n_ctx, heads=heads)
+    return fold
+
+
 def spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_ref, w_aud, kv=None, audio_zero=None):
     with ops.frame_rows(H * W, items=b):
         return _spatial_transformer_read(P, x, b=b, f=f, H=H, W=W, heads=heads, groups=groups, ehs=ehs, bank=bank,
@@ -246,7 +263,13 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
     n_ctx = ehs.shape[0] // frames
     if kv is None:
         kv = audio_kv(P, ehs)
-    if audio_zero is None or not any(audio_zero):
+    # One launch per (block, batch item with audio): q-projection, 5-key attention and out-projection collapse into two
+    # 48-column products with per-frame operands (ops.audio_xattn; built once per kv tensor, i.e. once per clip and window)
+    ax = f_q2 and ops.audio_xattn_applies(c, heads, n_ctx, hw)
+    if ax and (audio_zero is None or not any(audio_zero)):
+        ops.audio_xattn(h, st, _audio_fold(P, kv, 0, frames, n_ctx, heads), P.attn2.out.b, w_aud, rows_per_frame=hw,
+                        stats_out=st if f_ff else None)
+    elif audio_zero is None or not any(audio_zero):
         if f_q2:
             q = ops.gemm(h, P.ln_q2.w, P.ln_q2.b, ln=(st, P.ln_q2.s))
         else:
@@ -265,6 +288,10 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
                     ops.add_row_bias(hb, P.attn2.out.b, w_aud)
                     if f_ff:
                         ops.row_stats(hb, out=sb)      # the rows changed after their producer's statistics
+                continue
+            if ax:
+                ops.audio_xattn(hb, sb, _audio_fold(P, kv, bi * f, (bi + 1) * f, n_ctx, heads), P.attn2.out.b, w_aud,
+                                rows_per_frame=hw, stats_out=sb if f_ff else None)
                 continue
             with ops.frame_rows(hw, items=1):
                 if f_q2:

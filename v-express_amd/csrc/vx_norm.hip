@@ -29,10 +29,6 @@ constexpr int GN_MAX_SETS = 2;   // chunks per thread per pixel -> C <= 8*256*2 
 // loads per thread in flight.
 constexpr int GN_UNROLL = 4;
 constexpr int GN_SUBS = 8;      // parallel sub-sums of the per-slice partials in gn_apply
-#ifndef VX_GN_PRE
-#define VX_GN_PRE 8
-#endif
-constexpr int GN_PRE = VX_GN_PRE;   // 16-B loads of gn_apply in flight under its statistics prologue
 
 struct GnPlan {
   const bf16_t* base[GN_MAX_SETS];   // first pixel of the frame, at this thread's chunk (nullptr: no chunk)
@@ -263,18 +259,6 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
   float* gstat = shift + C;                        // [groups][2] mean, rstd
   double* dpart = reinterpret_cast<double*>(gstat + 2 * groups);   // [GN_SUBS][groups][2]
   const int cg = C / groups;
-  const GnPlan P = gn_plan(x1, c1, x2, c2, hw, frame);
-  const int p_begin = slice * slice_pix;
-  const int p_end = min(hw, p_begin + slice_pix);
-  // The first GN_PRE pixels of this thread's first channel chunk are requested BEFORE the statistics prologue (round 6): the
-  // prologue (re-reduction of the frame's partial sums in fp64, scale / shift table, three barriers: ~3 us in which all
-  // co-resident blocks of a CU used to have nothing in flight) then runs under their latency.  Element-wise pass: same bits.
-  uint4 pre[GN_PRE];
-#pragma unroll
-  for (int k = 0; k < GN_PRE; ++k) {
-    const int px = p_begin + P.pl + k * P.pl_count;
-    if (P.base[0] != nullptr && px < p_end) pre[k] = *reinterpret_cast<const uint4*>(P.base[0] + (size_t)px * P.pstride[0]);
-  }
   // `slices` partitions THIS kernel's work; the statistics were written as `stat_slices` partial sums per frame
   gn_group_stats(ws, frame, stat_slices, groups, cg, hw, eps, gstat, dpart);
   for (int ch = tid; ch < C; ch += GN_THREADS) {
@@ -284,6 +268,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
     shift[ch] = beta[ch] - gstat[g * 2 + 0] * sc;
   }
   __syncthreads();
+  const GnPlan P = gn_plan(x1, c1, x2, c2, hw, frame);
+  const int p_begin = slice * slice_pix;
+  const int p_end = min(hw, p_begin + slice_pix);
   // out_pad > 0: the destination is the interior of a [frames, H + 2*pad, W + 2*pad, C] image whose border the
   // caller keeps zero (so the following 3x3 conv needs no bounds checks: vx_gemm FAST path)
   const int wp = width + 2 * out_pad;
@@ -321,15 +308,6 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const bf16_t* __re
       *reinterpret_cast<uint4*>(oframe + (size_t)opix(px) * C + ch) = pack_bf16x8(f);
     };
     int px = p_begin + P.pl;
-    if (u == 0) {
-#pragma unroll
-      for (int k = 0; k < GN_PRE; ++k) {
-        if (px < p_end) {
-          emit(pre[k], px);
-          px += P.pl_count;
-        }
-      }
-    }
     for (; px + (GN_UNROLL - 1) * P.pl_count < p_end; px += GN_UNROLL * P.pl_count) {
       uint4 raw[GN_UNROLL];
 #pragma unroll

@@ -30,6 +30,16 @@ class FfParams(C.Structure):
     ]
 
 
+class AxAttnParams(C.Structure):
+    """Mirror of `vx_axattn_params` (include/vexpress_hip.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int32), ("out", C.c_void_p), ("ldo", C.c_int32), ("rows", C.c_int32), ("c", C.c_int32),
+        ("rows_per_frame", C.c_int32), ("ln_stats", C.c_void_p), ("ln_stats_parts", C.c_int32), ("ln_eps", C.c_float),
+        ("kq", C.c_void_p), ("kq_colsum", C.c_void_p), ("kq_bias", C.c_void_p), ("vo", C.c_void_p), ("bias_o", C.c_void_p),
+        ("alpha", C.c_float), ("row_stats_out", C.c_void_p), ("row_stats_parts", C.c_int32), ("row_stats_eps", C.c_float),
+    ]
+
+
 class TBlockParams(C.Structure):
     """Mirror of `vx_tblock_params` (include/vexpress_hip.h)."""
     _fields_ = [
@@ -125,6 +135,11 @@ def _load(path=None, element="bf16"):
     lib.vx_tblock_pack.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.vx_tblock_packed_bytes.argtypes = [i32]
     lib.vx_tblock_packed_bytes.restype = i64
+    lib.vx_audio_xattn_packed_bytes.argtypes = [i32, i32]
+    lib.vx_audio_xattn_packed_bytes.restype = i64
+    lib.vx_audio_xattn_supported.argtypes = [i32, i32, i32, i32]
+    lib.vx_audio_xattn_pack.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.vx_audio_xattn.argtypes = [C.POINTER(AxAttnParams), vp]
     lib.vx_groupnorm_fold_linear.argtypes = [vp, i32, i32, i32, i32, f32, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.vx_layernorm.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, i32, i32, vp, i32, vp]
     lib.vx_row_stats.argtypes = [vp, i32, i32, i32, f32, vp, vp]
@@ -151,9 +166,9 @@ def _load(path=None, element="bf16"):
         fn = getattr(lib, name)
         if name not in ("vx_last_error_string", "vx_groupnorm_ws_floats", "vx_gemm_config_name",
                         "vx_gemm_splitk_ws_bytes", "vx_gemm_last_kernel", "vx_last_kernel", "vx_build_id",
-                        "vx_tblock_packed_bytes", "vx_element_type"):
+                        "vx_tblock_packed_bytes", "vx_element_type", "vx_audio_xattn_packed_bytes"):
             fn.restype = i32
-    if lib.vx_abi_version() != 14:
+    if lib.vx_abi_version() != 15:
         raise ImportError(f"{os.path.basename(path)} ABI version mismatch")
     if lib.vx_element_type().decode() != element:
         raise ImportError(f"{path} computes on {lib.vx_element_type().decode()} elements, expected {element}")

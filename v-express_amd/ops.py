@@ -1113,6 +1113,81 @@ def small_kv_attention(q, kv, *, batch, n_q, n_kv, heads, head_dim, out=None):
     return out
 
 
+# The audio cross-attention of a spatial transformer block as ONE streaming launch (vx_audio_xattn, round 6): five audio
+# tokens per frame -> q-projection, 5-key attention and out-projection collapse into two 48-column products with per-frame
+# operands built once per clip (vx_audio_xattn_pack).  VX_AX_FUSED=0 restores the three launches (A/B knob).
+AX_FUSED = [os.environ.get("VX_AX_FUSED", "1") != "0"]
+
+
+class AudioFold:
+    """Per-frame operands of `audio_xattn` for `frames` frames of width c (vx_audio_xattn_pack outputs)."""
+
+    def __init__(self, kq, colsum, sbias, vo, frames, c):
+        self.kq, self.colsum, self.sbias, self.vo, self.frames, self.c = kq, colsum, sbias, vo, frames, c
+
+
+def audio_xattn_applies(c, heads, n_ctx, hw):
+    geom = (("c", c), ("heads", heads), ("n_ctx", n_ctx), ("hw%16", hw % 16))
+    one, three = "one launch (vx_audio_xattn)", "three launches (q GEMM + 5-key attention + output GEMM)"
+    if not AX_FUSED[0] or not LN_FOLD[0] or FP8_PROJ[0]:
+        return _note_path("audio_cross_attention", geom, False, three, "switched off / LayerNorm fold off / fp8 projections")
+    ok = bool(_lib.vx_audio_xattn_supported(int(c), int(heads), int(n_ctx), int(hw)))
+    return _note_path("audio_cross_attention", geom, ok, one if ok else three,
+                      "" if ok else "the one-launch form is built for 8 heads, 5 audio tokens per frame, c % 320 == 0")
+
+
+def audio_xattn_pack(kv, wq_folded, bq_folded, wo, *, frames, n_ctx, heads):
+    """kv: [frames*n_ctx, 2C] (K | V: the to_k | to_v GEMM of the audio tokens), wq_folded / bq_folded: the LayerNorm-folded
+    to_q weight [C, C] / bias [C] (weights.fold_layernorm), wo: to_out weight [C, C] -> AudioFold."""
+    _chk_bf16(kv, "kv")
+    _chk_bf16(wq_folded, "wq")
+    _chk_bf16(wo, "wo")
+    c = wo.shape[0]
+    if kv.shape != (frames * n_ctx, 2 * c) or tuple(wq_folded.shape) != (c, c) or tuple(wo.shape) != (c, c) or \
+            not wq_folded.is_contiguous() or not wo.is_contiguous():
+        raise ValueError("audio_xattn_pack: shapes")
+    if bq_folded is not None and (bq_folded.dtype != torch.float32 or bq_folded.numel() != c):
+        raise TypeError("audio_xattn_pack: folded bias must be float32 [C]")
+    dev = kv.device
+    kq = torch.empty((frames, 48 * c), device=dev, dtype=L.ELEM[0])
+    vo = torch.empty((frames, 48 * c), device=dev, dtype=L.ELEM[0])
+    cs = torch.empty((frames, 48), device=dev, dtype=torch.float32)
+    sb = torch.empty((frames, 48), device=dev, dtype=torch.float32)
+    L.check(_lib.vx_audio_xattn_pack(_ptr(kv), _row_stride(kv)[0], _ptr(wq_folded), _ptr(bq_folded), _ptr(wo), c, heads, n_ctx,
+                                     frames, _ptr(kq), _ptr(cs), _ptr(sb), _ptr(vo), _stream()), "vx_audio_xattn_pack")
+    return AudioFold(kq, cs, sb, vo, frames, c)
+
+
+def audio_xattn(h, stats, fold, bias_o, alpha, *, rows_per_frame, stats_out=None, stats_eps=1e-5, out=None):
+    """h [frames*rows_per_frame, C] <- h + alpha * attn2(LayerNorm(h), audio tokens) in one launch (in place unless `out`).
+    stats: the LayerNorm statistics of h's rows ([m, 2] or [m, 4], as ops.gemm(ln=...)); stats_out: receives the statistics of
+    the rows written (same formats; may be `stats`)."""
+    _chk_bf16(h, "h")
+    ldx, m = _row_stride(h)
+    c = h.shape[-1]
+    if out is None:
+        out = h
+    if m != fold.frames * rows_per_frame or c != fold.c:
+        raise ValueError(f"audio_xattn: {m} rows of width {c} against operands for {fold.frames} frames x {rows_per_frame} rows, width {fold.c}")
+    if stats.dtype != torch.float32 or not stats.is_contiguous() or tuple(stats.shape) not in ((m, 2), (m, 4)):
+        raise ValueError("audio_xattn: stats must be a contiguous float32 [m, 2] / [m, 4] tensor")
+    p = L.AxAttnParams()
+    p.x, p.ldx, p.out, p.ldo = h.data_ptr(), ldx, out.data_ptr(), _row_stride(out)[0]
+    p.rows, p.c, p.rows_per_frame = m, c, rows_per_frame
+    p.ln_stats, p.ln_stats_parts, p.ln_eps = stats.data_ptr(), 2 if stats.shape[1] == 4 else 0, 1e-5
+    p.kq, p.kq_colsum, p.kq_bias, p.vo = fold.kq.data_ptr(), fold.colsum.data_ptr(), fold.sbias.data_ptr(), fold.vo.data_ptr()
+    p.bias_o, p.alpha = bias_o.data_ptr(), float(alpha)
+    if stats_out is not None:
+        if stats_out.dtype != torch.float32 or not stats_out.is_contiguous() or tuple(stats_out.shape) not in ((m, 2), (m, 4)):
+            raise ValueError("audio_xattn: stats_out must be a contiguous float32 [m, 2] / [m, 4] tensor")
+        p.row_stats_out, p.row_stats_parts, p.row_stats_eps = stats_out.data_ptr(), 2 if stats_out.shape[1] == 4 else 0, float(stats_eps)
+    # algorithmic bytes: the rows read once and written once, the per-frame operands once
+    with _hbm_op("audio_xattn", 2 * (2 * m * c + 2 * fold.frames * 48 * c)):
+        L.check(_lib.vx_audio_xattn(C.byref(p), _stream()), "vx_audio_xattn")
+    _set_gn(out)
+    return out
+
+
 def add_row_bias(x, bias, alpha=1.0):
     ldx, rows = _row_stride(x)
     L.check(_lib.vx_add_row_bias(_ptr(x), ldx, rows, x.shape[-1], _ptr(bias), float(alpha), _stream()),
