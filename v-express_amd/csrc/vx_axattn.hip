@@ -388,18 +388,61 @@ __global__ __launch_bounds__(256) void axattn_split_kernel(const vx_axattn_param
   }
 }
 
-// ---- once per clip: the per-frame operands.  grid (frames, 48 slots): one block = one row of Kq (C columns) + its column
-// sum (of the ROUNDED values the MFMA sees, like weights.fold_layernorm) + its bias; padding slots are zero rows.
+// ---- once per clip: the per-frame operands.  Both products are [frames * 5 tokens, d] x [d, C] per head - tiny, but a
+// block per output row re-reads the head's weight slice 80 times (first version: 98 + 191 us per transformer block, 4.6 ms per
+// clip).  Here a block = (head, 64 output columns / rows, 16 frames): the head's K (or V) rows of those frames sit in LDS as
+// float (80 x d <= 51 KB), the weight slice is read ONCE, and every thread owns one column x 20 (frame, token) rows.
+constexpr int AXP_FR = 16;                       // frames per block
+constexpr int AXP_ROWS = AXP_FR * AX_TOK;        // 80 (frame, token) rows
+constexpr int AXP_RPT = AXP_ROWS / 4;            // 20 rows per thread (4 row groups x 64 columns = 256 threads)
+
+__device__ __forceinline__ int ax_kq_index(int KS, int frame, int slot, int col) {
+  const int ks = col >> 5, fgrp = (col & 31) >> 3, e = col & 7;
+  return ((frame * KS + ks) * 3 + (slot >> 4)) * 512 + (fgrp * 16 + (slot & 15)) * 8 + e;
+}
+
+// grid (8 heads, C / 64, ceil(frames / 16)); dynamic LDS 80 * d floats
 __global__ __launch_bounds__(256) void axattn_pack_kq_kernel(const bf16_t* __restrict__ kv, int ldkv, const bf16_t* __restrict__ wq,
-                                                             const float* __restrict__ bq, int c, int d, float scale,
-                                                             bf16_t* __restrict__ kq, float* __restrict__ colsum,
-                                                             float* __restrict__ sbias) {
+                                                             int c, int d, float scale, int frames, bf16_t* __restrict__ kq) {
+  extern __shared__ float kvals[];               // [80][d]
+  const int h = blockIdx.x, col = blockIdx.y * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6, f0 = blockIdx.z * AXP_FR;
+  const int nrows = min(AXP_FR, frames - f0) * AX_TOK;
+  for (int i = threadIdx.x; i < AXP_ROWS * d; i += 256) {
+    const int r = i / d, j = i - r * d;
+    kvals[i] = r < nrows ? bf16_to_f32(kv[(size_t)(f0 * AX_TOK + r) * ldkv + h * d + j]) : 0.f;
+  }
+  __syncthreads();
+  float acc[AXP_RPT];
+#pragma unroll
+  for (int r = 0; r < AXP_RPT; ++r) acc[r] = 0.f;
+  const bf16_t* wcol = wq + (size_t)(h * d) * c + col;
+  const float* kr = kvals + (size_t)(rg * AXP_RPT) * d;
+#pragma unroll 4
+  for (int j = 0; j < d; ++j) {
+    const float w = bf16_to_f32(wcol[(size_t)j * c]);
+#pragma unroll
+    for (int r = 0; r < AXP_RPT; ++r) acc[r] = fmaf(kr[r * d + j], w, acc[r]);
+  }
+  const int KS = c >> 5;
+#pragma unroll
+  for (int r = 0; r < AXP_RPT; ++r) {
+    const int row = rg * AXP_RPT + r;
+    if (row < nrows) {
+      const int fr = f0 + row / AX_TOK, t = row % AX_TOK;
+      kq[ax_kq_index(KS, fr, ax_slot(h, t), col)] = f32_to_bf16(acc[r] * scale);
+    }
+  }
+}
+
+// grid (frames, 48): the padding slots' zero rows, the column sums of the ROUNDED values the MFMA sees (like
+// weights.fold_layernorm; fixed-order tree) and the bias  sbias[(h, t)] = scale * sum_j K[t, h d + j] bq[h d + j]
+__global__ __launch_bounds__(256) void axattn_pack_sums_kernel(const bf16_t* __restrict__ kv, int ldkv, const float* __restrict__ bq,
+                                                               int c, int d, float scale, bf16_t* __restrict__ kq,
+                                                               float* __restrict__ colsum, float* __restrict__ sbias) {
   __shared__ float red[256];
-  __shared__ float kvals[256];       // d <= 256
   const int frame = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x;
   const int KS = c >> 5;
-  // inverse of ax_slot
-  int h = -1, t = -1;
+  int h = -1, t = -1;            // inverse of ax_slot
   if (slot < 32) {
     h = 4 * (slot >> 4) + ((slot & 15) >> 2);
     t = slot & 3;
@@ -407,24 +450,11 @@ __global__ __launch_bounds__(256) void axattn_pack_kq_kernel(const bf16_t* __res
     h = ((slot - 32) >> 2) + 4 * ((slot - 32) & 3);
     t = 4;
   }
-  const int j16 = slot >> 4, frow = slot & 15;
-  bf16_t* dst = kq + (size_t)frame * KS * (3 * 512);
   float part = 0.f;
-  if (h >= 0) {
-    const bf16_t* krow = kv + (size_t)(frame * AX_TOK + t) * ldkv + h * d;
-    for (int j = tid; j < d; j += 256) kvals[j] = bf16_to_f32(krow[j]);
-  }
-  __syncthreads();
   for (int col = tid; col < c; col += 256) {
-    float acc = 0.f;
-    if (h >= 0) {
-      for (int j = 0; j < d; ++j) acc = fmaf(kvals[j], bf16_to_f32(wq[(size_t)(h * d + j) * c + col]), acc);
-      acc *= scale;
-    }
-    const bf16_t r = f32_to_bf16(acc);
-    part += bf16_to_f32(r);
-    const int ks = col >> 5, fgrp = (col & 31) >> 3, e = col & 7;
-    dst[(size_t)(ks * 3 + j16) * 512 + (fgrp * 16 + frow) * 8 + e] = r;
+    const int idx = ax_kq_index(KS, frame, slot, col);
+    if (h < 0) kq[idx] = 0;
+    else part += bf16_to_f32(kq[idx]);
   }
   red[tid] = part;
   __syncthreads();
@@ -432,46 +462,65 @@ __global__ __launch_bounds__(256) void axattn_pack_kq_kernel(const bf16_t* __res
     if (tid < s) red[tid] += red[tid + s];
     __syncthreads();
   }
+  const float cs = red[0];
+  __syncthreads();
+  float sb = 0.f;
+  if (h >= 0 && bq != nullptr)
+    for (int j = tid; j < d; j += 256) sb = fmaf(bf16_to_f32(kv[(size_t)(frame * AX_TOK + t) * ldkv + h * d + j]), bq[h * d + j], sb);
+  red[tid] = sb;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
   if (tid == 0) {
-    colsum[(size_t)frame * AX_SLOTS + slot] = red[0];
-    float sb = 0.f;
-    if (h >= 0 && bq != nullptr) {
-      for (int j = 0; j < d; ++j) sb = fmaf(kvals[j], bq[h * d + j], sb);
-      sb *= scale;
-    }
-    sbias[(size_t)frame * AX_SLOTS + slot] = sb;
+    colsum[(size_t)frame * AX_SLOTS + slot] = cs;
+    sbias[(size_t)frame * AX_SLOTS + slot] = red[0] * scale;
   }
 }
 
-// grid (frames, C / 32): thread = (output channel n of the block's 32, head h) -> the 5 tokens of that head
+// grid (8 heads, C / 64 output channels, ceil(frames / 16)); thread = one output channel n x 20 (frame, token) rows; the
+// thread's weight row segment wo[n, h d .. h d + d) is read once, 16 bytes at a time
 __global__ __launch_bounds__(256) void axattn_pack_vo_kernel(const bf16_t* __restrict__ kv, int ldkv, const bf16_t* __restrict__ wo,
-                                                             int c, int d, bf16_t* __restrict__ vo) {
-  const int frame = blockIdx.x, tid = threadIdx.x;
-  const int n = blockIdx.y * 32 + (tid >> 3), h = tid & 7;
-  const int NB = c >> 4;
-  const bf16_t* wrow = wo + (size_t)n * c + h * d;
-  float acc[AX_TOK];
-#pragma unroll
-  for (int t = 0; t < AX_TOK; ++t) acc[t] = 0.f;
-  for (int j = 0; j < d; ++j) {
-    const float w = bf16_to_f32(wrow[j]);
-#pragma unroll
-    for (int t = 0; t < AX_TOK; ++t)
-      acc[t] = fmaf(w, bf16_to_f32(kv[(size_t)(frame * AX_TOK + t) * ldkv + c + h * d + j]), acc[t]);
+                                                             int c, int d, int frames, bf16_t* __restrict__ vo) {
+  extern __shared__ float vvals[];               // [80][d]
+  const int h = blockIdx.x, n = blockIdx.y * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6, f0 = blockIdx.z * AXP_FR;
+  const int nrows = min(AXP_FR, frames - f0) * AX_TOK;
+  for (int i = threadIdx.x; i < AXP_ROWS * d; i += 256) {
+    const int r = i / d, j = i - r * d;
+    vvals[i] = r < nrows ? bf16_to_f32(kv[(size_t)(f0 * AX_TOK + r) * ldkv + c + h * d + j]) : 0.f;
   }
-  bf16_t* dst = vo + (size_t)frame * NB * (3 * 256);
-  const int nb = n >> 4, frow = n & 15;
+  __syncthreads();
+  float acc[AXP_RPT];
 #pragma unroll
-  for (int t = 0; t < AX_TOK; ++t) {
-    const int slot = ax_slot(h, t);
-    const int jk = slot >> 4, fgrp = (slot & 15) >> 2, e = slot & 3;
-    dst[(size_t)(nb * 3 + jk) * 256 + (fgrp * 16 + frow) * 4 + e] = f32_to_bf16(acc[t]);
+  for (int r = 0; r < AXP_RPT; ++r) acc[r] = 0.f;
+  const bf16_t* wrow = wo + (size_t)n * c + h * d;          // d % 8 == 0 (c % 320 == 0, 8 heads), rows 16-byte aligned
+  const float* vr = vvals + (size_t)(rg * AXP_RPT) * d;
+  for (int j8 = 0; j8 < d; j8 += 8) {
+    float w[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(wrow + j8), w);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int r = 0; r < AXP_RPT; ++r) acc[r] = fmaf(vr[r * d + j8 + e], w[e], acc[r]);
   }
-  // padding slots 32 + 4 q + 2, + 3 of this row: written by the threads of heads 0 .. 3 (q = h)
+  const int NB = c >> 4, nb = n >> 4, frow = n & 15;
+#pragma unroll
+  for (int r = 0; r < AXP_RPT; ++r) {
+    const int row = rg * AXP_RPT + r;
+    if (row < nrows) {
+      const int fr = f0 + row / AX_TOK, t = row % AX_TOK;
+      const int slot = ax_slot(h, t);
+      vo[((size_t)(fr * NB + nb) * 3 + (slot >> 4)) * 256 + (((slot & 15) >> 2) * 16 + frow) * 4 + (slot & 3)] = f32_to_bf16(acc[r]);
+    }
+  }
+  // the padding slots 32 + 4 q + 2, + 3 (q = 0 .. 3) of this thread's row: heads 0 .. 3 write those of q = h
   if (h < 4) {
-    const int slot = 32 + 4 * h + 2;
-    dst[(size_t)(nb * 3 + 2) * 256 + (((slot & 15) >> 2) * 16 + frow) * 4 + 2] = 0;
-    dst[(size_t)(nb * 3 + 2) * 256 + (((slot & 15) >> 2) * 16 + frow) * 4 + 3] = 0;
+    for (int row = rg; row < nrows / AX_TOK; row += 4) {
+      bf16_t* dst = vo + ((size_t)((f0 + row) * NB + nb) * 3 + 2) * 256 + (h * 16 + frow) * 4;
+      dst[2] = 0;
+      dst[3] = 0;
+    }
   }
 }
 
@@ -499,12 +548,29 @@ extern "C" int vx_audio_xattn_pack(const void* kv, int ldkv, const void* wq, con
   hipStream_t stream = (hipStream_t)stream_;
   const int d = c / heads;
   const float scale = 1.4426950408889634f / sqrtf((float)d);
-  hipLaunchKernelGGL(axattn_pack_kq_kernel, dim3(frames, AX_SLOTS), dim3(256), 0, stream, (const bf16_t*)kv, ldkv,
-                     (const bf16_t*)wq, bq, c, d, scale, (bf16_t*)kq, kq_colsum, kq_bias);
+  const unsigned fz = (unsigned)((frames + AXP_FR - 1) / AXP_FR);
+  const size_t lds = (size_t)AXP_ROWS * d * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)axattn_pack_kq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 256 * 4);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)axattn_pack_vo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 256 * 4);
+    if (e != hipSuccess) {
+      vx_set_error("vx_audio_xattn_pack: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return VX_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(axattn_pack_kq_kernel, dim3(AX_HEADS, c / 64, fz), dim3(256), lds, stream, (const bf16_t*)kv, ldkv,
+                     (const bf16_t*)wq, c, d, scale, frames, (bf16_t*)kq);
   int rc = vx_check_launch("vx_audio_xattn_pack(kq)");
   if (rc) return rc;
-  hipLaunchKernelGGL(axattn_pack_vo_kernel, dim3(frames, c / 32), dim3(256), 0, stream, (const bf16_t*)kv, ldkv,
-                     (const bf16_t*)wo, c, d, (bf16_t*)vo);
+  hipLaunchKernelGGL(axattn_pack_sums_kernel, dim3(frames, AX_SLOTS), dim3(256), 0, stream, (const bf16_t*)kv, ldkv, bq, c, d,
+                     scale, (bf16_t*)kq, kq_colsum, kq_bias);
+  rc = vx_check_launch("vx_audio_xattn_pack(sums)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(axattn_pack_vo_kernel, dim3(AX_HEADS, c / 64, fz), dim3(256), lds, stream, (const bf16_t*)kv, ldkv,
+                     (const bf16_t*)wo, c, d, frames, (bf16_t*)vo);
   return vx_check_launch("vx_audio_xattn_pack(vo)");
 }
 
