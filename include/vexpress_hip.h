@@ -385,6 +385,12 @@ int vx_small_kv_attention(const void* q, int ldq, const void* kv, int ldkv, int 
 /* ---- elementwise / layout ---------------------------------------------------------------------------------- */
 /* x[r, :] += alpha * bias[:]  (uncond half of reference attention == to_out bias) */
 int vx_add_row_bias(void* x, int ldx, int rows, int c, const float* bias, float alpha, void* stream);
+/* out[r, :] = element(x[r, :] + y[r, :]) with y float32 (ABI 15): the last two steps of vx_gemm's STORE epilogue (add the
+ * residual, round once) for an accumulator row that was written with out_f32 and moved between GPUs before the residual
+ * it belongs to is at hand - the frame-sharded motion module's folded feed-forward output / proj_out GEMM runs in the
+ * pixel-shard layout, its float32 rows go through the all-to-all, and the residual add happens in the frame-shard layout
+ * with the bits of the unsharded launch. */
+int vx_add_residual_f32(const void* x, int ldx, const float* y, int ldy, int rows, int c, void* out, int ldo, void* stream);
 /* gather window frames of the fp32 latent clip [1,C,F,h,w] into NHWC bf16 [reps*f, h*w, c_pad] (channels >= C zero).
  * Replaces latents[:, :, context].repeat(2,...) + rearrange (pipelines/v_express_pipeline.py:538-539, resnet.py:13). */
 int vx_gather_latents(const float* latents, int c, int total_frames, int hw, const int32_t* frame_ids, int f,

@@ -204,11 +204,14 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=0
         grp = torch.arange(y.shape[0]) // rows_per_group
         y = y + rowbias[grp, :y.shape[1]]
     y = _act(y, act)
+    # the accumulator + bias is a float32 value in the kernel; the residual is added to it in float32, then ONE rounding to
+    # the element type (so that add_residual_f32(x, gemm(..., out_f32=True)) has the bits of gemm(..., residual=x))
+    y = y.float()
     if residual is not None:
-        y = residual.double().reshape(y.shape) + alpha * y
+        y = residual.float().reshape(y.shape) + (y if alpha == 1.0 else torch.tensor(alpha, dtype=torch.float32) * y)
     elif alpha != 1.0:
-        y = alpha * y
-    y = y.float() if out_f32 else y.to(BF16)
+        y = torch.tensor(alpha, dtype=torch.float32) * y
+    y = y if out_f32 else y.to(BF16)
     if stats_out is not None:                          # statistics of the STORED rows (vx_gemm_params.row_stats_out)
         assert not out_f32
         row_stats(y, stats_eps, out=stats_out)
@@ -320,6 +323,64 @@ def small_kv_attention(q, kv, *, batch, n_q, n_kv, heads, head_dim, out=None):
     return o
 
 
+class _FakeAudioFold:
+    def __init__(self, kq, colsum, sbias, vo, frames, c, heads, n_ctx):
+        self.kq, self.colsum, self.sbias, self.vo, self.frames, self.c, self.heads, self.n_ctx = kq, colsum, sbias, vo, frames, c, heads, n_ctx
+
+
+def audio_xattn_pack(kv, wq_folded, bq_folded, wo, *, frames, n_ctx, heads):
+    """vx_audio_xattn_pack with the kernel's rounding points: Kq_f[(h, t), :] = bf16(log2(e) / sqrt(d) K_f,h[t] Wq_h),
+    colsum of the ROUNDED rows, sbias in float, VO_f[:, (h, t)] = bf16(Wo_h V_f,h[t])  (natural [frames, heads, n_ctx, C] order)."""
+    c = wo.shape[0]
+    d = c // heads
+    scale = 1.4426950408889634 / d ** 0.5
+    k = kv[:, :c].double().reshape(frames, n_ctx, heads, d)
+    v = kv[:, c:].double().reshape(frames, n_ctx, heads, d)
+    wq = wq_folded.double().reshape(heads, d, c)                        # rows h d + j
+    kq = (torch.einsum("fthj,hjc->fhtc", k, wq) * scale).to(BF16)
+    colsum = kq.double().sum(-1)
+    sbias = torch.zeros(frames, heads, n_ctx, dtype=torch.float64)
+    if bq_folded is not None:
+        sbias = torch.einsum("fthj,hj->fht", k, bq_folded.double().reshape(heads, d)) * scale
+    wo_h = wo.double().reshape(c, heads, d)
+    vo = torch.einsum("nhj,fthj->fhtn", wo_h, v).to(BF16)
+    return _FakeAudioFold(kq, colsum, sbias, vo, frames, c, heads, n_ctx)
+
+
+def audio_xattn(h, stats, fold, bias_o, alpha, *, rows_per_frame, stats_out=None, stats_eps=1e-5, out=None):
+    """vx_audio_xattn: S = LN-folded x Kq^T (+ sbias), base-2 softmax per head, P rounded to bf16, y = x + alpha (P VO^T + b)."""
+    m, c = h.shape
+    assert m == fold.frames * rows_per_frame and c == fold.c
+    x = h.double().reshape(fold.frames, rows_per_frame, c)
+    st = stats.double()
+    if stats.shape[1] == 4:
+        mean = (st[:, 0] + st[:, 2]) / c
+        var = ((st[:, 1] + st[:, 3]) / c - mean * mean).clamp_min(0)
+        st = torch.stack([mean, torch.rsqrt(var + 1e-5)], dim=1)
+    mean = st[:, 0].reshape(fold.frames, rows_per_frame, 1, 1)
+    rstd = st[:, 1].reshape(fold.frames, rows_per_frame, 1, 1)
+    s = torch.einsum("frc,fhtc->frht", x, fold.kq.double())
+    s = rstd * (s - mean * fold.colsum[:, None]) + fold.sbias[:, None]
+    p = torch.softmax(s * 0.6931471805599453, dim=-1).to(BF16).double()        # 2^s = e^(s ln 2)
+    y = torch.einsum("frht,fhtn->frn", p, fold.vo.double()) + bias_o.double()
+    y = (x + alpha * y).reshape(m, c).to(BF16)
+    if stats_out is not None:
+        row_stats(y, stats_eps, out=stats_out)
+    dst = h if out is None else out
+    dst.copy_(y)
+    return dst
+
+
+def add_residual_f32(x, y32, out=None):
+    """vx_add_residual_f32: the residual add (float32) and the one rounding of the STORE epilogue."""
+    assert y32.dtype == torch.float32 and y32.shape == x.shape
+    r = (x.float() + y32).to(BF16)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
 def add_row_bias(x, bias, alpha=1.0):
     x.copy_((x.double() + alpha * bias).to(BF16))
     return x
@@ -387,7 +448,7 @@ def vae_postprocess(x, n, c, h, w):
 
 
 ALL = ("wave_conv1d", "groupnorm", "groupnorm_stats", "groupnorm_fold_linear", "layernorm", "row_stats", "layernorm_fp8", "quantize_fp8", "gemm", "geglu", "ff_fused", "tblock_fused", "alloc_vt", "gemm_split", "key_norm_max", "attention",
-       "temporal_attention", "small_kv_attention", "add_row_bias", "gather_latents", "cfg_combine", "pack_rows", "combine_units", "overlap_ddim_step",
+       "temporal_attention", "small_kv_attention", "audio_xattn_pack", "audio_xattn", "add_residual_f32", "add_row_bias", "gather_latents", "cfg_combine", "pack_rows", "combine_units", "overlap_ddim_step",
        "ncfhw_to_nhwc", "nhwc_to_ncfhw", "vae_postprocess")
 
 

@@ -83,7 +83,9 @@ def _worker(rank, world, port, F, cs, co, steps, q, S=1):
     frames = torch.zeros(distributed.split_frames(F, world)[0][1], 3)
     frames[:hi - lo] = float(rank + 1)
     allf = dc.all_gather_frames(frames).reshape(-1, 3)[:F]
-    q.put((rank, out, allf[:, 0].clone()))
+    # by VALUE (numpy arrays are pickled into the queue): a torch tensor travels as a file descriptor that the parent must
+    # fetch from THIS process while it is still alive - on a busy machine the child was gone first (EOFError in q.get)
+    q.put((rank, out.numpy().copy(), allf[:, 0].numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -101,6 +103,7 @@ def test_sharded_loop_is_bit_identical_to_single_process(F, cs, co):
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in procs]
+    results = [(r, torch.from_numpy(o), torch.from_numpy(w)) for r, o, w in results]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -120,6 +123,7 @@ def _spawn(world, F, cs, co, steps, S):
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in procs]
+    results = [(r, torch.from_numpy(o), torch.from_numpy(w)) for r, o, w in results]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -474,6 +474,33 @@ def test_small_kv_attention(ops, batch, n_q, n_kv, heads, d):
     check(out, ref, f"small-kv attention n_kv={n_kv} d={d}", rel=1e-2, mx=2 ** -6)
 
 
+@pytest.mark.parametrize("m,c,hw", [(8192, 640, 1024), (2048, 1280, 256)])
+def test_ff_proj_fold_dual_source_gemm(ops, m, c, hw):
+    """weights.fold_ff_proj: a transformer block's proj_out folded into the feed-forward's second linear -
+    out = [h | g] [Wp | Wp W2]^T + (bp + Wp b2) + x_in as ONE dual-source GEMM (K = 5C) - against the fp32 statement of the
+    two layers it replaces (modules/transformer_3d.py:150-169: ff.net.2 + residual, then proj_out + residual)."""
+    from v_express_amd import weights
+    g_ = torch.Generator().manual_seed(c)
+    sd = {"ff.weight": torch.randn(c, 4 * c, generator=g_) * (4 * c) ** -0.5, "ff.bias": torch.randn(c, generator=g_) * 0.1,
+          "po.weight": (torch.randn(c, c, generator=g_) * c ** -0.5).view(c, c, 1, 1), "po.bias": torch.randn(c, generator=g_) * 0.1}
+    Fp = weights.fold_ff_proj(sd, "ff", "po", "cuda")
+    assert tuple(Fp.w.shape) == (c, 5 * c) and Fp.w.dtype == BF
+    h, gg, x_in = rnd(m, c), rnd(m, 4 * c, seed=1), rnd(m, c, seed=2)
+    with ops.frame_rows(hw, items=2):
+        out = ops.gemm(h, Fp.w, Fp.b, a2=gg, residual=x_in, gn=(32, hw))
+    w2, b2 = sd["ff.weight"].cuda(), sd["ff.bias"].cuda()
+    wp, bp = sd["po.weight"].view(c, c).cuda(), sd["po.bias"].cuda()
+    h1 = h.float() + gg.float() @ w2.t() + b2
+    ref = x_in.float() + h1 @ wp.t() + bp
+    check(out, ref, f"ff_proj fold c={c}", rel=8e-3, mx=2 ** -6)
+    assert ops.gn_of(out) is not None            # the next GroupNorm's partial sums ride in the same launch
+    # frame shards (blocks._motion_module): the same GEMM into float32 (accumulator + bias), the residual added afterwards by
+    # vx_add_residual_f32 - the bits of the one-launch form, whichever tile kernels the two launches take
+    with ops.frame_rows(hw, items=2):
+        y32 = ops.gemm(h, Fp.w, Fp.b, a2=gg, out_f32=True)
+    assert torch.equal(ops.add_residual_f32(x_in, y32), out)
+
+
 @pytest.mark.parametrize("frames,hw,c,alpha", [(3, 64, 1280, 3.0), (2, 256, 1280, 3.0), (4, 1024, 640, 3.0), (16, 4096, 320, 3.0),
                                                (1, 48, 320, 0.5)])
 def test_audio_xattn_one_launch(ops, frames, hw, c, alpha):

@@ -207,7 +207,7 @@ def _worker(rank, world, port, F, cf, co, S, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     W.emulate_kernels()
     lat = W.run(F, cf, co, 2, S, device="cpu")
-    q.put((rank, lat))
+    q.put((rank, lat.float().numpy().copy()))      # by value: a tensor's file descriptor must be fetched while this process lives
     dist.barrier()
     dist.destroy_process_group()
 
@@ -228,7 +228,7 @@ def test_sharded_loop_with_the_real_host_code_matches_single_process(emulated, w
     procs = [ctx.Process(target=_worker, args=(r, world, port, F, cf, co, S, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=600) for _ in procs]
+    results = [(r, torch.from_numpy(a)) for r, a in (q.get(timeout=600) for _ in procs)]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -256,7 +256,7 @@ def test_sharded_loop_with_the_round4_paths_forced_on(emulated, monkeypatch, wor
     procs = [ctx.Process(target=_worker, args=(r, world, port, F, cf, co, S, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=600) for _ in procs]
+    results = [(r, torch.from_numpy(a)) for r, a in (q.get(timeout=600) for _ in procs)]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -393,7 +393,7 @@ def _call_worker(rank, world, port, q):
                reference_attention_weight=cases.W_REF, audio_attention_weight=cases.W_AUD, generator=None,
                reference_latents=inp["ref_latents"], kps_features=inp["kps_features"],
                audio_embeddings=inp["audio_embeddings"], decode=False)
-    q.put((rank, lat.clone()))
+    q.put((rank, lat.float().numpy().copy()))      # by value (see _worker)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -409,7 +409,7 @@ def test_call_without_generator_gives_every_rank_the_same_clip():
     procs = [ctx.Process(target=_call_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=600) for _ in procs)
+    results = {r: torch.from_numpy(a) for r, a in (q.get(timeout=600) for _ in procs)}
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

@@ -63,12 +63,21 @@ def main():
                 marker.cos_()
                 return r
         return orig(*a, **k)
-    whole = fn_name == "step"
+    whole = fn_name in ("step", "vae")
     if not whole:
         setattr(B, fn_name, wrapped)
+    if fn_name == "vae":
+        vae.load_state_dict(synth.vae_decoder_state_dict(synth.VaeConfig(), seed=44, device=dev, dtype=elem, draw_on_device=True))
+        vae._prepared()
+        vae.decode_video(inp["latents"][:, :, :8].contiguous())
+        torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
-        if whole:
+        if fn_name == "vae":
+            marker.cos_()
+            vae.decode_video(inp["latents"][:, :, :8].contiguous())     # one chunk of 8 frames (a 16-frame clip = two)
+            marker.cos_()
+        elif whole:
             # two DDIM steps, markers around the SECOND (the first carries the once-per-clip work: audio K | V, operand packs)
             lat = inp["latents"].clone()
             orig_step = ops.overlap_ddim_step

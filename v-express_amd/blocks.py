@@ -130,9 +130,13 @@ def _norm_proj_in(P, x, frames, hw, groups, stats_out=None):
     return ops.gemm(n.view(m, c), P.proj_in.w, P.proj_in.b, stats_out=stats_out)
 
 
-def _feed_forward(P, h, stats=None):
+def _feed_forward(P, h, stats=None, proj=None):
     """h += FF(LN(h)): GEGLU fused in the first GEMM's epilogue (with the LayerNorm folded into that GEMM when the
     weights carry the fold), residual in the second's.  stats: the row statistics of h when its producer emitted them.
+    proj = (residual, gn): the block's proj_out follows (out = proj_out(h) + residual, nothing else reads h; residual None:
+    float32 rows without the residual, see _motion_module): where
+    `ops.ff_proj_fold_applies` the second GEMM and proj_out run as ONE dual-source launch over [h | g] with the load-time
+    fold weights.fold_ff_proj, and the function RETURNS out (None otherwise: the caller runs proj_out itself).
     ops.FF_SLAB_BYTES: the [rows, 4C] GEGLU result of a whole launch (335 MB at the 64x64 level) is larger than the 256 MB
     Infinity Cache, so the second GEMM re-reads all of it from HBM; run in row slabs whose intermediate fits, each slab's
     second GEMM right behind its first, it reads what the first just wrote.  Rows are independent: same bits."""
@@ -152,7 +156,12 @@ def _feed_forward(P, h, stats=None):
         stats = ops.row_stats(h)
     if fold and ops.ff_fused_applies(m, c, n_hidden):
         ops.ff_fused(h, F.w, F.b, F.s, stats, P.ff.out.w, P.ff.out.b)      # one launch, no [m, 4C] intermediate
-        return
+        return None
+    if proj is not None and fold and slabs == 1 and P.get("ff_proj") is not None and ops.ff_proj_fold_applies(m, c, n_hidden):
+        residual, gn = proj
+        g = ops.geglu(h, F.w, F.b, ln=(stats, F.s))
+        # residual None: the caller adds it later (frame shards) - float32 rows = accumulator + bias, unrounded
+        return ops.gemm(h, P.ff_proj.w, P.ff_proj.b, a2=g, residual=residual, gn=gn, out_f32=residual is None)
     rows = m // slabs
     for i in range(slabs):
         hs = h[i * rows:(i + 1) * rows]
@@ -162,6 +171,7 @@ def _feed_forward(P, h, stats=None):
             ln = ops.layernorm(hs, P.norm3.g if "norm3" in P else P.ff_norm.g, P.norm3.b if "norm3" in P else P.ff_norm.b)
             g = ops.geglu(ln, P.ff.w1, P.ff.b1)
         ops.gemm(g, P.ff.out.w, P.ff.out.b, residual=hs, out=hs)
+    return None
 
 
 def audio_kv(P, ehs):
@@ -304,8 +314,9 @@ def _spatial_transformer_read(P, x, *, b, f, H, W, heads, groups, ehs, bank, w_r
                 ops.gemm(a, ops.proj_weight(a, P.attn2.out.w), P.attn2.out.b, residual=hb, alpha=w_aud, out=hb,
                          stats_out=sb if f_ff else None)
     # 3. feed-forward (:247)
-    _feed_forward(P, h, st if f_ff else None)
-    out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x2d, gn=(groups, hw))      # read next by the motion module's norm
+    out = _feed_forward(P, h, st if f_ff else None, proj=(x2d, (groups, hw)))
+    if out is None:
+        out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x2d, gn=(groups, hw))  # read next by the motion module's norm
     return ops.keep_gn(out.view(frames, hw, c), out)
 
 
@@ -390,10 +401,20 @@ def _motion_module(P, x, *, b, f, H, W, heads, groups, shard=None, gn_next=False
         ops.gemm(a, ops.proj_weight(a, A.attn.out.w), A.attn.out.b, residual=h, out=h,
                  stats_out=st if wants[i + 1] else None)
         have_st = wants[i + 1]
-    _feed_forward(P, h, st if folds[-1] and have_st else None)
-    if shard is not None:
-        h = shard.to_frame_shard(h.view(b * f_all, hw_t, c), b, f).view(frames * hw, c)
-    out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x.view(frames * hw, c), gn=(groups, hw) if gn_next else None)
+    # proj_out folded into the feed-forward's second linear (weights.fold_ff_proj).  Frame shards: the folded GEMM runs in the
+    # pixel-shard layout into FLOAT32 (accumulator + bias, exactly what the unsharded epilogue holds before its residual
+    # add), those rows go through the all-to-all, and the residual add + the one rounding happen in the frame-shard layout
+    # (ops.add_residual_f32): the same bits as the unsharded launch, for twice the bytes of one all-to-all.
+    out = _feed_forward(P, h, st if folds[-1] and have_st else None,
+                        proj=((None if shard is not None else x.view(frames * hw, c)),
+                              ((groups, hw) if gn_next and shard is None else None)) if ops.FF_PROJ_FOLD_MM[0] else None)
+    if out is not None and shard is not None:
+        y32 = shard.to_frame_shard(out.view(b * f_all, hw_t, c), b, f).view(frames * hw, c)
+        out = ops.add_residual_f32(x.view(frames * hw, c), y32)
+    elif out is None:
+        if shard is not None:
+            h = shard.to_frame_shard(h.view(b * f_all, hw_t, c), b, f).view(frames * hw, c)
+        out = ops.gemm(h, P.proj_out.w, P.proj_out.b, residual=x.view(frames * hw, c), gn=(groups, hw) if gn_next else None)
     return ops.keep_gn(out.view(frames, hw, c), out)
 
 

@@ -19,6 +19,22 @@ __global__ void add_row_bias_kernel(bf16_t* x, int ldx, int rows, int c, const f
   *reinterpret_cast<uint4*>(p) = pack_bf16x8(f);
 }
 
+// out[r, :] = element(x[r, :] + y[r, :]), y float32: the last two steps of vx_gemm's STORE epilogue (v += residual; round)
+// on an accumulator row that travelled as float32 (frame-sharded motion module: blocks._motion_module)
+__global__ void add_residual_f32_kernel(const bf16_t* x, int ldx, const float* y, int ldy, int rows, int c, bf16_t* out, int ldo) {
+  const int cch = c >> 3;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * cch) return;
+  int row = (int)(idx / cch), ch = (int)(idx % cch) * 8;
+  float f[8];
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(x + (size_t)row * ldx + ch), f);
+  const float4 a = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + ch);
+  const float4 b = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + ch + 4);
+  f[0] = a.x + f[0]; f[1] = a.y + f[1]; f[2] = a.z + f[2]; f[3] = a.w + f[3];
+  f[4] = b.x + f[4]; f[5] = b.y + f[5]; f[6] = b.z + f[6]; f[7] = b.w + f[7];
+  *reinterpret_cast<uint4*>(out + (size_t)row * ldo + ch) = pack_bf16x8(f);
+}
+
 // latents fp32 [1, C, F, hw] -> out bf16 [reps*f, hw, c_pad]
 __global__ void gather_latents_kernel(const float* latents, int c, int total_frames, int hw, const int32_t* frame_ids,
                                       int f, int reps, int c_pad, bf16_t* out) {
@@ -233,6 +249,15 @@ extern "C" int vx_add_row_bias(void* x, int ldx, int rows, int c, const float* b
   hipLaunchKernelGGL(add_row_bias_kernel, grid1d((long)rows * (c / 8)), dim3(256), 0, (hipStream_t)stream,
                      (bf16_t*)x, ldx, rows, c, bias, alpha);
   return vx_check_launch("vx_add_row_bias");
+}
+
+extern "C" int vx_add_residual_f32(const void* x, int ldx, const float* y, int ldy, int rows, int c, void* out, int ldo,
+                                   void* stream) {
+  VX_REQUIRE(x && y && out && rows > 0 && c > 0 && (c % 8) == 0 && (ldx % 8) == 0 && (ldy % 4) == 0 && (ldo % 8) == 0,
+             "vx_add_residual_f32: bad arguments");
+  hipLaunchKernelGGL(add_residual_f32_kernel, grid1d((long)rows * (c / 8)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, y, ldy, rows, c, (bf16_t*)out, ldo);
+  return vx_check_launch("vx_add_residual_f32");
 }
 
 extern "C" int vx_gather_latents(const float* latents, int c, int total_frames, int hw, const int32_t* frame_ids,

@@ -1113,6 +1113,26 @@ def small_kv_attention(q, kv, *, batch, n_q, n_kv, heads, head_dim, out=None):
     return out
 
 
+# proj_out folded into the feed-forward's second linear (weights.fold_ff_proj, round 6): out = [h | g] [Wp | Wp W2]^T + b +
+# x_in as ONE dual-source GEMM of K = 5C.  VX_FF_PROJ_FOLD=0 restores the two launches (A/B knob); VX_FF_PROJ_FOLD_MIN_HW:
+# smallest frame (rows) that takes the fold - at the 8x8 level the K = 6400 launch is a split-K launch, which cannot leave
+# the next GroupNorm's partial sums.
+FF_PROJ_FOLD = [os.environ.get("VX_FF_PROJ_FOLD", "1") != "0"]
+FF_PROJ_FOLD_MIN_HW = [int(os.environ.get("VX_FF_PROJ_FOLD_MIN_HW", "256"))]
+FF_PROJ_FOLD_MM = [os.environ.get("VX_FF_PROJ_FOLD_MM", "1") != "0"]      # the motion modules' blocks as well (A/B knob)
+
+
+def ff_proj_fold_applies(m, c, hidden):
+    """Batch-independent: the rows of one frame (ops.frame_rows), the widths and the switch."""
+    hw = _FRAME_ROWS[0]
+    geom = (("c", c), ("hidden", hidden), ("hw", hw))
+    one, two = "FF output GEMM + proj_out as one dual-source GEMM (K = 5C)", "two launches (FF output GEMM, proj_out)"
+    if not FF_PROJ_FOLD[0] or FP8_PROJ[0]:
+        return _note_path("ff_proj_out", geom, False, two, "switched off / fp8 projections")
+    ok = hw is not None and hw >= FF_PROJ_FOLD_MIN_HW[0] and c % 64 == 0 and hidden % 64 == 0
+    return _note_path("ff_proj_out", geom, ok, one if ok else two, "" if ok else "frame below VX_FF_PROJ_FOLD_MIN_HW rows")
+
+
 # The audio cross-attention of a spatial transformer block as ONE streaming launch (vx_audio_xattn, round 6): five audio
 # tokens per frame -> q-projection, 5-key attention and out-projection collapse into two 48-column products with per-frame
 # operands built once per clip (vx_audio_xattn_pack).  VX_AX_FUSED=0 restores the three launches (A/B knob).
@@ -1193,6 +1213,22 @@ def add_row_bias(x, bias, alpha=1.0):
     L.check(_lib.vx_add_row_bias(_ptr(x), ldx, rows, x.shape[-1], _ptr(bias), float(alpha), _stream()),
             "vx_add_row_bias")
     return x
+
+
+def add_residual_f32(x, y32, out=None):
+    """element(x + y32): x [rows, C] elements, y32 [rows, C] float32 (a GEMM's out_f32 rows) -> [rows, C] elements - the
+    residual add and the one rounding of vx_gemm's STORE epilogue, for rows that travelled as float32 in between."""
+    _chk_bf16(x, "x")
+    if y32.dtype != torch.float32 or y32.shape != x.shape or y32.stride(-1) != 1:
+        raise TypeError("add_residual_f32: y32 must be float32 of x's shape")
+    ldx, rows = _row_stride(x)
+    ldy, _ = _row_stride(y32)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=L.ELEM[0])
+    L.check(_lib.vx_add_residual_f32(_ptr(x), ldx, _ptr(y32), ldy, rows, x.shape[-1], _ptr(out), _row_stride(out)[0], _stream()),
+            "vx_add_residual_f32")
+    _set_gn(out)
+    return out
 
 
 def gather_latents(latents, frame_ids, reps, c_pad=8):

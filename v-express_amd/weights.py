@@ -117,6 +117,25 @@ def fold_layernorm(w_src, bias, gamma, beta, device, row_scale=None, interleave=
     return Prepared(w=w.contiguous(), s=colsum.contiguous(), b=b.contiguous())
 
 
+def fold_ff_proj(sd, ff_out, proj_out, device):
+    """The block's proj_out folded into the feed-forward's second linear (round 6).  A transformer block ends with
+        h' = h + W2 g + b2   (FeedForward.net.2 + residual),      out = Wp h' + bp + x_in   (proj_out + residual)
+    and nothing else reads h' (modules/transformer_3d.py:150-169, modules/motion_module.py:172-182), so
+        out = [h | g] [Wp | Wp W2]^T + (bp + Wp b2) + x_in
+    is ONE dual-source GEMM of K = C + 4C instead of two launches with the [rows, C] tensor h' written and read back.
+    w = bf16([Wp | Wp W2]) (the product in float32, ONE rounding), b = bp + Wp b2 (float32)."""
+    w2 = sd[ff_out + ".weight"].detach().to(device=device, dtype=torch.float32)
+    b2 = sd[ff_out + ".bias"].detach().to(device=device, dtype=torch.float32)
+    wp = sd[proj_out + ".weight"].detach().to(device=device, dtype=torch.float32)
+    if wp.dim() == 4:
+        wp = wp.reshape(wp.shape[0], wp.shape[1])
+    b = wp @ b2
+    if (proj_out + ".bias") in sd:
+        b = b + sd[proj_out + ".bias"].detach().to(device=device, dtype=torch.float32)
+    w = torch.cat([wp, wp @ w2], dim=1).to(L.ELEM[0])
+    return Prepared(w=w.contiguous(), b=b.contiguous())
+
+
 def fold_groupnorm(w_src, bias, gamma, beta, device):
     """A GroupNorm WITHOUT activation folded into the 1x1 / linear layer that consumes it (ops.groupnorm_fold_linear):
     the frame-independent parts - the bf16 weight the per-frame copies are scaled from, gamma, and
@@ -218,6 +237,7 @@ def prep_spatial_read(sd, p, device, heads=None):
     # the block's GroupNorm (no activation) folded into proj_in (used where ops.gn_fold_applies says so)
     P["gn_fold"] = fold_groupnorm(sd[p + ".proj_in.weight"], sd.get(p + ".proj_in.bias"), sd[p + ".norm.weight"],
                                   sd[p + ".norm.bias"], device)
+    P["ff_proj"] = fold_ff_proj(sd, t + ".ff.net.2", p + ".proj_out", device)
     return P
 
 
@@ -252,4 +272,5 @@ def prep_motion(sd, p, device):
                                 sd[b + ".ff_norm.weight"], sd[b + ".ff_norm.bias"], device, interleave=True)
     P["gn_fold"] = fold_groupnorm(sd[t + ".proj_in.weight"], sd.get(t + ".proj_in.bias"), sd[t + ".norm.weight"],
                                   sd[t + ".norm.bias"], device)
+    P["ff_proj"] = fold_ff_proj(sd, b + ".ff.net.2", t + ".proj_out", device)
     return P
