@@ -26,7 +26,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for r in rows:
     k = r.get("Kernel_Name", "")
     if not any(t in k for t in ("tblock_kernel", "ff_fused_kernel", "attn3_kernel", "gemm_ring_kernel<1", "true, true>(",
-                                "gemm_ring_kernel<0, false, false, false, false, true, false>")): continue
+                                "gemm_ring_kernel<0, false, false, false, false, true, false>", "axattn", "gemm_kernel<128, 160, 2, 2, 2, 0, true, false, false, false>")): continue
     k = k.replace("(anonymous namespace)::", "")[:84]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
 for k, d in sorted(agg.items()):
