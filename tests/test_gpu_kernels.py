@@ -406,11 +406,14 @@ def test_flash_attention_prescaled_keys(ops):
 
 
 def test_key_norm_max(ops):
-    for kvb, heads, n, d in ((3, 8, 100, 40), (1, 8, 4096, 40), (2, 4, 7, 64)):
+    # (8 heads and >= 512 keys: the row-coalesced kernel with the atomic maximum, incl. a ragged last block and a table that
+    # held larger values before the call; everything else: one block per (batch, head))
+    for kvb, heads, n, d in ((3, 8, 100, 40), (1, 8, 4096, 40), (2, 4, 7, 64), (5, 8, 1000, 40), (2, 8, 1024, 80), (3, 8, 513, 160)):
         k = rnd(kvb * n, heads * d, seed=n)
         got = ops.key_norm_max(k, kv_batches=kvb, heads=heads, n_kv=n, head_dim=d)
         ref = k.float().view(kvb, n, heads, d).norm(dim=-1).amax(dim=1).reshape(-1)
         assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6), (got, ref)
+        assert torch.equal(got, ops.key_norm_max(k, kv_batches=kvb, heads=heads, n_kv=n, head_dim=d))
 
 
 @pytest.mark.parametrize("qs,ks,spike", [(1.0, 1.0, 0.0), (6.0, 6.0, 0.0), (25.0, 25.0, 0.0), (1.0, 1.0, 300.0),

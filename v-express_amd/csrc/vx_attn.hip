@@ -904,6 +904,45 @@ __global__ __launch_bounds__(256) void key_norm_max_kernel(const bf16_t* __restr
   if (threadIdx.x == 0) out[bh] = sqrtf(red[0]);
 }
 
+// The same table for EIGHT heads from whole rows (round 6).  The kernel above gives a thread one key's head slice: a wave's
+// load touches 64 different rows, and the 32 KB L1 must hold every line until the slice's other chunks are read - at 4 waves
+// per CU that works (2 TB/s), with more waves or more keys per thread in flight it thrashes (1.3 TB/s: profiles/r06w_*,
+// r06x_*).  Here a wave reads 8 keys x 8 heads: lane = (key l >> 3, head l & 7), the five 16-byte chunks of its slice back to
+// back, so a wave consumes eight whole rows (5 KB) at a time; a block = 256 keys of one kv batch, all heads; the block maxima
+// meet in the table through an integer atomic maximum (the table is zeroed first; squared norms are non-negative floats, whose
+// bit patterns order like the values, and a maximum does not depend on the order: same bits as the kernel above).
+constexpr int KNM8_KEYS = 256;
+__global__ __launch_bounds__(256) void key_norm_max8_kernel(const bf16_t* __restrict__ k, int ldk, int n_kv, int d,
+                                                            float* __restrict__ out) {
+  __shared__ float red[4][8];
+  const int b = blockIdx.y, key0 = blockIdx.x * KNM8_KEYS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane & 7;
+  const bf16_t* base = k + (size_t)b * n_kv * ldk + h * d;
+  const int chunks = d >> 3;
+  float best = 0.f;
+  for (int kk = wave * 8 + (lane >> 3); kk < KNM8_KEYS; kk += 32) {
+    const int key = min(key0 + kk, n_kv - 1);                     // (clamped: a repeated key does not change the maximum)
+    const bf16_t* row = base + (size_t)key * ldk;
+    float ss = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+      float f[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(row + 8 * c), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+    }
+    best = fmaxf(best, ss);
+  }
+  best = fmaxf(best, __shfl_xor(best, 8, 64));
+  best = fmaxf(best, __shfl_xor(best, 16, 64));
+  best = fmaxf(best, __shfl_xor(best, 32, 64));
+  if (lane < 8) red[wave][lane] = best;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const float m = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+    atomicMax(reinterpret_cast<unsigned int*>(out) + b * 8 + threadIdx.x, __float_as_uint(sqrtf(m)));
+  }
+}
+
 int attention_impl(const void* q, int ldq, const void* k, int ldk, const void* vt, int vt_pitch, void* out, int ldo,
                    int batch, int heads, int n_q, int n_kv, int head_dim, int q_per_kv, float scale,
                    const float* key_norm_max, hipStream_t stream);
@@ -921,6 +960,21 @@ extern "C" int vx_key_norm_max(const void* k, int ldk, int kv_batches, int heads
   VX_REQUIRE(k && out, "vx_key_norm_max: null pointer");
   VX_REQUIRE(kv_batches > 0 && heads > 0 && n_kv > 0 && head_dim > 0 && (head_dim % 8) == 0 && (ldk % 8) == 0,
              "vx_key_norm_max: bad sizes (head_dim=%d ldk=%d)", head_dim, ldk);
+  static int v8 = -1;
+  if (v8 < 0) {
+    const char* e = getenv("VX_KNM8");            // A/B knob: 0 = always the one-block-per-(batch, head) kernel
+    v8 = !(e && atoi(e) == 0);
+  }
+  if (v8 && heads == 8 && n_kv >= 2 * KNM8_KEYS && kv_batches <= 65535) {
+    // (short key sets - the 8x8 level, the audio tokens - keep the plain kernel: one block each is all they need)
+    if (hipMemsetAsync(out, 0, (size_t)kv_batches * heads * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+      vx_set_error("vx_key_norm_max: hipMemsetAsync failed");
+      return VX_ERR_HIP;
+    }
+    hipLaunchKernelGGL(key_norm_max8_kernel, dim3((n_kv + KNM8_KEYS - 1) / KNM8_KEYS, kv_batches), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)k, ldk, n_kv, head_dim, out);
+    return vx_check_launch("vx_key_norm_max");
+  }
   hipLaunchKernelGGL(key_norm_max_kernel, dim3(kv_batches * heads), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)k, ldk, heads, n_kv, head_dim, out);
   return vx_check_launch("vx_key_norm_max");
