@@ -391,6 +391,16 @@ int vx_add_row_bias(void* x, int ldx, int rows, int c, const float* bias, float 
  * pixel-shard layout, its float32 rows go through the all-to-all, and the residual add happens in the frame-shard layout
  * with the bits of the unsharded launch. */
 int vx_add_residual_f32(const void* x, int ldx, const float* y, int ldy, int rows, int c, void* out, int ldo, void* stream);
+/* Nearest-2x upsampling + 3x3 convolution (Upsample3D, modules/resnet.py:53-90; diffusers Upsample2D of the VAE decoder) as
+ * FOUR 2x2 convolutions over the ORIGINAL image (round 6, ABI 15): output pixel (2y + a, 2x + b) sees only a 2x2 neighbourhood
+ * of the input, with the 3x3 taps that land on the same input pixel added up (weights.fold_upsample_phases: float32 sums, one
+ * rounding) - 16 instead of 36 tap products per input pixel, 2.25x fewer FLOPs than the convolution over the upsampled image.
+ * vx_pad_image copies x [frames, h, w, c] into the interior of a zero-bordered [frames, h + 2, w + 2, c] image (border kept zero
+ * by the caller), the four phases run as pad-0 2x2 vx_gemm launches over it (A pointer advanced by (a (w + 2) + b) pixels,
+ * h_out = h, w_out = w), vx_pixel_shuffle2x interleaves their outputs (phases[a * 2 + b] at phases + (a * 2 + b) * phase_stride
+ * elements, each [frames, h, w, c]) into out [frames, 2h, 2w, c]. */
+int vx_pad_image(const void* x, int frames, int h, int w, int c, void* out, void* stream);
+int vx_pixel_shuffle2x(const void* phases, int64_t phase_stride, int frames, int h, int w, int c, void* out, void* stream);
 /* gather window frames of the fp32 latent clip [1,C,F,h,w] into NHWC bf16 [reps*f, h*w, c_pad] (channels >= C zero).
  * Replaces latents[:, :, context].repeat(2,...) + rearrange (pipelines/v_express_pipeline.py:538-539, resnet.py:13). */
 int vx_gather_latents(const float* latents, int c, int total_frames, int hw, const int32_t* frame_ids, int f,

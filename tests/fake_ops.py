@@ -371,6 +371,20 @@ def audio_xattn(h, stats, fold, bias_o, alpha, *, rows_per_frame, stats_out=None
     return dst
 
 
+def upsample_conv_phases(x, w_phases, bias, *, frames, H, W):
+    """ops.upsample_conv_phases: four pad-0 2x2 convolutions over the zero-bordered image (float64 accumulate, + bias, one
+    rounding per phase output) interleaved into the 2H x 2W image."""
+    cin, cout = x.shape[-1], w_phases.shape[1]
+    xp = F.pad(x.double().reshape(frames, H, W, cin).permute(0, 3, 1, 2), (1, 1, 1, 1))
+    out = torch.empty((frames, 2 * H, 2 * W, cout), dtype=BF16)
+    for a in (0, 1):
+        for b in (0, 1):
+            w = w_phases[a * 2 + b].double().reshape(cout, 2, 2, cin).permute(0, 3, 1, 2)
+            y = F.conv2d(xp[:, :, a:a + H + 1, b:b + W + 1], w) + bias.double()[None, :, None, None]
+            out[:, a::2, b::2] = y.float().to(BF16).permute(0, 2, 3, 1)
+    return out.reshape(frames, 4 * H * W, cout)
+
+
 def add_residual_f32(x, y32, out=None):
     """vx_add_residual_f32: the residual add (float32) and the one rounding of the STORE epilogue."""
     assert y32.dtype == torch.float32 and y32.shape == x.shape
@@ -448,7 +462,7 @@ def vae_postprocess(x, n, c, h, w):
 
 
 ALL = ("wave_conv1d", "groupnorm", "groupnorm_stats", "groupnorm_fold_linear", "layernorm", "row_stats", "layernorm_fp8", "quantize_fp8", "gemm", "geglu", "ff_fused", "tblock_fused", "alloc_vt", "gemm_split", "key_norm_max", "attention",
-       "temporal_attention", "small_kv_attention", "audio_xattn_pack", "audio_xattn", "add_residual_f32", "add_row_bias", "gather_latents", "cfg_combine", "pack_rows", "combine_units", "overlap_ddim_step",
+       "temporal_attention", "small_kv_attention", "audio_xattn_pack", "audio_xattn", "upsample_conv_phases", "add_residual_f32", "add_row_bias", "gather_latents", "cfg_combine", "pack_rows", "combine_units", "overlap_ddim_step",
        "ncfhw_to_nhwc", "nhwc_to_ncfhw", "vae_postprocess")
 
 

@@ -477,6 +477,31 @@ def test_small_kv_attention(ops, batch, n_q, n_kv, heads, d):
     check(out, ref, f"small-kv attention n_kv={n_kv} d={d}", rel=1e-2, mx=2 ** -6)
 
 
+@pytest.mark.parametrize("frames,H,W,cin,cout,items", [(4, 32, 32, 640, 640, 2), (2, 16, 16, 1280, 1280, 2), (3, 16, 24, 128, 64, 3),
+                                                       (2, 64, 64, 512, 512, 2)])
+def test_upsample_conv_as_four_phase_convolutions(ops, frames, H, W, cin, cout, items):
+    """weights.fold_upsample_phases + ops.upsample_conv_phases (nearest-2x upsampling + conv3x3 as four 2x2 convolutions over
+    the original image: Upsample3D, modules/resnet.py:53-90) against F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"))
+    in fp32 on the same rounded inputs; and the four launches of a subset of the items have the bits of the batched call."""
+    from v_express_amd import weights
+    g_ = torch.Generator().manual_seed(cin + H)
+    wt = torch.randn(cout, cin, 3, 3, generator=g_) * (9 * cin) ** -0.5
+    bias = torch.randn(cout, generator=g_) * 0.1
+    Pw = weights.fold_upsample_phases({"u.weight": wt, "u.bias": bias}, "u", "cuda")
+    assert tuple(Pw.w.shape) == (4, cout, 4 * cin)
+    x = rnd(frames, H * W, cin)
+    with ops.frame_rows(H * W, items=items):
+        out = ops.upsample_conv_phases(x, Pw.w, Pw.b, frames=frames, H=H, W=W)
+    xi = x.float().view(frames, H, W, cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(F.interpolate(xi, scale_factor=2.0, mode="nearest"), wt.to(BF).float().cuda(), bias.cuda(), padding=1)
+    check(out, ref.permute(0, 2, 3, 1).reshape(frames, 4 * H * W, cout), f"upsample conv phases {H}x{W} {cin}->{cout}", rel=8e-3, mx=2 ** -6)
+    per = frames // items
+    if per and frames % items == 0 and items > 1:
+        with ops.frame_rows(H * W, items=1):
+            one = ops.upsample_conv_phases(x[:per].contiguous(), Pw.w, Pw.b, frames=per, H=H, W=W)
+        assert torch.equal(one, out[:per])
+
+
 @pytest.mark.parametrize("m,c,hw", [(8192, 640, 1024), (2048, 1280, 256)])
 def test_ff_proj_fold_dual_source_gemm(ops, m, c, hw):
     """weights.fold_ff_proj: a transformer block's proj_out folded into the feed-forward's second linear -

@@ -35,6 +35,38 @@ __global__ void add_residual_f32_kernel(const bf16_t* x, int ldx, const float* y
   *reinterpret_cast<uint4*>(out + (size_t)row * ldo + ch) = pack_bf16x8(f);
 }
 
+// x [frames, H, W, C] -> the interior of the zero-bordered image out [frames, H + 2, W + 2, C] (the border is the caller's to
+// keep zero); one 16-byte chunk per thread
+__global__ void pad_image_kernel(const bf16_t* __restrict__ x, int H, int W, int c8, bf16_t* __restrict__ out, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ch = (int)(idx % c8);
+  long px = idx / c8;
+  const int xx = (int)(px % W);
+  px /= W;
+  const int yy = (int)(px % H);
+  const long f = px / H;
+  const long dst = ((f * (H + 2) + yy + 1) * (W + 2) + xx + 1) * c8 + ch;
+  reinterpret_cast<uint4*>(out)[dst] = reinterpret_cast<const uint4*>(x)[idx];
+}
+
+// the four phase images ph[a][b] [frames, H, W, C] (phase_stride 16-byte chunks apart) -> out [frames, 2H, 2W, C] with
+// out[f, 2y + a, 2x + b] = ph[a][b][f, y, x]; indexed by the OUTPUT chunk (coalesced stores; a pixel's C channels are one
+// contiguous run on both sides)
+__global__ void pixel_shuffle2_kernel(const bf16_t* __restrict__ ph, long phase_stride, int H, int W, int c8,
+                                      bf16_t* __restrict__ out, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ch = (int)(idx % c8);
+  long px = idx / c8;
+  const int ox = (int)(px % (2 * W));
+  px /= 2 * W;
+  const int oy = (int)(px % (2 * H));
+  const long f = px / (2 * H);
+  const long src = (long)((oy & 1) * 2 + (ox & 1)) * phase_stride + ((f * H + (oy >> 1)) * W + (ox >> 1)) * c8 + ch;
+  reinterpret_cast<uint4*>(out)[idx] = reinterpret_cast<const uint4*>(ph)[src];
+}
+
 // latents fp32 [1, C, F, hw] -> out bf16 [reps*f, hw, c_pad]
 __global__ void gather_latents_kernel(const float* latents, int c, int total_frames, int hw, const int32_t* frame_ids,
                                       int f, int reps, int c_pad, bf16_t* out) {
@@ -258,6 +290,24 @@ extern "C" int vx_add_residual_f32(const void* x, int ldx, const float* y, int l
   hipLaunchKernelGGL(add_residual_f32_kernel, grid1d((long)rows * (c / 8)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, ldx, y, ldy, rows, c, (bf16_t*)out, ldo);
   return vx_check_launch("vx_add_residual_f32");
+}
+
+extern "C" int vx_pad_image(const void* x, int frames, int h, int w, int c, void* out, void* stream) {
+  VX_REQUIRE(x && out && frames > 0 && h > 0 && w > 0 && c > 0 && (c % 8) == 0, "vx_pad_image: bad arguments");
+  const long total = (long)frames * h * w * (c / 8);
+  hipLaunchKernelGGL(pad_image_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, h, w, c / 8,
+                     (bf16_t*)out, total);
+  return vx_check_launch("vx_pad_image");
+}
+
+extern "C" int vx_pixel_shuffle2x(const void* phases, int64_t phase_stride, int frames, int h, int w, int c, void* out,
+                                  void* stream) {
+  VX_REQUIRE(phases && out && frames > 0 && h > 0 && w > 0 && c > 0 && (c % 8) == 0 && (phase_stride % 8) == 0 &&
+                 phase_stride >= (int64_t)frames * h * w * c, "vx_pixel_shuffle2x: bad arguments");
+  const long total = (long)frames * 4 * h * w * (c / 8);
+  hipLaunchKernelGGL(pixel_shuffle2_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)phases,
+                     (long)(phase_stride / 8), h, w, c / 8, (bf16_t*)out, total);
+  return vx_check_launch("vx_pixel_shuffle2x");
 }
 
 extern "C" int vx_gather_latents(const float* latents, int c, int total_frames, int hw, const int32_t* frame_ids,

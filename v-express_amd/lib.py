@@ -153,6 +153,8 @@ def _load(path=None, element="bf16"):
     lib.vx_small_kv_attention.argtypes = [vp, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp]
     lib.vx_add_row_bias.argtypes = [vp, i32, i32, i32, vp, f32, vp]
     lib.vx_add_residual_f32.argtypes = [vp, i32, vp, i32, i32, i32, vp, i32, vp]
+    lib.vx_pad_image.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.vx_pixel_shuffle2x.argtypes = [vp, i64, i32, i32, i32, i32, vp, vp]
     lib.vx_gather_latents.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, vp, vp]
     lib.vx_cfg_combine.argtypes = [vp, i32, i32, i32, i32, f32, vp, vp]
     lib.vx_pack_rows.argtypes = [vp, i32, i64, i32, vp, vp]

@@ -233,7 +233,7 @@ def _row_stride(t):
 class ConvGeom:
     """Geometry of an implicit-GEMM convolution over NHWC frames."""
 
-    def __init__(self, nb, h_in, w_in, kh=1, kw=1, stride=1, pad=0, upsample=0, pad_end=0):
+    def __init__(self, nb, h_in, w_in, kh=1, kw=1, stride=1, pad=0, upsample=0, pad_end=0, out_hw=None):
         """pad: zero padding before AND after each spatial axis; pad_end: extra zero padding after only
         (diffusers Downsample2D(padding=0): F.pad(x, (0, 1, 0, 1)) + conv stride 2 -> pad=0, pad_end=1).  The
         kernel's gather zero-fills every tap that falls outside the stored image, so pad_end only changes the
@@ -243,6 +243,12 @@ class ConvGeom:
         he, we = h_in << upsample, w_in << upsample
         self.h_out = (he + 2 * pad + pad_end - kh) // stride + 1
         self.w_out = (we + 2 * pad + pad_end - kw) // stride + 1
+        if out_hw is not None:
+            # a sub-window of the valid outputs (the caller advances the A pointer to the window's first input pixel:
+            # ops.gemm(a_pixel_offset=...)); it must lie inside the stored image
+            if out_hw[0] > self.h_out or out_hw[1] > self.w_out or pad or upsample or pad_end:
+                raise ValueError("out_hw must be a sub-window of a pad-0 convolution's outputs")
+            self.h_out, self.w_out = out_hw
 
     @property
     def m(self):
@@ -674,7 +680,8 @@ def _ring_coop(p, device):
 
 
 def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L.VX_ACT_NONE, rowbias=None,
-         rows_per_group=0, out=None, out_f32=False, ln=None, stats_out=None, stats_eps=1e-5, w_group_rows=0, gn=None):
+         rows_per_group=0, out=None, out_f32=False, ln=None, stats_out=None, stats_eps=1e-5, w_group_rows=0, gn=None,
+         a_pixel_offset=0):
     """out[m, n] = residual + alpha * act(sum_k A[m,k] W[n,k] + bias[n] + rowbias[m // rows_per_group, n]).
     ln=(stats, colsum): a LayerNorm folded into this GEMM - the sum is replaced by rstd[m] * (sum - mean[m] * colsum[n])
     with `w`, `bias` the folded weight / bias of weights.fold_layernorm and `a` the un-normalised rows.
@@ -691,6 +698,13 @@ def gemm(a, w, bias=None, *, geom=None, a2=None, residual=None, alpha=1.0, act=L
         n_groups = w.shape[0]
         w = w.view(-1, w.shape[-1])
     p, geom = _base_params(a, w, geom, a2)
+    if a_pixel_offset:
+        # the convolution window starts `a_pixel_offset` pixels into every frame (ConvGeom(out_hw=...)): its last tap must
+        # stay inside the frame
+        last = a_pixel_offset + ((geom.h_out - 1) * geom.stride + geom.kh - 1) * geom.w_in + (geom.w_out - 1) * geom.stride + geom.kw - 1
+        if a2 is not None or a_pixel_offset < 0 or last >= geom.h_in * geom.w_in:
+            raise ValueError("a_pixel_offset: the shifted window leaves the frame")
+        p.a = a.data_ptr() + a_pixel_offset * p.lda1 * a.element_size()
     if w_group_rows:
         if p.m != n_groups * w_group_rows:
             raise ValueError(f"{n_groups} weight groups of {w_group_rows} rows do not cover m={p.m}")
@@ -1111,6 +1125,59 @@ def small_kv_attention(q, kv, *, batch, n_q, n_kv, heads, head_dim, out=None):
                                            n_kv, heads, head_dim, head_dim ** -0.5, _stream()),
                 "vx_small_kv_attention")
     return out
+
+
+# Nearest-2x upsampling + conv3x3 as four 2x2 convolutions over the original image (weights.fold_upsample_phases, round 6):
+# 2.25x fewer FLOPs than the convolution over the upsampled image.  VX_UPSAMPLE_PHASES=0 restores the one launch with the
+# upsampling fused into its gather (A/B knob); VX_UPSAMPLE_PHASES_MIN_HW: smallest INPUT frame (pixels) that takes the four
+# launches (below, the 2x2 launches are latency-bound split-K launches and the copies cost more than the FLOPs save).
+UPSAMPLE_PHASES = [os.environ.get("VX_UPSAMPLE_PHASES", "1") != "0"]
+UPSAMPLE_PHASES_MIN_HW = [int(os.environ.get("VX_UPSAMPLE_PHASES_MIN_HW", "256"))]
+
+
+def upsample_phases_applies(H, W, c):
+    geom = (("hw_in", H * W), ("c", c))
+    four, one = "four 2x2 convolutions over the original image + interleave", "one 3x3 convolution with the upsampling in its gather"
+    ok = UPSAMPLE_PHASES[0] and H * W >= UPSAMPLE_PHASES_MIN_HW[0] and c % 64 == 0
+    return _note_path("upsample_conv", geom, ok, four if ok else one,
+                      "" if ok else "switched off / input frame below VX_UPSAMPLE_PHASES_MIN_HW pixels / channels not a multiple of 64")
+
+
+def pad_image(x, frames, H, W):
+    """x [frames, H*W, C] -> the persistent zero-bordered image [frames, (H+2)*(W+2), C] of that shape (`padded_buffer`)."""
+    _chk_bf16(x, "x")
+    if not x.is_contiguous():
+        raise ValueError("pad_image: contiguous input")
+    c = x.shape[-1]
+    out = padded_buffer(x.device, frames, H, W, c)
+    L.check(_lib.vx_pad_image(_ptr(x), frames, H, W, c, _ptr(out), _stream()), "vx_pad_image")
+    return out
+
+
+def pixel_shuffle2x(phases, frames, H, W):
+    """phases [4, frames*H*W, C] (phase a * 2 + b) -> [frames, 2H*2W, C] with out[f, 2y + a, 2x + b] = phases[a * 2 + b][f, y, x]."""
+    _chk_bf16(phases, "phases")
+    if phases.dim() != 3 or phases.shape[0] != 4 or phases.shape[1] != frames * H * W or not phases.is_contiguous():
+        raise ValueError("pixel_shuffle2x: phases must be a contiguous [4, frames*H*W, C] tensor")
+    c = phases.shape[-1]
+    out = torch.empty((frames, 4 * H * W, c), device=phases.device, dtype=L.ELEM[0])
+    L.check(_lib.vx_pixel_shuffle2x(_ptr(phases), phases.stride(0), frames, H, W, c, _ptr(out), _stream()), "vx_pixel_shuffle2x")
+    return out
+
+
+def upsample_conv_phases(x, w_phases, bias, *, frames, H, W):
+    """Upsample (nearest x2) + conv3x3 of x [frames, H*W, Cin] -> [frames, 2H*2W, Cout] through the four phase weights of
+    weights.fold_upsample_phases: one copy into the zero-bordered image, four pad-0 2x2 convolutions whose window starts
+    (a, b) pixels into it, one interleave."""
+    cout = w_phases.shape[1]
+    xp = pad_image(x, frames, H, W)
+    ph = torch.empty((4, frames * H * W, cout), device=x.device, dtype=L.ELEM[0])
+    g = ConvGeom(frames, H + 2, W + 2, 2, 2, 1, 0, out_hw=(H, W))
+    for a in (0, 1):
+        for b in (0, 1):
+            gemm(xp.view(frames * (H + 2) * (W + 2), -1), w_phases[a * 2 + b], bias, geom=g,
+                 a_pixel_offset=a * (W + 2) + b, out=ph[a * 2 + b])
+    return pixel_shuffle2x(ph, frames, H, W)
 
 
 # proj_out folded into the feed-forward's second linear (weights.fold_ff_proj, round 6): out = [h | g] [Wp | Wp W2]^T + b +

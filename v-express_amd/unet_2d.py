@@ -96,7 +96,7 @@ class UNet2DConditionModel(_UNetBase):
             if done:
                 break
             if blk["sampler"]:
-                x, h_, w_ = B.upsample(P[f"{p}.upsamplers.0"], x, frames, h_, w_)
+                x, h_, w_ = B.upsample(P[f"{p}.upsamplers.0"], x, frames, h_, w_, items=frames)
         self.banks = banks
         out = torch.zeros_like(sample)
         return (out,) if not return_dict else type("UNet2DConditionOutput", (), {"sample": out})()

@@ -129,6 +129,8 @@ class _UNetBase(DeviceModule):
             if blk["sampler"]:
                 name = "downsamplers" if p.startswith("down") else "upsamplers"
                 P[f"{p}.{name}.0"] = Wt.prep_conv(sd, f"{p}.{name}.0.conv", dev)
+                if name == "upsamplers":
+                    P[f"{p}.{name}.0"]["phases"] = Wt.fold_upsample_phases(sd, f"{p}.{name}.0.conv", dev)
         add_resnet("mid_block.resnets.0")
         P["mid_block.attentions.0"] = spatial(sd, "mid_block.attentions.0", dev, cfg.heads)
         if self.THREE_D:
@@ -304,7 +306,7 @@ class UNet3DConditionModel(_UNetBase):
                 x = layer(p, j, blk["attn"], x, skip,
                           gn_next=(bi_ == len(plan["up"]) - 1 and j == len(blk["layers"]) - 1 and not blk["sampler"]))
             if blk["sampler"]:
-                x, h_, w_ = B.upsample(P[f"{p}.upsamplers.0"], x, frames, h_, w_)
+                x, h_, w_ = B.upsample(P[f"{p}.upsamplers.0"], x, frames, h_, w_, items=b)
         n = ops.groupnorm(x, P.conv_norm_out.g, P.conv_norm_out.b, frames=frames, hw=hw, groups=g, eps=eps, silu=True,
                           pad_hw=(H, W))
         return ops.gemm(n.view(frames * (H + 2) * (W + 2), -1), P.conv_out.w, P.conv_out.b,

@@ -65,6 +65,7 @@ class AutoencoderKLDecoder(DeviceModule):
                 P[f"up.{i}.resnets.{j}"] = Wt.prep_resnet(sd, f"decoder.up_blocks.{i}.resnets.{j}", dev)
             if i != n - 1:
                 P[f"up.{i}.upsampler"] = Wt.prep_conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", dev)
+                P[f"up.{i}.upsampler"]["phases"] = Wt.fold_upsample_phases(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", dev)
         P["norm_out"] = Wt.prep_norm(sd, "decoder.conv_norm_out", dev)
         P["conv_out"] = Wt.prep_conv(sd, "decoder.conv_out", dev)
         self._P = P
@@ -92,7 +93,7 @@ class AutoencoderKLDecoder(DeviceModule):
             for j in range(cfg.layers_per_block + 1):
                 x = B.resnet_block(P[f"up.{i}.resnets.{j}"], x, n, H, W, groups=g, eps=1e-6)
             if i != nb - 1:
-                x, H, W = B.upsample(P[f"up.{i}.upsampler"], x, n, H, W)
+                x, H, W = B.upsample(P[f"up.{i}.upsampler"], x, n, H, W, items=n)
         hw = H * W
         nrm = ops.groupnorm(x, P.norm_out.g, P.norm_out.b, frames=n, hw=hw, groups=g, eps=1e-6, silu=True,
                             pad_hw=(H, W))

@@ -55,6 +55,32 @@ def prep_conv(sd, p, device, cin_pad=None, cout_pad=None):
     return Prepared(w=wp.reshape(cout_p, kh * kw * cin_p).to(L.ELEM[0]).contiguous(), b=b, k=kh, cout=cout)
 
 
+def fold_upsample_phases(sd, p, device):
+    """Nearest-2x upsampling + conv3x3 as four 2x2 convolutions over the original image (ops.upsample_conv_phases): output
+    pixel (2y + a, 2x + b) reads input rows {y - 1 + a, y + a} and columns {x - 1 + b, x + b}; the 3x3 taps that land on the same
+    input pixel are added in float32 and rounded once.  Rows: a = 0 -> {ky 0 | ky 1 + 2}, a = 1 -> {ky 0 + 1 | ky 2}; columns
+    alike.  -> Prepared(w=[4 phases (a * 2 + b), Cout, 2 * 2 * Cin] elements, b=bias float32)."""
+    w = sd[p + ".weight"].detach().to(device=device, dtype=torch.float32)          # [Cout, Cin, 3, 3]
+    cout, cin, kh, kw = w.shape
+    if (kh, kw) != (3, 3) or cin % 8 or cout % 8:
+        return None
+    rows = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+    phases = []
+    for a in (0, 1):
+        for b in (0, 1):
+            wp = torch.zeros((cout, 2, 2, cin), device=device, dtype=torch.float32)
+            for dy, kys in enumerate(rows[a]):
+                for dx, kxs in enumerate(rows[b]):
+                    for ky in kys:
+                        for kx in kxs:
+                            wp[:, dy, dx, :] += w[:, :, ky, kx]
+            phases.append(wp.reshape(cout, 4 * cin))
+    bias = torch.zeros(cout, device=device, dtype=torch.float32)
+    if (p + ".bias") in sd:
+        bias = sd[p + ".bias"].detach().to(device=device, dtype=torch.float32)
+    return Prepared(w=torch.stack(phases).to(L.ELEM[0]).contiguous(), b=bias.contiguous())
+
+
 def prep_linear(sd, p, device):
     w = _dev(sd[p + ".weight"], device, L.ELEM[0])
     if w.dim() == 4:     # 1x1 conv stored as [Cout, Cin, 1, 1]
